@@ -1,0 +1,247 @@
+"""ctypes binding of the C-ABI in ``include/catint_pnp.h`` (the drop-in boundary).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``catint_amd.build.build_library()`` into ``catint_amd/lib/libcatint_pnp.so``.  There is no
+CPU fallback: if the library is missing, or no HIP device is visible, the transport path
+raises (``PnpLibraryError`` / ``PnpError``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libcatint_pnp.so')
+
+PNP_MAX_SPECIES = 16
+PNP_MAX_REACTIONS = 16
+PNP_MAX_REACTANTS = 4
+
+METHOD_CRANK_NICOLSON = 0
+METHOD_FTCS = 1
+METHODS = {'Crank-Nicolson': METHOD_CRANK_NICOLSON, 'FTCS': METHOD_FTCS}
+
+PB_DD, PB_VWALL_GBULK, PB_GWALL_VBULK, PB_VWALL_GWALL, PB_VBULK_GBULK = range(5)
+
+STATUS_OK, STATUS_NAN, STATUS_NEGATIVE = 0, 2, 3
+
+# every symbol include/catint_pnp.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    'pnp_create', 'pnp_destroy', 'pnp_last_error', 'pnp_version', 'pnp_set_species', 'pnp_set_reactions',
+    'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_get_state',
+    'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
+    'pnp_device_bytes', 'pnp_row_pitch',
+]
+
+
+class PnpLibraryError(RuntimeError):
+    pass
+
+
+class PnpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('catint_pnp error %d: %s' % (code, msg))
+        self.code = code
+
+
+class PnpConfig(C.Structure):
+    _fields_ = [
+        ('struct_size', C.c_int32), ('device', C.c_int32), ('nspecies', C.c_int32), ('nx', C.c_int32),
+        ('method', C.c_int32), ('pb_mode', C.c_int32), ('lax_friedrich', C.c_int32), ('use_migration', C.c_int32),
+        ('batch_capacity', C.c_int64), ('dx', C.c_double), ('dt', C.c_double), ('beta', C.c_double),
+        ('eps', C.c_double),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library; raises PnpLibraryError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PnpLibraryError(
+            'HIP extension %s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback for the transport path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    lib.pnp_create.argtypes = [C.POINTER(PnpConfig), C.POINTER(vp)]
+    lib.pnp_create.restype = C.c_int
+    lib.pnp_destroy.argtypes = [vp]
+    lib.pnp_destroy.restype = None
+    lib.pnp_last_error.argtypes = [vp]
+    lib.pnp_last_error.restype = C.c_char_p
+    lib.pnp_version.argtypes = []
+    lib.pnp_version.restype = C.c_char_p
+    lib.pnp_set_species.argtypes = [vp, dp, dp]
+    lib.pnp_set_reactions.argtypes = [vp, C.c_int32, ip, ip, ip, ip, dp, dp]
+    lib.pnp_set_batch.argtypes = [vp, C.c_int64, dp, dp, dp, dp]
+    lib.pnp_set_flux.argtypes = [vp, dp]
+    lib.pnp_set_pb.argtypes = [vp, dp, dp]
+    lib.pnp_step.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.pnp_integrate.argtypes = [vp, C.c_int32, ip, C.c_int32, dp, ip]
+    lib.pnp_get_state.argtypes = [vp, dp, dp, dp, dp]
+    lib.pnp_get_surface.argtypes = [vp, dp, dp, dp]
+    lib.pnp_get_status.argtypes = [vp, ip]
+    lib.pnp_synchronize.argtypes = [vp]
+    lib.pnp_timer_start.argtypes = [vp]
+    lib.pnp_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    for name in ('pnp_set_species', 'pnp_set_reactions', 'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step',
+                 'pnp_integrate', 'pnp_get_state', 'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize',
+                 'pnp_timer_start', 'pnp_timer_stop'):
+        getattr(lib, name).restype = C.c_int
+    lib.pnp_device_bytes.argtypes = [vp]
+    lib.pnp_device_bytes.restype = C.c_int64
+    lib.pnp_row_pitch.argtypes = [vp]
+    lib.pnp_row_pitch.restype = C.c_int32
+    _lib = lib
+    return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError('expected shape %s, got %s' % (tuple(shape), a.shape))
+    return a
+
+
+class PnpSolver(object):
+    """Thin object wrapper over one ``pnp_handle`` (one GPU)."""
+
+    def __init__(self, nspecies, nx, dx, dt, beta, eps, D, charges, method='Crank-Nicolson', pb_mode=PB_DD,
+                 lax_friedrich=False, use_migration=True, batch_capacity=1, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        if method not in METHODS:
+            raise PnpError(-1, 'No calculator found with this name: %r' % (method,))
+        cfg = PnpConfig(C.sizeof(PnpConfig), int(device), int(nspecies), int(nx), METHODS[method], int(pb_mode),
+                        int(bool(lax_friedrich)), int(bool(use_migration)), int(batch_capacity), float(dx), float(dt),
+                        float(beta), float(eps))
+        rc = self._lib.pnp_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.pnp_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise PnpError(rc, msg)
+        self.N, self.nx, self.B = int(nspecies), int(nx), 0
+        self.method = method
+        self._check(self._lib.pnp_set_species(self._h, _dptr(_f64(D, (self.N,))), _dptr(_f64(charges, (self.N,)))))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PnpError(rc, self._lib.pnp_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.pnp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- parameters ------------------------------------------------------------------------
+    def set_reactions(self, reactions):
+        """reactions: list of (lhs_indices, rhs_indices, kf, kr) in the reference's dict order."""
+        n = len(reactions)
+        n_lhs = np.zeros(max(n, 1), np.int32)
+        n_rhs = np.zeros(max(n, 1), np.int32)
+        lhs = np.zeros((max(n, 1), PNP_MAX_REACTANTS), np.int32)
+        rhs = np.zeros((max(n, 1), PNP_MAX_REACTANTS), np.int32)
+        kf = np.zeros(max(n, 1))
+        kr = np.zeros(max(n, 1))
+        for r, (l, rr, f, b) in enumerate(reactions):
+            if len(l) > PNP_MAX_REACTANTS or len(rr) > PNP_MAX_REACTANTS:
+                raise PnpError(-1, 'too many reactants in reaction %d' % r)
+            n_lhs[r], n_rhs[r] = len(l), len(rr)
+            lhs[r, :len(l)] = l
+            rhs[r, :len(rr)] = rr
+            kf[r], kr[r] = f, b
+        self._check(self._lib.pnp_set_reactions(self._h, n, _iptr(n_lhs), _iptr(lhs), _iptr(n_rhs), _iptr(rhs),
+                                                _dptr(kf), _dptr(kr)))
+
+    def set_batch(self, c0, pb, vzeta, flux):
+        c0 = np.ascontiguousarray(c0, dtype=np.float64)
+        B = c0.shape[0]
+        c0 = _f64(c0.reshape(B, self.N, self.nx))
+        pb = np.nan_to_num(_f64(pb, (B, 4)), nan=0.0)
+        self._check(self._lib.pnp_set_batch(self._h, B, _dptr(c0), _dptr(pb), _dptr(_f64(vzeta, (B,))),
+                                            _dptr(_f64(flux, (B, self.N)))))
+        self.B = B
+
+    def set_flux(self, flux):
+        self._check(self._lib.pnp_set_flux(self._h, _dptr(_f64(flux, (self.B, self.N)))))
+
+    def set_pb(self, pb, vzeta):
+        pb = np.nan_to_num(_f64(pb, (self.B, 4)), nan=0.0)
+        self._check(self._lib.pnp_set_pb(self._h, _dptr(pb), _dptr(_f64(vzeta, (self.B,)))))
+
+    # -- hot path --------------------------------------------------------------------------
+    def step(self, nsteps=1, steps_per_launch=0):
+        self._check(self._lib.pnp_step(self._h, int(nsteps), int(steps_per_launch)))
+
+    def integrate(self, nt, itout):
+        """Reference loop + outputs: returns (cout[n_out, B, N*nx], status[B])."""
+        itout = np.ascontiguousarray(itout, dtype=np.int32)
+        cout = np.zeros((len(itout), self.B, self.N * self.nx))
+        status = np.zeros(self.B, np.int32)
+        self._check(self._lib.pnp_integrate(self._h, int(nt), _iptr(itout), len(itout), _dptr(cout), _iptr(status)))
+        return cout, status
+
+    # -- read-back -------------------------------------------------------------------------
+    def get_state(self, potential=True):
+        c = np.zeros((self.B, self.N, self.nx))
+        if potential:
+            v = np.zeros((self.B, self.nx)); g = np.zeros((self.B, self.nx)); l = np.zeros((self.B, self.nx))
+            self._check(self._lib.pnp_get_state(self._h, _dptr(c), _dptr(v), _dptr(g), _dptr(l)))
+            return c, v, g, l
+        self._check(self._lib.pnp_get_state(self._h, _dptr(c), None, None, None))
+        return c
+
+    def get_surface(self):
+        cs = np.zeros((self.B, self.N)); vs = np.zeros(self.B); es = np.zeros(self.B)
+        self._check(self._lib.pnp_get_surface(self._h, _dptr(cs), _dptr(vs), _dptr(es)))
+        return cs, vs, es
+
+    def get_status(self):
+        st = np.zeros(self.B, np.int32)
+        self._check(self._lib.pnp_get_status(self._h, _iptr(st)))
+        return st
+
+    def synchronize(self):
+        self._check(self._lib.pnp_synchronize(self._h))
+
+    def timer_start(self):
+        self._check(self._lib.pnp_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self._check(self._lib.pnp_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    @property
+    def device_bytes(self):
+        return int(self._lib.pnp_device_bytes(self._h))
+
+    @property
+    def row_pitch(self):
+        return int(self._lib.pnp_row_pitch(self._h))

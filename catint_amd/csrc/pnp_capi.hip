@@ -1,0 +1,422 @@
+// C-ABI of the batched PNP transport path (include/catint_pnp.h): handle, device buffers, the
+// integrate_pnp loop (reference catint/calculator_old.py:210, :512, :990) around the HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pnp_internal.h"
+
+using namespace pnp;
+
+struct pnp_handle {
+  pnp_config cfg;
+  DevArgs a;
+  ReactionTable rt;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int P = 0;
+  int64_t B = 0;
+  bool have_species = false, have_batch = false;
+  int64_t steps_done = 0;
+  // device buffers (capacity-sized)
+  double *c = nullptr, *lapl[2] = {nullptr, nullptr}, *v = nullptr, *gradv = nullptr, *rates = nullptr;
+  double *pb = nullptr, *vzeta = nullptr, *flux = nullptr, *cbulk = nullptr, *csurf = nullptr;
+  int32_t* status = nullptr;
+  int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
+  int64_t dev_bytes = 0;
+  std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(pnp_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(h, e_ == hipErrorOutOfMemory ? PNP_ENOMEM : PNP_EDEVICE,                    \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                         \
+  } while (0)
+
+template <typename T>
+static hipError_t dev_alloc(pnp_handle* h, T** p, size_t count) {
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e == hipSuccess) h->dev_bytes += (int64_t)(count * sizeof(T));
+  return e;
+}
+
+extern "C" {
+
+const char* pnp_version(void) { return "catint_pnp 0.1 (gfx950)"; }
+
+const char* pnp_last_error(const pnp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void pnp_destroy(pnp_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
+                  (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status})
+    if (p) hipFree(p);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int pnp_create(const pnp_config* cfg, pnp_handle** out) {
+  if (!cfg || !out) return fail(nullptr, PNP_EINVAL, "pnp_create: null argument");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(pnp_config))
+    return fail(nullptr, PNP_EINVAL, "pnp_create: pnp_config.struct_size mismatch (ABI)");
+  if (cfg->nspecies < 1 || cfg->nspecies > PNP_MAX_SPECIES)
+    return fail(nullptr, PNP_EINVAL, "pnp_create: nspecies out of range [1,16]");
+  const int P = points_per_lane(cfg->nx);
+  if (P == 0)
+    return fail(nullptr, PNP_EINVAL, "pnp_create: nx must be in [5, 1026] (one grid per wavefront, <=16 points per lane)");
+  if (cfg->method != PNP_METHOD_CRANK_NICOLSON && cfg->method != PNP_METHOD_FTCS)
+    return fail(nullptr, PNP_EINVAL, "pnp_create: no calculator found with this method");  // calculator_old.py:109-111
+  if (cfg->pb_mode < PNP_PB_DD || cfg->pb_mode > PNP_PB_VBULK_GBULK)
+    return fail(nullptr, PNP_EINVAL, "pnp_create: unsupported pb_bound combination");
+  if (cfg->method == PNP_METHOD_CRANK_NICOLSON && !cfg->use_migration)
+    return fail(nullptr, PNP_EINVAL,
+                "pnp_create: Crank-Nicolson needs use_migration (the reference reads an unbound 'v', calculator_old.py:514,529)");
+  if (cfg->batch_capacity < 1) return fail(nullptr, PNP_EINVAL, "pnp_create: batch_capacity < 1");
+  if (!(cfg->dx > 0) || !(cfg->dt > 0) || !(cfg->eps > 0) || !(cfg->beta > 0))
+    return fail(nullptr, PNP_EINVAL, "pnp_create: dx, dt, eps, beta must be positive");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, PNP_EDEVICE, "pnp_create: no HIP device visible (the transport path has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, PNP_EINVAL, "pnp_create: bad device ordinal");
+
+  pnp_handle* h = new pnp_handle();
+  h->cfg = *cfg;
+  h->P = P;
+  memset(&h->a, 0, sizeof(DevArgs));
+  memset(&h->rt, 0, sizeof(ReactionTable));
+  auto bail = [&](int code) {
+    g_create_error = h->err;
+    pnp_destroy(h);
+    return code;
+  };
+#define HIP_TRYC(expr)                                                                                  \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) {                                                                             \
+      h->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                       \
+      return bail(e_ == hipErrorOutOfMemory ? PNP_ENOMEM : PNP_EDEVICE);                                \
+    }                                                                                                   \
+  } while (0)
+  HIP_TRYC(hipSetDevice(cfg->device));
+  HIP_TRYC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_TRYC(hipEventCreate(&h->ev0));
+  HIP_TRYC(hipEventCreate(&h->ev1));
+  const int64_t Bc = cfg->batch_capacity;
+  const int N = cfg->nspecies;
+  const int ldx = (cfg->nx + 15) / 16 * 16;
+  HIP_TRYC(dev_alloc(h, &h->c, (size_t)Bc * N * ldx));
+  HIP_TRYC(dev_alloc(h, &h->lapl[0], (size_t)Bc * ldx));
+  HIP_TRYC(dev_alloc(h, &h->lapl[1], (size_t)Bc * ldx));
+  HIP_TRYC(dev_alloc(h, &h->pb, (size_t)Bc * 4));
+  HIP_TRYC(dev_alloc(h, &h->vzeta, (size_t)Bc));
+  HIP_TRYC(dev_alloc(h, &h->flux, (size_t)Bc * N));
+  HIP_TRYC(dev_alloc(h, &h->cbulk, (size_t)Bc * N));
+  HIP_TRYC(dev_alloc(h, &h->csurf, (size_t)Bc * N));
+  HIP_TRYC(dev_alloc(h, &h->status, (size_t)Bc));
+#undef HIP_TRYC
+  DevArgs& a = h->a;
+  a.N = N;
+  a.nx = cfg->nx;
+  a.m = cfg->nx - 2;
+  a.ldx = ldx;
+  a.pb_mode = cfg->pb_mode;
+  a.method = cfg->method;
+  a.lf = cfg->lax_friedrich ? 1 : 0;
+  a.use_mig = cfg->use_migration ? 1 : 0;
+  a.nsteps = 1;
+  a.has_rates = 0;
+  a.B = 0;
+  a.dx = cfg->dx;
+  a.dt = cfg->dt;
+  a.beta = cfg->beta;
+  a.eps = cfg->eps;
+  a.c = h->c;
+  a.pb = h->pb;
+  a.vzeta = h->vzeta;
+  a.flux = h->flux;
+  a.cbulk = h->cbulk;
+  a.status = h->status;
+  a.rates = nullptr;
+  *out = h;
+  return PNP_OK;
+}
+
+int pnp_set_species(pnp_handle* h, const double* D, const double* charges) {
+  if (!h || !D || !charges) return fail(h, PNP_EINVAL, "pnp_set_species: null argument");
+  for (int k = 0; k < h->a.N; ++k) {
+    if (!(D[k] >= 0) || !std::isfinite(charges[k])) return fail(h, PNP_EINVAL, "pnp_set_species: bad D or charge");
+    h->a.D[k] = D[k];
+    h->a.q[k] = charges[k];
+  }
+  h->have_species = true;
+  return PNP_OK;
+}
+
+int pnp_set_reactions(pnp_handle* h, int32_t nreactions, const int32_t* n_lhs, const int32_t* lhs, const int32_t* n_rhs,
+                      const int32_t* rhs, const double* kf, const double* kr) {
+  if (!h) return PNP_EINVAL;
+  if (nreactions < 0 || nreactions > PNP_MAX_REACTIONS) return fail(h, PNP_EINVAL, "pnp_set_reactions: too many reactions");
+  if (nreactions > 0 && h->cfg.method != PNP_METHOD_FTCS)
+    return fail(h, PNP_EINVAL, "pnp_set_reactions: only FTCS has a rate term (calculator_old.py:1022; CN has none)");
+  ReactionTable& rt = h->rt;
+  memset(&rt, 0, sizeof(rt));
+  rt.n = nreactions;
+  for (int r = 0; r < nreactions; ++r) {
+    if (n_lhs[r] < 0 || n_lhs[r] > PNP_MAX_REACTANTS || n_rhs[r] < 0 || n_rhs[r] > PNP_MAX_REACTANTS)
+      return fail(h, PNP_EINVAL, "pnp_set_reactions: too many reactants");
+    rt.n_lhs[r] = n_lhs[r];
+    rt.n_rhs[r] = n_rhs[r];
+    for (int j = 0; j < n_lhs[r]; ++j) {
+      const int k = lhs[r * PNP_MAX_REACTANTS + j];
+      if (k < 0 || k >= h->a.N) return fail(h, PNP_EINVAL, "pnp_set_reactions: species index out of range");
+      rt.lhs[r][j] = k;
+    }
+    for (int j = 0; j < n_rhs[r]; ++j) {
+      const int k = rhs[r * PNP_MAX_REACTANTS + j];
+      if (k < 0 || k >= h->a.N) return fail(h, PNP_EINVAL, "pnp_set_reactions: species index out of range");
+      rt.rhs[r][j] = k;
+    }
+    rt.kf[r] = kf[r];
+    rt.kr[r] = kr[r];
+  }
+  if (nreactions > 0 && !h->rates) {
+    hipSetDevice(h->cfg.device);
+    HIP_TRY(h, dev_alloc(h, &h->rates, (size_t)h->cfg.batch_capacity * h->a.N * h->a.ldx));
+    HIP_TRY(h, hipMemsetAsync(h->rates, 0, (size_t)h->cfg.batch_capacity * h->a.N * h->a.ldx * sizeof(double), h->stream));
+  }
+  h->a.has_rates = nreactions > 0 ? 1 : 0;
+  h->a.rates = h->rates;
+  return PNP_OK;
+}
+
+int pnp_set_flux(pnp_handle* h, const double* flux) {
+  if (!h || !flux) return fail(h, PNP_EINVAL, "pnp_set_flux: null argument");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_set_flux: call pnp_set_batch first");
+  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipMemcpyAsync(h->flux, flux, (size_t)h->B * h->a.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
+int pnp_set_pb(pnp_handle* h, const double* pb, const double* vzeta) {
+  if (!h || !pb || !vzeta) return fail(h, PNP_EINVAL, "pnp_set_pb: null argument");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_set_pb: call pnp_set_batch first");
+  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipMemcpyAsync(h->pb, pb, (size_t)h->B * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->vzeta, vzeta, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
+int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, const double* vzeta, const double* flux) {
+  if (!h || !c0 || !pb || !vzeta || !flux) return fail(h, PNP_EINVAL, "pnp_set_batch: null argument");
+  if (!h->have_species) return fail(h, PNP_ESTATE, "pnp_set_batch: call pnp_set_species first");
+  if (B < 1 || B > h->cfg.batch_capacity) return fail(h, PNP_EINVAL, "pnp_set_batch: B outside [1, batch_capacity]");
+  hipSetDevice(h->cfg.device);
+  const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
+  h->B = B;
+  h->a.B = B;
+  // pads of the pitched rows must be zero (they travel through the kernels untouched)
+  HIP_TRY(h, hipMemsetAsync(h->c, 0, (size_t)B * N * ldx * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemcpy2DAsync(h->c, (size_t)ldx * sizeof(double), c0, (size_t)nx * sizeof(double), (size_t)nx * sizeof(double),
+                              (size_t)B * N, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->pb, pb, (size_t)B * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->vzeta, vzeta, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->flux, flux, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // bulk Dirichlet values = last grid point of the initial state (calculator_old.py:540)
+  HIP_TRY(h, hipMemcpy2DAsync(h->cbulk, sizeof(double), c0 + (nx - 1), (size_t)nx * sizeof(double), sizeof(double), (size_t)B * N,
+                              hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->status, 0, (size_t)B * sizeof(int32_t), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->lapl[1], 0, (size_t)B * ldx * sizeof(double), h->stream));
+  h->cur = 0;
+  HIP_TRY(h, launch_charge_row(h->a, h->lapl[0], h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->have_batch = true;
+  h->steps_done = 0;
+  return PNP_OK;
+}
+
+// one or more fused timesteps in a single launch
+static int run_steps(pnp_handle* h, int nsteps) {
+  DevArgs a = h->a;
+  a.nsteps = nsteps;
+  a.lapl_a = h->lapl[h->cur];
+  a.lapl_b = h->lapl[1 - h->cur];
+  if (a.has_rates) {
+    if (nsteps != 1) return fail(h, PNP_EINVAL, "internal: rate terms need one step per launch");
+    HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
+  }
+  HIP_TRY(h, launch_step(a, h->stream));
+  if (nsteps & 1) h->cur = 1 - h->cur;
+  h->steps_done += nsteps;
+  return PNP_OK;
+}
+
+int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch) {
+  if (!h) return PNP_EINVAL;
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_step: call pnp_set_batch first");
+  if (nsteps < 0) return fail(h, PNP_EINVAL, "pnp_step: nsteps < 0");
+  hipSetDevice(h->cfg.device);
+  int spl = steps_per_launch <= 0 ? 64 : steps_per_launch;
+  if (h->a.has_rates) spl = 1;
+  int left = nsteps;
+  while (left > 0) {
+    const int n = left < spl ? left : spl;
+    const int rc = run_steps(h, n);
+    if (rc != PNP_OK) return rc;
+    left -= n;
+  }
+  return PNP_OK;
+}
+
+int pnp_integrate(pnp_handle* h, int32_t nt, const int32_t* itout, int32_t n_out, double* cout, int32_t* status) {
+  if (!h) return PNP_EINVAL;
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_integrate: call pnp_set_batch first");
+  if (nt < 1 || n_out < 0 || (n_out > 0 && (!itout || !cout))) return fail(h, PNP_EINVAL, "pnp_integrate: bad arguments");
+  hipSetDevice(h->cfg.device);
+  const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
+  const int64_t B = h->B;
+  // CN: for n in range(1,nt) (calculator_old.py:512);  FTCS: for n in range(0,nt) (:990)
+  const int n_first = (h->cfg.method == PNP_METHOD_CRANK_NICOLSON) ? 1 : 0;
+  int n = n_first;  // index of the next loop pass to run
+  for (int io = 0; io <= n_out; ++io) {
+    int target;  // run passes n .. target (inclusive)
+    if (io < n_out) {
+      target = itout[io];
+      if (target < n || target > nt - 1) {
+        if (target < n_first) continue;  // an output index the loop never visits (e.g. CN n=0)
+        return fail(h, PNP_EINVAL, "pnp_integrate: itout must be ascending and < nt");
+      }
+    } else {
+      target = nt - 1;
+    }
+    const int todo = target - n + 1;
+    if (todo > 0) {
+      const int rc = pnp_step(h, todo, 0);
+      if (rc != PNP_OK) return rc;
+      n = target + 1;
+    }
+    if (io < n_out) {
+      double* dst = cout + (size_t)io * B * N * nx;
+      HIP_TRY(h, hipMemcpy2DAsync(dst, (size_t)nx * sizeof(double), h->c, (size_t)ldx * sizeof(double), (size_t)nx * sizeof(double),
+                                  (size_t)B * N, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (status) return pnp_get_status(h, status);
+  return PNP_OK;
+}
+
+static int ensure_potential_buffers(pnp_handle* h) {
+  if (!h->v) {
+    HIP_TRY(h, dev_alloc(h, &h->v, (size_t)h->cfg.batch_capacity * h->a.ldx));
+    HIP_TRY(h, dev_alloc(h, &h->gradv, (size_t)h->cfg.batch_capacity * h->a.ldx));
+  }
+  return PNP_OK;
+}
+
+int pnp_get_state(pnp_handle* h, double* c, double* v, double* grad_v, double* lapl_v) {
+  if (!h) return PNP_EINVAL;
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_get_state: call pnp_set_batch first");
+  hipSetDevice(h->cfg.device);
+  const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
+  const int64_t B = h->B;
+  const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
+  if (c) HIP_TRY(h, hipMemcpy2DAsync(c, w, h->c, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, h->stream));
+  // Poisson solve of the most recent step used the lagged row; before any step it is the initial row
+  const double* lagged = (h->steps_done > 0) ? h->lapl[1 - h->cur] : h->lapl[h->cur];
+  if (v || grad_v) {
+    const int rc = ensure_potential_buffers(h);
+    if (rc != PNP_OK) return rc;
+    HIP_TRY(h, launch_poisson(h->a, lagged, h->v, h->gradv, h->stream));
+    if (v) HIP_TRY(h, hipMemcpy2DAsync(v, w, h->v, dp, w, (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (grad_v) HIP_TRY(h, hipMemcpy2DAsync(grad_v, w, h->gradv, dp, w, (size_t)B, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (lapl_v) HIP_TRY(h, hipMemcpy2DAsync(lapl_v, w, lagged, dp, w, (size_t)B, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
+int pnp_get_surface(pnp_handle* h, double* csurf, double* vsurf, double* esurf) {
+  if (!h) return PNP_EINVAL;
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_get_surface: call pnp_set_batch first");
+  hipSetDevice(h->cfg.device);
+  const int64_t B = h->B;
+  const int ldx = h->a.ldx;
+  if (csurf) {
+    HIP_TRY(h, launch_surface(h->a, h->csurf, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(csurf, h->csurf, (size_t)B * h->a.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  if (vsurf || esurf) {
+    const int rc = ensure_potential_buffers(h);
+    if (rc != PNP_OK) return rc;
+    const double* lagged = (h->steps_done > 0) ? h->lapl[1 - h->cur] : h->lapl[h->cur];
+    HIP_TRY(h, launch_poisson(h->a, lagged, h->v, h->gradv, h->stream));
+    const size_t dp = (size_t)ldx * sizeof(double);
+    if (vsurf) HIP_TRY(h, hipMemcpy2DAsync(vsurf, sizeof(double), h->v, dp, sizeof(double), (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (esurf) HIP_TRY(h, hipMemcpy2DAsync(esurf, sizeof(double), h->gradv, dp, sizeof(double), (size_t)B, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (esurf)
+    for (int64_t b = 0; b < B; ++b) esurf[b] = -esurf[b];  // tp.efield = -grad_v, calculator_old.py:816
+  return PNP_OK;
+}
+
+int pnp_get_status(pnp_handle* h, int32_t* status) {
+  if (!h || !status) return fail(h, PNP_EINVAL, "pnp_get_status: null argument");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_get_status: call pnp_set_batch first");
+  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipMemcpyAsync(status, h->status, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
+int pnp_synchronize(pnp_handle* h) {
+  if (!h) return PNP_EINVAL;
+  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
+int pnp_timer_start(pnp_handle* h) {
+  if (!h) return PNP_EINVAL;
+  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  return PNP_OK;
+}
+
+int pnp_timer_stop(pnp_handle* h, float* elapsed_ms) {
+  if (!h || !elapsed_ms) return fail(h, PNP_EINVAL, "pnp_timer_stop: null argument");
+  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(h, hipEventSynchronize(h->ev1));
+  HIP_TRY(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+  return PNP_OK;
+}
+
+int64_t pnp_device_bytes(const pnp_handle* h) { return h ? h->dev_bytes : 0; }
+int32_t pnp_row_pitch(const pnp_handle* h) { return h ? h->a.ldx : 0; }
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Internal declarations shared by the HIP kernels (pnp_kernels.hip) and the C-ABI
+// implementation (pnp_capi.hip).  gfx950 / MI355X only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/catint_pnp.h"
+
+namespace pnp {
+
+// Everything a wave needs to advance one operating point; passed by value as the kernel argument.
+struct DevArgs {
+  // sizes
+  int32_t N;         // species
+  int32_t nx;        // grid points incl. the two boundary points
+  int32_t m;         // nx-2 interior unknowns of every tridiagonal system
+  int32_t ldx;       // row pitch in doubles (multiple of 16 -> rows are 128-B aligned)
+  int32_t pb_mode;
+  int32_t method;
+  int32_t lf;
+  int32_t use_mig;
+  int32_t nsteps;    // timesteps fused into this launch
+  int32_t has_rates; // FTCS: add rates[b][k][i]*dt (computed by rates_kernel before the step)
+  int64_t B;
+  double dx, dt, beta, eps;
+  // per species (problem-wide)
+  double D[PNP_MAX_SPECIES];
+  double q[PNP_MAX_SPECIES];      // z*F
+  // state
+  double* c;          // [B][N][ldx]  concentrations, in place
+  double* lapl_a;     // [B][ldx]     -sum_k q_k c_k / eps: read by the first step of this launch
+  double* lapl_b;     // [B][ldx]     written by the first step (ping-pong with lapl_a)
+  const double* rates;  // [B][N][ldx] or null
+  // per lane
+  const double* pb;     // [B][4]
+  const double* vzeta;  // [B]
+  const double* flux;   // [B][N]
+  const double* cbulk;  // [B][N]   C0[k][nx-1]
+  int32_t* status;      // [B]
+};
+
+struct ReactionTable {
+  int32_t n;
+  int32_t n_lhs[PNP_MAX_REACTIONS];
+  int32_t n_rhs[PNP_MAX_REACTIONS];
+  int32_t lhs[PNP_MAX_REACTIONS][PNP_MAX_REACTANTS];
+  int32_t rhs[PNP_MAX_REACTIONS][PNP_MAX_REACTANTS];
+  double kf[PNP_MAX_REACTIONS];
+  double kr[PNP_MAX_REACTIONS];
+};
+
+// points-per-lane template instance that covers nx (interior m = nx-2 <= 64*P); 0 if unsupported
+int points_per_lane(int nx);
+size_t step_lds_bytes(int nx, int P);
+
+// launchers (all asynchronous on `stream`)
+hipError_t launch_step(const DevArgs& a, hipStream_t stream);
+// lapl[b][i] = -sum_k q_k c[b][k][i]/eps for all nx points (initial charge row, calculator_old.py:767-771)
+hipError_t launch_charge_row(const DevArgs& a, double* lapl, hipStream_t stream);
+// v, grad_v [B][ldx] from a lapl row (get_potential_and_gradient, calculator_old.py:773-803)
+hipError_t launch_poisson(const DevArgs& a, const double* lapl, double* v, double* gradv, hipStream_t stream);
+// rates[b][k][i] (get_rates, calculator_old.py:159-208)
+hipError_t launch_rates(const DevArgs& a, const ReactionTable& rt, double* rates, hipStream_t stream);
+// surface gather: csurf[B][N] = c[b][k][0]
+hipError_t launch_surface(const DevArgs& a, double* csurf, hipStream_t stream);
+
+}  // namespace pnp

@@ -1,0 +1,35 @@
+"""Host-side glue between problem descriptions and the C-ABI solver."""
+import numpy as np
+
+from ._capi import PnpSolver, PB_DD, PB_VWALL_GBULK, PB_GWALL_VBULK, PB_VWALL_GWALL, PB_VBULK_GBULK
+
+
+def pb_mode_from_bound(pb):
+    """pb = [potential wall, potential bulk, gradient wall, gradient bulk], NaN/None = unset
+    (reference tp.pb_bound, catint/transport.py:1296-1311; branch selection
+    catint/calculator_old.py:712-714, :776-803)."""
+    vw, vb, gw, gb = [x is not None and not np.isnan(x) for x in pb]
+    if gw and gb:
+        raise ValueError('Cannot use two boundary conditions for gradient')
+    if vw and vb:
+        return PB_DD
+    if vw and gb:
+        return PB_VWALL_GBULK
+    if gw and vb:
+        return PB_GWALL_VBULK
+    if vw and gw:
+        return PB_VWALL_GWALL
+    if vb and gb:
+        return PB_VBULK_GBULK
+    raise ValueError('unsupported pb_bound combination: %r' % (pb,))
+
+
+def solver_from_problem(p, method, batch_capacity=1, device=0):
+    """Build a PnpSolver from any object with the reference's per-problem fields
+    (D, charges, beta, eps, dx, nx, dt, pb, lax_friedrich, use_migration, reactions)."""
+    s = PnpSolver(nspecies=len(p.D), nx=p.nx, dx=p.dx, dt=p.dt, beta=p.beta, eps=p.eps, D=p.D, charges=p.charges,
+                  method=method, pb_mode=pb_mode_from_bound(p.pb), lax_friedrich=p.lax_friedrich,
+                  use_migration=p.use_migration, batch_capacity=batch_capacity, device=device)
+    if getattr(p, 'reactions', None):
+        s.set_reactions(p.reactions)
+    return s

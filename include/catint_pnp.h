@@ -1,0 +1,144 @@
+/*
+ * catint_pnp.h -- C-ABI of the MI355X-native batched 1D Poisson-Nernst-Planck transport path.
+ *
+ * This is the drop-in boundary for the ONE hot path of sringe/CatINT that this repository
+ * accelerates: the legacy finite-difference transport solve that sits under
+ * `Calculator.run_single_step` (reference catint/calculator.py:408; legacy numeric seam
+ * `Calculator.integrate_pnp(dx,nx,dt,nt,ntout,method)`, catint/calculator_old.py:210), batched
+ * over B independent operating points ("lanes": one (phiM, bulk concentrations, wall fluxes)
+ * tuple each -- the reference's descriptor loop calculator.py:204-212).
+ *
+ * Conventions
+ *   - plain C, no HIP/torch types; every pointer is a HOST pointer to C-contiguous fp64/int32
+ *     owned by the caller unless the name ends in _dev;
+ *   - host-visible layouts are the reference's: a state is species-major flat `c[k*nx+i]`
+ *     (calculator_old.py:508,562), batched as [B][N][nx];
+ *   - every entry point returns 0 on success or a negative PNP_E* code and never calls exit();
+ *     `pnp_last_error(h)` gives the message (replaces the reference's logger.error+sys.exit,
+ *     e.g. calculator_old.py:109-111, :712-714);
+ *   - the library owns the device buffers and one HIP stream behind the opaque handle; one
+ *     handle per GPU; calls on one handle are not thread-safe, distinct handles are independent;
+ *   - per-lane `status` replaces Comsol.check_error / the NaN test of calculator.py:409-414:
+ *     0 ok, 2 NaN/Inf in the state, 3 negative concentration.
+ */
+#ifndef CATINT_PNP_H
+#define CATINT_PNP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNP_MAX_SPECIES 16
+#define PNP_MAX_REACTIONS 16
+#define PNP_MAX_REACTANTS 4
+
+/* error codes */
+#define PNP_OK 0
+#define PNP_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define PNP_ENOMEM (-2)      /* device or host allocation failed */
+#define PNP_EDEVICE (-3)     /* HIP runtime error (no GPU, launch failure, ...) */
+#define PNP_ESTATE (-4)      /* call order violated (e.g. step before set_batch) */
+
+/* integrator, mirrors the reference's calculator names (calculator_old.py:107, :1121-1140) */
+#define PNP_METHOD_CRANK_NICOLSON 0   /* integrate_Crank_Nicolson, calculator_old.py:457-564 */
+#define PNP_METHOD_FTCS 1             /* integrate_FTCS,           calculator_old.py:976-1029 */
+
+/* Poisson boundary combination = which two slots of tp.pb_bound are set
+ * (transport.py:1296-1311; branches of get_potential_and_gradient calculator_old.py:776-803) */
+#define PNP_PB_DD 0            /* potential wall + potential bulk   (:780-786) */
+#define PNP_PB_VWALL_GBULK 1   /* potential wall + gradient bulk    (reference default, transport.py:207-210) */
+#define PNP_PB_GWALL_VBULK 2   /* gradient wall  + potential bulk */
+#define PNP_PB_VWALL_GWALL 3   /* potential wall + gradient wall */
+#define PNP_PB_VBULK_GBULK 4   /* potential bulk + gradient bulk */
+
+/* lane status */
+#define PNP_STATUS_OK 0
+#define PNP_STATUS_NAN 2
+#define PNP_STATUS_NEGATIVE 3
+
+typedef struct pnp_handle pnp_handle;
+
+/* Problem-wide configuration: what the reference keeps on `tp` and `Calculator` and that is
+ * shared by every operating point of a sweep. */
+typedef struct pnp_config {
+  int32_t struct_size;      /* = sizeof(pnp_config), ABI guard */
+  int32_t device;           /* HIP device ordinal */
+  int32_t nspecies;         /* N  = tp.nspecies          (transport.py:264) */
+  int32_t nx;               /* tp.nx, INCLUDING both boundary points (transport.py:459-460) */
+  int32_t method;           /* PNP_METHOD_* */
+  int32_t pb_mode;          /* PNP_PB_* */
+  int32_t lax_friedrich;    /* '--LF' suffix (calculator_old.py:95-105) */
+  int32_t use_migration;    /* tp.use_migration (transport.py:316-319) */
+  int64_t batch_capacity;   /* max number of operating points held on this GPU */
+  double dx;                /* tp.dx */
+  double dt;                /* tp.dt */
+  double beta;              /* tp.beta = 1/(R T)         (transport.py:312) */
+  double eps;               /* tp.eps  = eps_r*eps_0     (transport.py:311) */
+} pnp_config;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int pnp_create(const pnp_config* cfg, pnp_handle** out);
+void pnp_destroy(pnp_handle* h);
+const char* pnp_last_error(const pnp_handle* h); /* h may be NULL: last create() error */
+const char* pnp_version(void);
+
+/* ---- problem-wide parameters ------------------------------------------------------------ */
+/* D[N] = tp.D (m^2/s, transport.py:423-434); charges[N] = tp.charges = z*F (transport.py:1271). */
+int pnp_set_species(pnp_handle* h, const double* D, const double* charges);
+
+/* Mass-action source terms of get_rates (calculator_old.py:159-208), FTCS only.
+ * Reaction r: lhs[r*PNP_MAX_REACTANTS + j] (j < n_lhs[r]) and rhs[...] are species indices,
+ * kf[r], kr[r] = tp.reactions[r]['rates']. Order matters (the reference's overwrite quirk). */
+int pnp_set_reactions(pnp_handle* h, int32_t nreactions, const int32_t* n_lhs, const int32_t* lhs,
+                      const int32_t* n_rhs, const int32_t* rhs, const double* kf, const double* kr);
+
+/* ---- the batch of operating points ------------------------------------------------------- */
+/* c0[B][N][nx]   initial concentrations = tp.c0 per lane (transport.py:1396-1412); its last grid
+ *                point is also the bulk Dirichlet value C0[(k+1)*nx-1] (calculator_old.py:540)
+ * pb[B][4]       {potential wall, potential bulk, gradient wall, gradient bulk} = tp.pb_bound
+ *                (slots not selected by cfg.pb_mode are ignored)
+ * vzeta[B]       tp.system['vzeta'] (calculator_old.py:529)
+ * flux[B][N]     tp.flux_bound[k,0], wall flux (calculator_old.py:531, :1001)                  */
+int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, const double* vzeta,
+                  const double* flux);
+
+/* Update only the wall fluxes / wall potentials between SCF iterations (calculator.py:373-385). */
+int pnp_set_flux(pnp_handle* h, const double* flux /* [B][N] */);
+int pnp_set_pb(pnp_handle* h, const double* pb /* [B][4] */, const double* vzeta /* [B] */);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* Advance every lane by `nsteps` passes of the integrator's time-loop body. The state stays on
+ * the device. `steps_per_launch` <= 0 lets the library choose (fused multi-step launches);
+ * 1 forces one kernel launch per timestep with the full state read from and written to HBM. */
+int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch);
+
+/* integrate_pnp (calculator_old.py:210): runs the reference's loop (n = 1..nt-1 for CN,
+ * 0..nt-1 for FTCS) and copies the flattened state of every lane out at the steps listed in
+ * itout[n_out] (tp.itout, calculator_old.py:140-152; ascending).
+ * cout[n_out][B][N][nx]; status[B] (nullable). */
+int pnp_integrate(pnp_handle* h, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
+                  int32_t* status);
+
+/* ---- read-back ------------------------------------------------------------------------------ */
+/* Any pointer may be NULL. c[B][N][nx]; v, grad_v, lapl_v [B][nx] are the Poisson solve of the
+ * most recent step = tp.potential, -tp.efield, -tp.total_charge/eps (calculator_old.py:816-818). */
+int pnp_get_state(pnp_handle* h, double* c, double* v, double* grad_v, double* lapl_v);
+/* Surface observables consumed by the SCF loop (comsol_reader.py:205-207, :278-279):
+ * csurf[B][N] = c(x=0), vsurf[B] = v(x=0), esurf[B] = -grad_v(x=0). */
+int pnp_get_surface(pnp_handle* h, double* csurf, double* vsurf, double* esurf);
+int pnp_get_status(pnp_handle* h, int32_t* status /* [B] */);
+
+/* ---- measurement hooks (bench.py; HIP events on the handle's own stream) ---------------------- */
+int pnp_synchronize(pnp_handle* h);
+int pnp_timer_start(pnp_handle* h);
+int pnp_timer_stop(pnp_handle* h, float* elapsed_ms); /* synchronises the stream */
+/* bytes of device memory held, and the device row pitch (in doubles) of one species row */
+int64_t pnp_device_bytes(const pnp_handle* h);
+int32_t pnp_row_pitch(const pnp_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CATINT_PNP_H */
