@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched 1D PNP timestep path (BASELINE.json metric:
+"batched 1D PNP Newton-timesteps/sec at 1/2/4/8 GPU; achieved HBM GB/s vs peak").
+
+One "step" = one pass of the integrator's time-loop body (reference catint/calculator_old.py:512-558)
+over one batch of B operating points = ONE kernel launch that reads the full state (N concentration
+rows + the charge row) from HBM and writes it back (`steps_per_launch = 1`, i.e. "state written
+every step").  Workload at N=1: BASELINE.json configs[1] -- batch=1024
+operating points, 3 species, 512 grid points, fp64.  Multi-GPU: the batch shards embarrassingly
+(weak scaling: every rank owns `--batch` lanes), no collective in the timed region; one RCCL
+all_gather of the polarization observables afterwards.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=1024, help='operating points per GPU')
+    ap.add_argument('--nspecies', type=int, default=3)
+    ap.add_argument('--nx', type=int, default=512)
+    ap.add_argument('--method', default='Crank-Nicolson')
+    ap.add_argument('--steps-per-launch', type=int, default=1,
+                    help='1 = headline (state through HBM every step); >1 = fused steps, reported as extra')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline sample length')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fused', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(prob, c0, pb, vz, fl, method, target_s):
+    """The oracle (C port of the reference algorithm, Thomas solves) on all host cores."""
+    from oracle import c_oracle as CO
+    CO.load()
+    cores = CO.max_threads()
+    B = c0.shape[0]
+    N, nx = prob.N, prob.nx
+    c = c0.reshape(B, N, nx).copy()
+    # calibrate on a short run, then size the sample
+    t0 = time.perf_counter()
+    CO.steps(prob, method, c, pb, vz, fl, 5, want_potential=False)
+    t1 = time.perf_counter() - t0
+    rate = B * 5 / max(t1, 1e-9)
+    nsteps = int(max(10, min(5000, target_s * rate / B)))
+    c = c0.reshape(B, N, nx).copy()
+    t0 = time.perf_counter()
+    CO.steps(prob, method, c, pb, vz, fl, nsteps, want_potential=False)
+    dt = time.perf_counter() - t0
+    return {
+        'value': B * nsteps / dt, 'unit': 'timesteps/s', 'cores': cores, 'kind': 'port',
+        'sample': '%d lanes x %d steps of the same workload, C restatement (oracle/pnp_oracle.c, banded Thomas, OpenMP) '
+                  'in %.1f s' % (B, nsteps, dt),
+    }
+
+
+def cpu_reference_faithful(prob, c0, pb, vz, fl, method):
+    """dense np.linalg.solve per species, exactly the reference's arithmetic (oracle/pnp_ref.py) -- 1 core."""
+    from oracle import pnp_ref as R
+    p = R.Problem(D=prob.D, charges=prob.charges, beta=prob.beta, eps=prob.eps, dx=prob.dx, nx=prob.nx, dt=prob.dt,
+                  pb=pb[0], vzeta=float(vz[0]), flux_bound=fl[0])
+    C0 = c0[0].reshape(prob.N, prob.nx).copy()
+    C = C0.copy(); COLD = np.zeros_like(C)
+    n = 4
+    t0 = time.perf_counter()
+    for i in range(n):
+        R.cn_step(C, COLD, C0, p, first=(i == 0), solver='dense')
+    return n / (time.perf_counter() - t0)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (no CPU fallback for the transport path)')
+    torch.cuda.set_device(local_rank)
+
+    from catint_amd.synthetic import make_batch
+    from catint_amd.host import solver_from_problem
+    B, N, nx = args.batch, args.nspecies, args.nx
+    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=1000 + rank, phi_max=0.025, dt_factor=1e-4)
+    solver = solver_from_problem(prob, args.method, batch_capacity=B, device=local_rank)
+    solver.set_batch(c0, pb, vz, fl)
+
+    def barrier():
+        solver.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def timed(nsteps, spl):
+        barrier()
+        t0 = time.perf_counter()
+        solver.timer_start()
+        solver.step(nsteps, spl)
+        ev_ms = solver.timer_stop()
+        solver.synchronize()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([wall, ev_ms], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, ev_ms = float(t[0]), float(t[1])
+        return wall, ev_ms
+
+    # warmup, then restart from the initial state so the timed steps see a finite state
+    solver.step(args.warmup, args.steps_per_launch)
+    solver.set_batch(c0, pb, vz, fl)
+    wall, ev_ms = timed(args.steps, args.steps_per_launch)
+    status = solver.get_status()
+    n_launch = (args.steps + args.steps_per_launch - 1) // args.steps_per_launch
+    steps_total = world * B * args.steps
+    value = steps_total / wall
+
+    # fused-launch variant (state stays in L2/LDS between steps of one launch) -- extra, not the headline
+    fused = None
+    if not args.no_fused and args.steps_per_launch == 1:
+        solver.set_batch(c0, pb, vz, fl)
+        fw, fe = timed(args.steps, 0)
+        fused = {'timesteps_per_s': world * B * args.steps / fw, 'ms_per_step': fw / args.steps * 1e3,
+                 'steps_per_launch': 64}
+
+    # the only exchange of the path: gather the polarization observables (RCCL all_gather over xGMI)
+    cs, vs, es = solver.get_surface()
+    gather_ms = None
+    if dist is not None:
+        obs = torch.from_numpy(np.concatenate([cs, vs[:, None], es[:, None]], axis=1)).cuda()
+        out = torch.empty((world,) + tuple(obs.shape), dtype=obs.dtype, device='cuda')
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.all_gather_into_tensor(out, obs)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+
+    if rank == 0:
+        alg_bytes_per_launch = 16.0 * (N + 1) * nx * B * args.steps_per_launch   # 2*8*(N+1)*nx per point-step
+        launch_s = ev_ms * 1e-3 / n_launch
+        achieved = alg_bytes_per_launch / launch_s / 1e9
+        out = {
+            'metric': 'batched 1D PNP Newton-timesteps/sec', 'value': value, 'unit': 'timesteps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: batch=%d operating points/GPU, %d species, %d grid points, fp64, %s '
+                                   'compat integrator, Dirichlet-Dirichlet Poisson' % (B, N, nx, args.method),
+                       'batch_per_gpu': B, 'nspecies': N, 'nx': nx, 'steps_per_launch': args.steps_per_launch,
+                       'parallelism': 'batch-sharded x%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'pnp::step_kernel<%d>' % next(P for P in (1, 2, 4, 8, 16) if nx - 2 <= 64 * P),
+                         'launch_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg_bytes_per_launch},
+            'lanes_ok': int((status == 0).sum()), 'lanes_total': int(B),
+        }
+        if fused:
+            out['fused'] = fused
+        if gather_ms is not None:
+            out['gather_ms'] = gather_ms
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(prob, c0, pb, vz, fl, args.method, args.cpu_seconds)
+            if args.method == 'Crank-Nicolson':
+                cb['reference_faithful_dense_1core'] = cpu_reference_faithful(prob, c0, pb, vz, fl, args.method)
+            out['cpu_baseline'] = cb
+        print(json.dumps(out))
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
