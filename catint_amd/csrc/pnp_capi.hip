@@ -26,6 +26,8 @@ struct pnp_handle {
   // device buffers (capacity-sized)
   double *c = nullptr, *lapl[2] = {nullptr, nullptr}, *v = nullptr, *gradv = nullptr, *rates = nullptr;
   double *pb = nullptr, *vzeta = nullptr, *flux = nullptr, *cbulk = nullptr, *csurf = nullptr;
+  SpecConst* spec = nullptr;
+  int waves_override = 0;  // CATINT_PNP_WAVES_PER_GRID (tuning / tests)
   int32_t* status = nullptr;
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
   int64_t dev_bytes = 0;
@@ -66,7 +68,8 @@ void pnp_destroy(pnp_handle* h) {
   hipSetDevice(h->cfg.device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
-                  (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status})
+                  (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
+                  (void*)h->spec})
     if (p) hipFree(p);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -134,7 +137,9 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   HIP_TRYC(dev_alloc(h, &h->cbulk, (size_t)Bc * N));
   HIP_TRYC(dev_alloc(h, &h->csurf, (size_t)Bc * N));
   HIP_TRYC(dev_alloc(h, &h->status, (size_t)Bc));
+  HIP_TRYC(dev_alloc(h, &h->spec, (size_t)PNP_MAX_SPECIES));
 #undef HIP_TRYC
+  if (const char* e = getenv("CATINT_PNP_WAVES_PER_GRID")) h->waves_override = atoi(e);
   DevArgs& a = h->a;
   a.N = N;
   a.nx = cfg->nx;
@@ -157,6 +162,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   a.flux = h->flux;
   a.cbulk = h->cbulk;
   a.status = h->status;
+  a.spec = h->spec;
   a.rates = nullptr;
   *out = h;
   return PNP_OK;
@@ -164,11 +170,32 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
 
 int pnp_set_species(pnp_handle* h, const double* D, const double* charges) {
   if (!h || !D || !charges) return fail(h, PNP_EINVAL, "pnp_set_species: null argument");
+  SpecConst sc[PNP_MAX_SPECIES];
+  memset(sc, 0, sizeof(sc));
+  const double dx = h->a.dx, dt = h->a.dt, beta = h->a.beta, eps = h->a.eps;
   for (int k = 0; k < h->a.N; ++k) {
     if (!(D[k] >= 0) || !std::isfinite(charges[k])) return fail(h, PNP_EINVAL, "pnp_set_species: bad D or charge");
-    h->a.D[k] = D[k];
-    h->a.q[k] = charges[k];
+    SpecConst& S = sc[k];
+    S.D = D[k];
+    S.q = charges[k];
+    S.mu = D[k] * charges[k] * beta;                 // transport.py:436
+    S.sf = D[k] * dt / (dx * dx);                    // calculator_old.py:543 / :1013
+    S.s = S.sf;
+    if (h->a.lf) S.s += 0.5;                         // :544-546
+    S.hs = 0.5 * S.s;
+    S.ee = charges[k] * beta * dt * D[k];            // :547
+    S.e4 = S.ee / 4. / dx;
+    S.rdiag = 1.0 / (1.0 + S.s);
+    S.oms = 1 - S.s;
+    S.qe = charges[k] / eps;
+    S.twoD = 2 * D[k];
+    S.dm = dt / (2. * dx) * S.mu;                    // :1014
+    S.Mf = -2. * D[k] * dt / (dx * dx);              // :1015
+    if (!h->a.lf) S.Mf += 1;                         // :1021
   }
+  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipMemcpyAsync(h->spec, sc, sizeof(sc), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->have_species = true;
   return PNP_OK;
 }
@@ -267,7 +294,9 @@ static int run_steps(pnp_handle* h, int nsteps) {
     if (nsteps != 1) return fail(h, PNP_EINVAL, "internal: rate terms need one step per launch");
     HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
   }
-  HIP_TRY(h, launch_step(a, h->stream));
+  int W = choose_waves_per_grid(a.N, a.B);
+  if (h->waves_override >= 1 && h->waves_override <= 4) W = h->waves_override;
+  HIP_TRY(h, launch_step(a, W, h->stream));
   if (nsteps & 1) h->cur = 1 - h->cur;
   h->steps_done += nsteps;
   return PNP_OK;

@@ -7,9 +7,29 @@
 
 namespace pnp {
 
-// Everything a wave needs to advance one operating point; passed by value as the kernel argument.
+// Per-species constants, computed once on the host with the reference's expression order
+// (catint/calculator_old.py:543-547, :1013-1017; catint/transport.py:436) and read by the kernels
+// through scalar loads.
+struct SpecConst {
+  double D;      // tp.D[k]
+  double q;      // tp.charges[k] = z*F
+  double mu;     // D*q*beta                         transport.py:436
+  double s;      // D*dt/dx**2 (+0.5 with --LF)      calculator_old.py:543-546
+  double hs;     // 0.5*s
+  double ee;     // q*beta*dt*D                      :547
+  double e4;     // ee/4/dx      (add_field :486-490)
+  double rdiag;  // 1/(1+s)
+  double oms;    // 1-s
+  double qe;     // q/eps        (:770)
+  double twoD;   // 2*D
+  double sf;     // D*dt/dx**2   (FTCS :1013)
+  double dm;     // dt/(2*dx)*mu (FTCS :1014)
+  double Mf;     // FTCS centre weight after the LF handling (:1015, :1021)
+  double pad0, pad1;
+};
+
+// Everything a workgroup needs to advance one operating point; passed by value as the kernel argument.
 struct DevArgs {
-  // sizes
   int32_t N;         // species
   int32_t nx;        // grid points incl. the two boundary points
   int32_t m;         // nx-2 interior unknowns of every tridiagonal system
@@ -22,9 +42,7 @@ struct DevArgs {
   int32_t has_rates; // FTCS: add rates[b][k][i]*dt (computed by rates_kernel before the step)
   int64_t B;
   double dx, dt, beta, eps;
-  // per species (problem-wide)
-  double D[PNP_MAX_SPECIES];
-  double q[PNP_MAX_SPECIES];      // z*F
+  const SpecConst* spec;  // [N]
   // state
   double* c;          // [B][N][ldx]  concentrations, in place
   double* lapl_a;     // [B][ldx]     -sum_k q_k c_k / eps: read by the first step of this launch
@@ -50,10 +68,12 @@ struct ReactionTable {
 
 // points-per-lane template instance that covers nx (interior m = nx-2 <= 64*P); 0 if unsupported
 int points_per_lane(int nx);
-size_t step_lds_bytes(int nx, int P);
+// waves (species in flight) per operating point chosen for a batch of B lanes
+int choose_waves_per_grid(int N, int64_t B);
+size_t step_lds_bytes(int P, int W);
 
 // launchers (all asynchronous on `stream`)
-hipError_t launch_step(const DevArgs& a, hipStream_t stream);
+hipError_t launch_step(const DevArgs& a, int waves_per_grid, hipStream_t stream);
 // lapl[b][i] = -sum_k q_k c[b][k][i]/eps for all nx points (initial charge row, calculator_old.py:767-771)
 hipError_t launch_charge_row(const DevArgs& a, double* lapl, hipStream_t stream);
 // v, grad_v [B][ldx] from a lapl row (get_potential_and_gradient, calculator_old.py:773-803)

@@ -1,9 +1,12 @@
 // Hand-written gfx950 (MI355X / CDNA4) kernels for the batched 1D Poisson-Nernst-Planck timestep.
 //
-// Mapping: ONE 1D GRID PER WAVEFRONT.  A 64-lane wave owns one operating point;
-// lane l owns P consecutive interior unknowns r = l*P .. l*P+P-1 (grid points r+1) in registers.
-// Rows are streamed HBM -> (coalesced 16 B/lane) -> LDS -> (blocked, bank-conflict-free padded
-// layout) -> registers, one species at a time, so HBM sees exactly the algorithmic traffic:
+// Mapping: ONE 1D GRID PER WAVEFRONT.  A 64-lane wave owns one tridiagonal system
+// of one operating point; lane l owns P consecutive interior unknowns r = l*P .. l*P+P-1 (grid
+// points r+1) in registers.  A workgroup = W waves works on ONE operating point: wave w advances
+// species w, w+W, ... (the species solves of one timestep are independent because the reference
+// lags the potential), so small batches still fill the chip; W = 1 for large batches.
+// Rows stream HBM -> (coalesced 16 B/lane) -> LDS -> (blocked, bank-conflict-free padded layout)
+// -> registers and back, one species at a time, so HBM sees exactly the algorithmic traffic:
 // N concentration rows + 1 charge row in, the same out, per timestep.
 //
 // Per timestep (reference: catint/calculator_old.py, time-loop bodies :512-558 (CN), :990-1023 (FTCS)):
@@ -13,12 +16,17 @@
 //   2. per species: Robin wall BC / Dirichlet bulk BC, stencil assembly with the reference's index
 //      conventions (add_field :473-491, add_boundary_values :493-500, row-vector RHS product :553),
 //      tridiagonal solve = per-lane substructuring (Thomas on the P-1 interior rows against the two
-//      interface unknowns) + a 64-unknown parallel cyclic reduction across the wave with
-//      ds_bpermute shuffles, back-substitution, and accumulation of the next step's charge row.
+//      interface unknowns) + a 64-unknown parallel cyclic reduction across the wave whose neighbour
+//      exchange goes through LDS (ds_read2_b64 with zero guard slots), back-substitution.
+//   3. cooperative epilogue: every thread stores its coalesced share of the new rows and folds them,
+//      in species order, into the charge row the next step will lag.
 // No MFMA: the work is O(N*nx) fp64 VALU on streamed bytes.
 #include "pnp_internal.h"
 
 namespace pnp {
+
+// native 16-byte vector (the HIP vector class wrapper keeps register arrays from being promoted)
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -42,6 +50,18 @@ __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// workgroup LDS hand-off that does NOT drain outstanding global stores (LDS-only fences).
+template <int W>
+__device__ __forceinline__ void wg_sync() {
+  if constexpr (W == 1) {
+    lds_sync();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  }
+}
+
 __device__ __forceinline__ double shfl_up0(double v, int s, int lane) {
   double t = __shfl_up(v, s, 64);
   return lane >= s ? t : 0.0;
@@ -55,52 +75,86 @@ __device__ __forceinline__ double shfl_dn0(double v, int s, int lane) {
 // (lane stride P doubles) hit 64 distinct banks for ds_read_b64 / ds_write_b64.
 template <int P>
 __device__ __forceinline__ int pidx(int i) {
-  return i + i / P;
+  return i + (int)((unsigned)i / (unsigned)P);   // i >= 0 always; unsigned keeps it a single shift
 }
 
+// LDS doubles per staged row: covers the largest pitch of this P (64P+16), one dummy slot for
+// masked stores, and the 384-double exchange area of the cyclic reduction.
 template <int P>
-__host__ __device__ constexpr int rowbuf_doubles(int ldx) {
-  return ((ldx + ldx / P + 2) + 1) & ~1;
+__host__ __device__ constexpr int rowbuf_doubles() {
+  constexpr int LDXMAX = 64 * P + 16;
+  constexpr int need = LDXMAX + LDXMAX / P + 4;
+  constexpr int n = need < 384 ? 384 : need;
+  return (n + 1) & ~1;
 }
 
-// coalesced global row (16 B per lane, 1 KiB per wave instruction) -> padded LDS row
+// coalesced global row (16 B per lane, 1 KiB per wave instruction) -> registers -> padded LDS row.
+// Split in two so that the HBM latency of a row overlaps the work issued between the halves.
 template <int P>
-__device__ __forceinline__ void load_row(const double* __restrict__ g, double* buf, int ldx, int lane) {
-  constexpr int IT = P / 2 + 1;  // ldx <= 64*P + 16
-  double2 t[IT];
+struct RowRegs {
+  static constexpr int IT = P / 2 + 1;  // ldx <= 64*P + 16
+  d2 t[IT];
+};
+
+// Pair addresses are affine in (lane, it): e = 2*lane + 128*it and, because P divides 128,
+// pidx(e) = pidx(2*lane) + it*(128 + 128/P); pidx(e+1) = pidx(e) + 1 for even P (+2 for P = 1).
+template <int P>
+__device__ __forceinline__ int pair_slot(int lane_slot, int it) {
+  return lane_slot + it * (128 + 128 / P);
+}
+template <int P>
+constexpr int PAIR_STEP = (P == 1) ? 2 : 1;
+
+template <int P>
+__device__ __forceinline__ void load_row_issue(const double* __restrict__ g, RowRegs<P>& rr, int ldx, int lane) {
 #pragma unroll
-  for (int it = 0; it < IT; ++it) {
+  for (int it = 0; it < RowRegs<P>::IT; ++it) {
     const int e = 2 * lane + 128 * it;
-    if (e < ldx) t[it] = *reinterpret_cast<const double2*>(g + e);
+    rr.t[it] = (d2)(0.0);
+    if (e < ldx) rr.t[it] = *reinterpret_cast<const d2*>(g + e);
   }
+}
+
+template <int P>
+__device__ __forceinline__ void load_row_commit(const RowRegs<P>& rr, double* buf, int ldx, int lane) {
+  const int ls = pidx<P>(2 * lane);
 #pragma unroll
-  for (int it = 0; it < IT; ++it) {
+  for (int it = 0; it < RowRegs<P>::IT; ++it) {
     const int e = 2 * lane + 128 * it;
     if (e < ldx) {
-      buf[pidx<P>(e)] = t[it].x;
-      buf[pidx<P>(e + 1)] = t[it].y;
+      buf[pair_slot<P>(ls, it)] = rr.t[it].x;
+      buf[pair_slot<P>(ls, it) + PAIR_STEP<P>] = rr.t[it].y;
     }
   }
+}
+
+template <int P>
+__device__ __forceinline__ void load_row(const double* __restrict__ g, double* buf, int ldx, int lane) {
+  RowRegs<P> rr;
+  load_row_issue<P>(g, rr, ldx, lane);
+  load_row_commit<P>(rr, buf, ldx, lane);
 }
 
 template <int P>
 __device__ __forceinline__ void store_row(double* __restrict__ g, const double* buf, int ldx, int lane) {
-  constexpr int IT = P / 2 + 1;
+  const int ls = pidx<P>(2 * lane);
 #pragma unroll
-  for (int it = 0; it < IT; ++it) {
+  for (int it = 0; it < RowRegs<P>::IT; ++it) {
     const int e = 2 * lane + 128 * it;
     if (e < ldx) {
-      double2 t;
-      t.x = buf[pidx<P>(e)];
-      t.y = buf[pidx<P>(e + 1)];
-      *reinterpret_cast<double2*>(g + e) = t;
+      d2 t;
+      t.x = buf[pair_slot<P>(ls, it)];
+      t.y = buf[pair_slot<P>(ls, it) + PAIR_STEP<P>];
+      *reinterpret_cast<d2*>(g + e) = t;
     }
   }
 }
 
-// Inclusive scan of the wave's 64*P blocked values (lane-major order). REV = suffix scan.
+// Inclusive scan of the wave's 64*P blocked values (lane-major order), in place. REV = suffix scan.
+// base = what the lane's first (REV: last) element inherited from the other lanes, so the exclusive
+// scan is x[j-1] (REV: x[j+1]) inside the lane and `base` at its edge.
 template <int P, bool REV>
-__device__ __forceinline__ void blocked_scan(double (&x)[P], int lane, double& total) {
+__device__ __forceinline__ void blocked_scan(double (&x)[P], int lane, double& total, double& base) {
   if (!REV) {
 #pragma unroll
     for (int j = 1; j < P; ++j) x[j] += x[j - 1];
@@ -108,12 +162,10 @@ __device__ __forceinline__ void blocked_scan(double (&x)[P], int lane, double& t
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
       double u = __shfl_up(inc, s, 64);
-      if (lane >= s) inc += u;
+      inc += (lane >= s) ? u : 0.0;
     }
     total = __shfl(inc, 63, 64);
-    double base = shfl_up0(inc, 1, lane);
-#pragma unroll
-    for (int j = 0; j < P; ++j) x[j] += base;
+    base = shfl_up0(inc, 1, lane);
   } else {
 #pragma unroll
     for (int j = P - 2; j >= 0; --j) x[j] += x[j + 1];
@@ -121,71 +173,77 @@ __device__ __forceinline__ void blocked_scan(double (&x)[P], int lane, double& t
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
       double u = __shfl_down(inc, s, 64);
-      if (lane + s < 64) inc += u;
+      inc += (lane + s < 64) ? u : 0.0;
     }
     total = __shfl(inc, 0, 64);
-    double base = shfl_dn0(inc, 1, lane);
-#pragma unroll
-    for (int j = 0; j < P; ++j) x[j] += base;
+    base = shfl_dn0(inc, 1, lane);
   }
+#pragma unroll
+  for (int j = 0; j < P; ++j) x[j] += base;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tridiagonal solve of 64*P unknowns held P per lane (rows pre-scaled to unit diagonal):
+// Tridiagonal solve of 64*P unknowns held P per lane, rows pre-scaled to unit diagonal:
 //     a[j]*x[r-1] + x[r] + c[j]*x[r+1] = d[j],   r = lane*P + j
-// a of the first and c of the last row of the wave must be 0.  The solution overwrites d.
+// (a of the wave's first row must be 0; beyond lane 63 the exchange reads zero guards).
+// Everything is done in place in the three P-vectors; the solution overwrites d.
 // Stage 1 (per lane, registers): Thomas elimination of the P-1 interior rows against the two
 //   interface unknowns yL = x[last row of lane-1] and y = x[last row of this lane].
-// Stage 2 (across the wave): the 64 interface rows form a tridiagonal system solved by
-//   parallel cyclic reduction in log2(64) = 6 shuffle steps.
+// Stage 2 (across the wave): the 64 interface rows form a tridiagonal system solved by parallel
+//   cyclic reduction in log2(64) = 6 steps.  Neighbour rows at distance s are exchanged through
+//   a wave-private LDS area X (3 arrays of 128 doubles: 32 zero guard slots on either side of the
+//   64 lanes), so one step costs 3 ds_write_b64 + 3 ds_read2_b64 and no select for the edges.
 // Stage 3: back-substitution of the interior rows.
 // ------------------------------------------------------------------------------------------------
 template <int P>
-__device__ __forceinline__ void tridiag_wave(const double (&a)[P], const double (&c)[P], double (&d)[P], int lane) {
-  constexpr int Q = (P > 1) ? P - 1 : 1;
-  double Vn[Q], Wn[Q], dn[Q];
+__device__ __forceinline__ void tridiag_wave(double (&a)[P], double (&c)[P], double (&d)[P], double* X, int lane) {
+  // in place: a[i] -> Vs_i, c[i] -> Ws_i, d[i] -> ds_i with x_i = ds_i - Vs_i*yL - Ws_i*y  (i < P-1)
   double ra, rc, rd;
+  double* XA = X + 32 + lane;
+  double* XC = X + 128 + 32 + lane;
+  double* XD = X + 256 + 32 + lane;
+  {  // zero guards: slots [0,32) and [96,128) of each array
+    const int gofs = (lane < 32) ? -32 : 32;
+    XA[gofs] = 0.0;
+    XC[gofs] = 0.0;
+    XD[gofs] = 0.0;
+  }
   if constexpr (P == 1) {
     ra = a[0];
     rc = c[0];
     rd = d[0];
   } else {
-    double r[Q];
-    Vn[0] = a[0];
-    dn[0] = d[0];
-    r[0] = 1.0;
 #pragma unroll
     for (int i = 1; i < P - 1; ++i) {
-      const double mlt = a[i] * r[i - 1];
-      const double bb = __builtin_fma(-mlt, c[i - 1], 1.0);
-      dn[i] = __builtin_fma(-mlt, dn[i - 1], d[i]);
-      Vn[i] = -mlt * Vn[i - 1];
-      r[i] = fast_rcp(bb);
+      const double ai = a[i];
+      const double bb = __builtin_fma(-ai, c[i - 1], 1.0);
+      const double dd = __builtin_fma(-ai, d[i - 1], d[i]);
+      const double vv = -ai * a[i - 1];
+      const double r = fast_rcp(bb);
+      a[i] = vv * r;
+      d[i] = dd * r;
+      c[i] = c[i] * r;
     }
-    Wn[P - 2] = c[P - 2];
 #pragma unroll
     for (int i = P - 3; i >= 0; --i) {
-      const double mlt = c[i] * r[i + 1];
-      dn[i] = __builtin_fma(-mlt, dn[i + 1], dn[i]);
-      Vn[i] = __builtin_fma(-mlt, Vn[i + 1], Vn[i]);
-      Wn[i] = -mlt * Wn[i + 1];
-    }
-#pragma unroll
-    for (int i = 0; i < P - 1; ++i) {
-      Vn[i] *= r[i];
-      Wn[i] *= r[i];
-      dn[i] *= r[i];
+      const double cs = c[i];
+      d[i] = __builtin_fma(-cs, d[i + 1], d[i]);
+      a[i] = __builtin_fma(-cs, a[i + 1], a[i]);
+      c[i] = -cs * c[i + 1];
     }
     // first interior row of the next lane closes this lane's interface row
-    const double dn0 = shfl_dn0(dn[0], 1, lane);
-    const double Vn0 = shfl_dn0(Vn[0], 1, lane);
-    const double Wn0 = shfl_dn0(Wn[0], 1, lane);
+    XA[0] = a[0];
+    XC[0] = c[0];
+    XD[0] = d[0];
+    lds_sync();
+    const double Vn0 = XA[1], Wn0 = XC[1], dn0 = XD[1];   // lane 63 reads the zero guard
+    lds_sync();
     const double aL = a[P - 1], cL = c[P - 1];
-    double rb = __builtin_fma(-aL, Wn[P - 2], 1.0);
+    double rb = __builtin_fma(-aL, c[P - 2], 1.0);
     rb = __builtin_fma(-cL, Vn0, rb);
-    ra = -aL * Vn[P - 2];
+    ra = -aL * a[P - 2];
     rc = -cL * Wn0;
-    rd = __builtin_fma(-aL, dn[P - 2], d[P - 1]);
+    rd = __builtin_fma(-aL, d[P - 2], d[P - 1]);
     rd = __builtin_fma(-cL, dn0, rd);
     const double rr = fast_rcp(rb);
     ra *= rr;
@@ -195,8 +253,14 @@ __device__ __forceinline__ void tridiag_wave(const double (&a)[P], const double 
   // parallel cyclic reduction over the 64 interface rows (unit diagonal kept by renormalising)
 #pragma unroll
   for (int s = 1; s < 64; s <<= 1) {
-    const double aL = shfl_up0(ra, s, lane), cL = shfl_up0(rc, s, lane), dL = shfl_up0(rd, s, lane);
-    const double aR = shfl_dn0(ra, s, lane), cR = shfl_dn0(rc, s, lane), dR = shfl_dn0(rd, s, lane);
+    XA[0] = ra;
+    XC[0] = rc;
+    XD[0] = rd;
+    lds_sync();
+    const double aL = XA[-s], aR = XA[s];
+    const double cL = XC[-s], cR = XC[s];
+    const double dL = XD[-s], dR = XD[s];
+    lds_sync();
     double nb = __builtin_fma(-ra, cL, 1.0);
     nb = __builtin_fma(-rc, aR, nb);
     double nd = __builtin_fma(-ra, dL, rd);
@@ -210,11 +274,14 @@ __device__ __forceinline__ void tridiag_wave(const double (&a)[P], const double 
   }
   const double y = rd;
   if constexpr (P > 1) {
-    const double yL = shfl_up0(y, 1, lane);
+    XA[0] = y;
+    lds_sync();
+    const double yL = XA[-1];   // lane 0 reads the zero guard
+    lds_sync();
 #pragma unroll
     for (int i = 0; i < P - 1; ++i) {
-      double t = __builtin_fma(-Vn[i], yL, dn[i]);
-      d[i] = __builtin_fma(-Wn[i], y, t);
+      const double t = __builtin_fma(-a[i], yL, d[i]);
+      d[i] = __builtin_fma(-c[i], y, t);
     }
   }
   d[P - 1] = y;
@@ -225,92 +292,88 @@ __device__ __forceinline__ void tridiag_wave(const double (&a)[P], const double 
 // index into GV (all nx entries incl. the extrapolated ends) and, if VV != nullptr, v into VV.
 // Returns v[1] (needed by the Robin wall condition, calculator_old.py:528-532).
 // ------------------------------------------------------------------------------------------------
-template <int P>
+template <int P, bool WANT_V, int SHIFT>
 __device__ __forceinline__ double poisson_wave(const DevArgs& A, const double* LV, double* GV, double* VV,
                                                double vw, double vb, double gw, double gb, int lane) {
   const int nx = A.nx, m = A.m;
   const int r0 = lane * P;
   const double dx = A.dx;
+  constexpr int DUMMY = rowbuf_doubles<P>() - 1;
   double vown[P], gown[P];
+  double v1;   // v at grid point 1
   if (A.pb_mode == PNP_PB_DD) {
     // v'' = lapl with v[0]=vw, v[nx-1]=vb (solve_poisson :716-730) as two prefix scans:
     // w_i = v_{i+1}-v_i = w_0 + H_i,  H_i = sum_{j=1..i} h_j,  h = lapl*dx^2
     // v_i = vw + i*w_0 + G_i,          G_i = sum_{j=1..i-1} H_j,  w_0 from v_{nx-1} = vb.
-    double h[P], Hi[P], Hx[P];
+    double Hi[P], G[P];
     const double dx2 = dx * dx;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      const int r = r0 + j;
-      h[j] = (r < m) ? LV[pidx<P>(r + 1)] * dx2 : 0.0;
-      Hi[j] = h[j];
+      const double lv = LV[pidx<P>(r0 + j + 1)];   // beyond the row: zero-initialised LDS
+      Hi[j] = (r0 + j < m) ? lv * dx2 : 0.0;
     }
-    double tot1;
-    blocked_scan<P, false>(Hi, lane, tot1);  // Hi[j] = H_{grid r+1}
-    double G[P];
+    double tot1, baseH;
+    blocked_scan<P, false>(Hi, lane, tot1, baseH);   // Hi[j] = H_{grid r+1}; H_{grid r} = Hi[j-1] | baseH
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
-      const int r = r0 + j;
-      Hx[j] = Hi[j] - h[j];                  // H_{grid r}
-      G[j] = (r < m) ? Hi[j] : 0.0;
-    }
-    double totG;
-    blocked_scan<P, false>(G, lane, totG);   // inclusive; exclusive = G[j] - own
+    for (int j = 0; j < P; ++j) G[j] = (r0 + j < m) ? Hi[j] : 0.0;
+    double totG, baseG;
+    blocked_scan<P, false>(G, lane, totG, baseG);    // G_{grid r+1} = G[j-1] | baseG  (exclusive)
     const double w0 = (vb - vw - totG) / (double)(nx - 1);
     const double inv2dx = 1.0 / (2 * dx);
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      const int r = r0 + j;
-      const double Gex = G[j] - ((r < m) ? Hi[j] : 0.0);   // G_{grid r+1}
-      vown[j] = vw + (double)(r + 1) * w0 + Gex;
-      gown[j] = inv2dx * ((w0 + Hi[j]) + (w0 + Hx[j]));    // (v[i+1]-v[i-1])/(2dx), :784
+      const double Hx = (j == 0) ? baseH : Hi[j > 0 ? j - 1 : 0];
+      gown[j] = inv2dx * ((w0 + Hi[j]) + (w0 + Hx));     // (v[i+1]-v[i-1])/(2dx), :784
+      if constexpr (WANT_V) {
+        const double Gex = (j == 0) ? baseG : G[j > 0 ? j - 1 : 0];
+        vown[j] = vw + (double)(r0 + j + 1) * w0 + Gex;
+      }
     }
+    v1 = vw + 1.0 * w0 + 0.0;
   } else {
     const bool g_from_wall = (A.pb_mode == PNP_PB_GWALL_VBULK) || (A.pb_mode == PNP_PB_VWALL_GWALL);
     const bool v_from_wall = (A.pb_mode == PNP_PB_VWALL_GBULK) || (A.pb_mode == PNP_PB_VWALL_GWALL);
     double t[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      const int r = r0 + j;
-      t[j] = (r < m) ? LV[pidx<P>(r + 1)] * dx : 0.0;
+      const double lv = LV[pidx<P>(r0 + j + 1)];
+      t[j] = (r0 + j < m) ? lv * dx : 0.0;
     }
-    double tot;
+    double tot, base;
     if (g_from_wall) {  // grad_v[i] = grad_v[i-1] + lapl_v[i]*dx, :761
-      blocked_scan<P, false>(t, lane, tot);
+      blocked_scan<P, false>(t, lane, tot, base);
 #pragma unroll
       for (int j = 0; j < P; ++j) gown[j] = gw + t[j];
     } else {            // grad_v[i] = grad_v[i+1] - lapl_v[i]*dx, :759
-      blocked_scan<P, true>(t, lane, tot);
+      blocked_scan<P, true>(t, lane, tot, base);
 #pragma unroll
       for (int j = 0; j < P; ++j) gown[j] = gb - t[j];
     }
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
-      const int r = r0 + j;
-      t[j] = (r < m) ? gown[j] * dx : 0.0;
-    }
+    for (int j = 0; j < P; ++j) t[j] = (r0 + j < m) ? gown[j] * dx : 0.0;
     if (v_from_wall) {
-      blocked_scan<P, false>(t, lane, tot);
+      blocked_scan<P, false>(t, lane, tot, base);
 #pragma unroll
       for (int j = 0; j < P; ++j) vown[j] = vw + t[j];
     } else {
-      blocked_scan<P, true>(t, lane, tot);
+      blocked_scan<P, true>(t, lane, tot, base);
 #pragma unroll
       for (int j = 0; j < P; ++j) vown[j] = vb - t[j];
     }
+    v1 = __shfl(vown[0], 0, 64);
   }
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     const int r = r0 + j;
-    if (r < m) {
-      GV[pidx<P>(r + 1)] = gown[j];
-      if (VV) VV[pidx<P>(r + 1)] = vown[j];
-    }
+    // masked stores without a branch; grad_v[i] lives in slot i+SHIFT
+    GV[(r < m) ? pidx<P>(r + 1 + SHIFT) : DUMMY] = gown[j];
+    if constexpr (WANT_V) VV[(r < m) ? pidx<P>(r + 1) : DUMMY] = vown[j];
   }
   lds_sync();
   if (lane == 0) {
     // extrapolated / prescribed end values, :785-786, :790-803
-    const double g1 = GV[pidx<P>(1)], g2 = GV[pidx<P>(2)];
-    const double gm1 = GV[pidx<P>(nx - 2)], gm2 = GV[pidx<P>(nx - 3)];
+    const double g1 = GV[pidx<P>(1 + SHIFT)], g2 = GV[pidx<P>(2 + SHIFT)];
+    const double gm1 = GV[pidx<P>(nx - 2 + SHIFT)], gm2 = GV[pidx<P>(nx - 3 + SHIFT)];
     double g0, gl;
     if (A.pb_mode == PNP_PB_DD) {
       g0 = g1 + (g1 - g2);
@@ -322,9 +385,13 @@ __device__ __forceinline__ double poisson_wave(const DevArgs& A, const double* L
       gl = gb;
       g0 = g1 + (g1 - g2);
     }
-    GV[pidx<P>(0)] = g0;
-    GV[pidx<P>(nx - 1)] = gl;
-    if (VV) {
+    GV[pidx<P>(0 + SHIFT)] = g0;
+    GV[pidx<P>(nx - 1 + SHIFT)] = gl;
+    if constexpr (SHIFT == 1) {
+      GV[pidx<P>(0)] = g0;          // interior index -1 clamps to grad_v[0]  (add_boundary_values :496)
+      GV[pidx<P>(nx + 1)] = gl;     // one past the end, read by the FTCS window of padded rows
+    }
+    if constexpr (WANT_V) {
       const double v1 = VV[pidx<P>(1)], v2 = VV[pidx<P>(2)];
       const double vm1 = VV[pidx<P>(nx - 2)], vm2 = VV[pidx<P>(nx - 3)];
       double v0, vl;
@@ -343,196 +410,239 @@ __device__ __forceinline__ double poisson_wave(const DevArgs& A, const double* L
     }
   }
   lds_sync();
-  return __shfl(vown[0], 0, 64);
+  return v1;
 }
 
 // ------------------------------------------------------------------------------------------------
-// The timestep kernel: grid = B blocks of one wave; dynamic LDS = 3 padded rows.
+// The timestep kernel: grid = B workgroups of W waves; dynamic LDS = (2 + W) padded rows
+//   LV (lagged charge row) | GV (grad_v) | ROW[W] (one staged species row per wave)
 // ------------------------------------------------------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(64) void step_kernel(const DevArgs A) {
+template <int P, int W>
+__global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_kernel(const DevArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int lane = threadIdx.x;
+  constexpr int RB = rowbuf_doubles<P>();
+  constexpr int DUMMY = RB - 1;          // sink for masked LDS stores
+  constexpr int V1SLOT = RB - 2;         // v[1] broadcast slot inside GV
+  constexpr int IT2 = P / (2 * W) + 1;   // coalesced 16-byte chunks owned by one thread
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t b = blockIdx.x;
   const int nx = A.nx, m = A.m, ldx = A.ldx, N = A.N;
-  const int rb = rowbuf_doubles<P>(ldx);
-  double* ROW = lds;
-  double* GV = lds + rb;
-  double* LV = lds + 2 * rb;
+  double* LV = lds;
+  double* GV = lds + RB;
+  double* ROWS = lds + 2 * RB;
+  double* ROW = ROWS + wave * RB;
   const int r0 = lane * P;
   const double dx = A.dx, dt = A.dt;
 
-  const double vw = A.pb[b * 4 + 0], vb = A.pb[b * 4 + 1], gw = A.pb[b * 4 + 2], gb = A.pb[b * 4 + 3];
-  const double vz = A.vzeta[b];
   double* lin = A.lapl_a + b * (int64_t)ldx;
   double* lout = A.lapl_b + b * (int64_t)ldx;
   double* crow0 = A.c + b * (int64_t)N * ldx;
-  const double inv_eps = 1.0 / A.eps;
-  int bad = 0;
+  const bool single_round = (N <= W);   // every species row stays staged in LDS between fused steps
+  double chk = 0.0;                     // NaN/Inf detector: sum of (x - x)
+  double mn = 0.0;                      // most negative concentration seen
+  // Every LDS slot is finite from here on: rows of padded unknowns (r >= m) read past the row ends.
+  for (int i = tid; i < (2 + W) * RB; i += 64 * W) lds[i] = 0.0;
+  wg_sync<W>();
+  const int ls2 = pidx<P>(2 * tid);     // LDS slot of this thread's first coalesced pair (W = 1: tid = lane)
 
   for (int step = 0; step < A.nsteps; ++step) {
-    // ---- 1. lagged potential ------------------------------------------------------------------
-    double v1 = 0.0;
+    const bool resident = single_round && step > 0;   // rows (and LV) already in LDS from the last step
+    // ---- 0. put this wave's first species row in flight before anything else ---------------------
+    RowRegs<P> rr;
+    if (!resident && wave < N) load_row_issue<P>(crow0 + (int64_t)wave * ldx, rr, ldx, lane);
+    // ---- 1. lagged potential (wave 0) ------------------------------------------------------------
     if (A.use_mig) {
-      load_row<P>(lin, LV, ldx, lane);
-      lds_sync();
-      v1 = poisson_wave<P>(A, LV, GV, nullptr, vw, vb, gw, gb, lane);
-    }
-    // species-independent stencil inputs: grad_v at grid r0-1 .. r0+P+1, lapl_v at grid r0 .. r0+P-1
-    double gq[P + 3], lq[P];
-#pragma unroll
-    for (int t = 0; t < P + 3; ++t) {
-      const int gi = r0 - 1 + t;
-      gq[t] = (A.use_mig && gi >= 0 && gi < nx) ? GV[pidx<P>(gi)] : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < P; ++j) lq[j] = (A.use_mig && r0 + j < nx) ? LV[pidx<P>(r0 + j)] : 0.0;
-    const double g_first = A.use_mig ? GV[pidx<P>(0)] : 0.0;       // grad_v[0]
-    const double g_last = A.use_mig ? GV[pidx<P>(nx - 1)] : 0.0;   // grad_v[-1]
-    lds_sync();
-
-    double acc[P];   // next step's charge row at own points
-#pragma unroll
-    for (int j = 0; j < P; ++j) acc[j] = 0.0;
-    double acc0 = 0.0, accL = 0.0;
-
-    // ---- 2. species ------------------------------------------------------------------------------
-    for (int k = 0; k < N; ++k) {
-      double* crow = crow0 + (int64_t)k * ldx;
-      load_row<P>(crow, ROW, ldx, lane);
-      lds_sync();
-      double cc[P + 2];   // C[k] at grid r0 .. r0+P+1
-#pragma unroll
-      for (int t = 0; t < P + 2; ++t) {
-        const int gi = r0 + t;
-        cc[t] = (gi < nx) ? ROW[pidx<P>(gi)] : 0.0;
+      if (wave == 0) {
+        if (!resident) {
+          load_row<P>(lin, LV, ldx, lane);
+          lds_sync();
+        }
+        const double vw = A.pb[b * 4 + 0], vb = A.pb[b * 4 + 1], gw = A.pb[b * 4 + 2], gb = A.pb[b * 4 + 3];
+        // grad_v[i] is kept in slot i+1 (slot 0 duplicates grad_v[0]) so that every stencil window
+        // below is an affine, clamp-free LDS address
+        const double v1w = poisson_wave<P, false, 1>(A, LV, GV, nullptr, vw, vb, gw, gb, lane);
+        if (lane == 0) {
+          GV[V1SLOT] = v1w;
+          // CN indexes grad_v with the interior index r <= nx-3 plus, for the bulk boundary term,
+          // grad_v[-1]: park the latter in the otherwise unused entry nx-2 (see the stencil below)
+          if (A.method == PNP_METHOD_CRANK_NICOLSON) GV[pidx<P>(nx - 2 + 1)] = GV[pidx<P>(nx - 1 + 1)];
+        }
       }
-      const double c1 = ROW[pidx<P>(1)];
-      const double c0old = ROW[pidx<P>(0)];
-      const double cLold = ROW[pidx<P>(nx - 1)];
-      const double Dk = A.D[k], qk = A.q[k];
-      const double muk = Dk * qk * A.beta;                 // transport.py:436
-      const double flux = A.flux[b * N + k];
-      const double cL = A.cbulk[b * N + k];                // C[k,-1] = C0[(k+1)*nx-1], :540 / :1008
-      double x[P];
-      double c0new;
-      if (A.method == PNP_METHOD_CRANK_NICOLSON) {
-        // Robin wall condition :528-532
-        const double aa = muk * (v1 - vz);
-        const double den = -2 * Dk + aa;
-        c0new = (-2 * Dk - aa) / den * c1 - 2 * flux * dx / den;
-        double s = Dk * dt / (dx * dx);                    // :543
-        if (A.lf) s += 0.5;
-        const double ee = qk * A.beta * dt * Dk;           // :547
-        const double hs = 0.5 * s;
-        const double rdiag = 1.0 / (1.0 + s);
-        const double e4 = ee / 4. / dx;
-        double ta[P], tc[P];
+    }
+    if (!resident && wave < N) load_row_commit<P>(rr, ROW, ldx, lane);
+    wg_sync<W>();
+    const double v1 = A.use_mig ? GV[V1SLOT] : 0.0;
+    const double vz = A.vzeta[b];
+
+    d2 accp[IT2];   // next step's charge row at this thread's coalesced positions
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) accp[it] = (d2)(0.0);
+
+    // ---- 2. species, W at a time ---------------------------------------------------------------------
+    for (int k0 = 0; k0 < N; k0 += W) {
+      const int k = k0 + wave;
+      if (k < N) {
+        double* crow = crow0 + (int64_t)k * ldx;
+        if (k0 > 0) {   // later rounds: the first round's row was prefetched above
+          load_row<P>(crow, ROW, ldx, lane);
+          lds_sync();
+        }
+        const SpecConst& S = A.spec[k];
+        const double flux = A.flux[b * N + k];
+        const double cL = A.cbulk[b * N + k];                // C[k,-1] = C0[(k+1)*nx-1], :540 / :1008
+        const bool cn = (A.method == PNP_METHOD_CRANK_NICOLSON);
+        // ---- wall / bulk boundary values ----------------------------------------------------------
+        const double c1 = ROW[pidx<P>(1)];
+        const double c0old = ROW[pidx<P>(0)];
+        const double cLold = ROW[pidx<P>(nx - 1)];
+        const double aa = S.mu * (v1 - vz);
+        double c0new;
+        if (cn) {   // Robin wall condition :528-532
+          const double den = -S.twoD + aa;
+          c0new = (-S.twoD - aa) / den * c1 - 2 * flux * dx / den;
+        } else {    // :1003-1006
+          c0new = ((S.twoD + aa) * c1 + flux * 2. * dx) / (S.twoD - aa);
+        }
+        lds_sync();
+        // Patch the two boundary slots so that the stencil below needs no per-row special cases:
+        //   CN  : add_boundary_values (:496-499) multiplies (C0+C0_old) resp. (C1+C1_old)
+        //   FTCS: the interior update reads the freshly set boundary values (:1010-1011, :1022)
+        if (lane == 0) {
+          ROW[pidx<P>(0)] = cn ? (c0new + c0old) : c0new;
+          ROW[pidx<P>(nx - 1)] = cn ? (cL + cLold) : cL;
+        }
+        lds_sync();
+        double x[P];
+        if (cn) {
+          const double hs = S.hs, e4 = S.e4, ee = S.ee, rdiag = S.rdiag, oms = S.oms;
+          double ta[P], tc[P];
+          {
+            // stencil inputs: C[k] at grid r0 .. r0+P+1, e4*grad_v at interior index r0-1 .. r0+P.
+            // grad_v is indexed with the INTERIOR index r (not r+1) as in add_field :483-490; the slot
+            // of interior index nx-2 holds grad_v[-1] (see the Poisson section), index -1 clamps to
+            // grad_v[0]: exactly the two values add_boundary_values uses.
+            double cc[P + 2], g4[P + 2];
+#pragma unroll
+            for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
+#pragma unroll
+            for (int t = 0; t < P + 2; ++t) g4[t] = e4 * GV[pidx<P>(r0 + t)];   // entry r0-1+t, shifted by one
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+              const int r = r0 + j;
+              const double lq = LV[pidx<P>(r)];
+              // B = C[k,1:-1] . B1  (row-vector x matrix, :553):
+              //   B[r] = c[r-1]*B1[r-1,r] + c[r]*B1[r,r] + c[r+1]*B1[r+1,r]
+              const double left = cc[j] * (hs + g4[j]);
+              const double right = cc[j + 2] * (hs - g4[j + 2]);
+              const double rhs = left + cc[j + 1] * (oms + ee * lq) + right;
+              const double av = (r == 0) ? 0.0 : (-hs + g4[j + 1]);          // A[r,r-1], :487
+              const double cv = (r == m - 1) ? 0.0 : (-hs - g4[j + 1]);      // A[r,r+1], :490
+              // rows r >= m only see clamped (finite) inputs and row m-1 has cv = 0, so they form a
+              // benign trailing block that never feeds back into the real unknowns
+              ta[j] = av * rdiag;
+              tc[j] = cv * rdiag;
+              x[j] = rhs * rdiag;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          lds_sync();
+          tridiag_wave<P>(ta, tc, x, ROW, lane);              // np.linalg.solve(A,B), :556
+        } else {
+          // FTCS :1012-1023
+          const double s = S.sf, dm = S.dm, Mf = S.Mf;
+          double cc[P + 2], gq[P + 2];   // grad_v at grid r0 .. r0+P+1
+#pragma unroll
+          for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
+#pragma unroll
+          for (int t = 0; t < P + 2; ++t) gq[t] = A.use_mig ? GV[pidx<P>(r0 + t + 1)] : 0.0;
+          lds_sync();
+#pragma unroll
+          for (int j = 0; j < P; ++j) {
+            const int r = r0 + j;                             // grid i = r+1
+            double Wt = s - dm * gq[j + 2] + 0.5;             // grad_v[i+1]
+            double Et = s + dm * gq[j] + 0.5;                 // grad_v[i-1]
+            if (!A.lf) {
+              Wt -= 0.5;
+              Et -= 0.5;
+            }
+            double val = Et * cc[j] + Mf * cc[j + 1] + Wt * cc[j + 2];
+            if (A.has_rates) val += A.rates[(b * N + k) * (int64_t)ldx + min(r + 1, nx - 1)] * dt;
+            x[j] = val;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-          const int r = r0 + j;
-          const double gm = e4 * gq[j];       // g_{r-1}
-          const double g0 = e4 * gq[j + 1];   // g_r      (grad_v[r]: interior index, not r+1 -- :483-490)
-          const double gp = e4 * gq[j + 2];   // g_{r+1}
-          // B = C[k,1:-1] . B1  (row-vector x matrix, :553):
-          //   B[r] = c[r-1]*B1[r-1,r] + c[r]*B1[r,r] + c[r+1]*B1[r+1,r]
-          double left, right;
-          if (r == 0) left = (hs + e4 * g_first) * (c0new + c0old);            // :496-497
-          else left = cc[j] * (hs + gm);
-          if (r == m - 1) right = (hs - e4 * g_last) * (cL + cLold);           // :498-499
-          else right = cc[j + 2] * (hs - gp);
-          const double diag = (1 - s) + ee * lq[j];
-          double rhs = left + cc[j + 1] * diag + right;
-          double av = (r == 0) ? 0.0 : (-hs + g0);          // A[r,r-1], :487
-          double cv = (r == m - 1) ? 0.0 : (-hs - g0);      // A[r,r+1], :490
-          if (r >= m) {
-            av = 0.0;
-            cv = 0.0;
-            rhs = 0.0;
+          const int slot = (r0 + j < m) ? pidx<P>(r0 + j + 1) : DUMMY;
+          ROW[slot] = x[j];
+        }
+        if (lane == 0) {
+          ROW[pidx<P>(0)] = c0new;
+          ROW[pidx<P>(nx - 1)] = cL;
+        }
+        // the pitch tail [nx, ldx) shares LDS with the reduction's exchange area: keep it zero
+        if (lane < ldx - nx) ROW[pidx<P>(nx + lane)] = 0.0;
+      }
+      wg_sync<W>();
+      // ---- 3. cooperative epilogue: store the round's rows, fold them into the next charge row ----
+      const int nk = min(W, N - k0);
+      for (int w2 = 0; w2 < nk; ++w2) {
+        const double* R2 = ROWS + w2 * RB;
+        double* grow = crow0 + (int64_t)(k0 + w2) * ldx;
+        const double qe = A.spec[k0 + w2].qe;
+#pragma unroll
+        for (int it = 0; it < IT2; ++it) {
+          const int e = 2 * tid + 128 * W * it;
+          if (e < ldx) {
+            d2 t;
+            t.x = R2[pair_slot<P>(ls2, W * it)];
+            t.y = R2[pair_slot<P>(ls2, W * it) + PAIR_STEP<P>];
+            *reinterpret_cast<d2*>(grow + e) = t;
+            accp[it].x = __builtin_fma(-t.x, qe, accp[it].x);
+            accp[it].y = __builtin_fma(-t.y, qe, accp[it].y);
+            chk += (t.x - t.x) + (t.y - t.y);
+            mn = fmin(mn, fmin(t.x, t.y));
           }
-          ta[j] = av * rdiag;
-          tc[j] = cv * rdiag;
-          x[j] = rhs * rdiag;
-        }
-        tridiag_wave<P>(ta, tc, x, lane);                   // np.linalg.solve(A,B), :556
-      } else {
-        // FTCS :1001-1023
-        const double aa = muk * (v1 - vz);
-        const double divisor = 2 * Dk - aa;
-        c0new = ((2 * Dk + aa) * c1 + flux * 2. * dx) / divisor;
-        const double s = Dk * dt / (dx * dx);
-        const double dm = dt / (2. * dx) * muk;
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-          const int r = r0 + j;                             // grid i = r+1
-          double W = s - dm * gq[j + 3] + 0.5;              // grad_v[i+1]
-          double M = -2. * Dk * dt / (dx * dx);
-          double E = s + dm * gq[j + 1] + 0.5;              // grad_v[i-1]
-          if (!A.lf) {
-            W -= 0.5;
-            E -= 0.5;
-            M += 1;
-          }
-          const double cm = (r == 0) ? c0new : cc[j];
-          const double cp = (r == m - 1) ? cL : cc[j + 2];
-          double val = E * cm + M * cc[j + 1] + W * cp;
-          if (A.has_rates && r < m) val += A.rates[(b * N + k) * (int64_t)ldx + r + 1] * dt;
-          x[j] = val;
         }
       }
-      // status + next charge row
-      const double qe = qk * inv_eps;
+      wg_sync<W>();
+    }
+    // ---- 4. charge row of the new state (lagged by the next step) -------------------------------
+    const bool keep = single_round && (step + 1 < A.nsteps);
 #pragma unroll
-      for (int j = 0; j < P; ++j) {
-        if (r0 + j < m) {
-          if (!(x[j] - x[j] == 0.0)) bad |= 2;
-          else if (x[j] < 0.0) bad |= 1;
-          acc[j] = __builtin_fma(-x[j], qe, acc[j]);
+    for (int it = 0; it < IT2; ++it) {
+      const int e = 2 * tid + 128 * W * it;
+      if (e < ldx) {
+        *reinterpret_cast<d2*>(lout + e) = accp[it];
+        if (keep) {
+          LV[pair_slot<P>(ls2, W * it)] = accp[it].x;
+          LV[pair_slot<P>(ls2, W * it) + PAIR_STEP<P>] = accp[it].y;
         }
       }
-      if (!(c0new - c0new == 0.0)) bad |= 2;
-      else if (c0new < 0.0) bad |= 1;
-      acc0 = __builtin_fma(-c0new, qe, acc0);
-      accL = __builtin_fma(-cL, qe, accL);
-      lds_sync();
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        if (r0 + j < m) ROW[pidx<P>(r0 + j + 1)] = x[j];
-      }
-      if (lane == 0) {
-        ROW[pidx<P>(0)] = c0new;
-        ROW[pidx<P>(nx - 1)] = cL;
-      }
-      lds_sync();
-      store_row<P>(crow, ROW, ldx, lane);
-      lds_sync();
     }
-    // ---- 3. charge row of the new state (lagged by the next step) -----------------------------
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-      if (r0 + j < m) LV[pidx<P>(r0 + j + 1)] = acc[j];
-    }
-    if (lane == 0) {
-      LV[pidx<P>(0)] = acc0;
-      LV[pidx<P>(nx - 1)] = accL;
-    }
-    lds_sync();
-    store_row<P>(lout, LV, ldx, lane);
-    lds_sync();
     double* tmp = lin;
     lin = lout;
     lout = tmp;
-    // the wave re-reads its own rows in the next fused step: make the stores visible first
-    if (step + 1 < A.nsteps) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (step + 1 < A.nsteps) {
+      if (single_round) {
+        wg_sync<W>();
+      } else {
+        // rows are re-read from global memory by other threads of this workgroup
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if constexpr (W > 1) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+    }
   }
   // lane status (replaces check_error / NaN test, calculator.py:409-414)
-  const unsigned long long nan_mask = __ballot(bad & 2);
-  const unsigned long long neg_mask = __ballot(bad & 1);
+  const unsigned long long nan_mask = __ballot(chk != chk);
+  const unsigned long long neg_mask = __ballot(mn < 0.0);
   if (lane == 0) {
     int st = PNP_STATUS_OK;
     if (neg_mask) st = PNP_STATUS_NEGATIVE;
     if (nan_mask) st = PNP_STATUS_NAN;
-    if (st > A.status[b]) A.status[b] = st;   // sticky until the next pnp_set_batch
+    if (st) atomicMax(&A.status[b], st);   // sticky until the next pnp_set_batch
   }
 }
 
@@ -541,19 +651,24 @@ template <int P>
 __global__ __launch_bounds__(64) void poisson_kernel(const DevArgs A, const double* __restrict__ lapl,
                                                       double* __restrict__ v, double* __restrict__ gradv) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int RB = rowbuf_doubles<P>();
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.x;
   const int ldx = A.ldx;
-  const int rb = rowbuf_doubles<P>(ldx);
   double* VV = lds;
-  double* GV = lds + rb;
-  double* LV = lds + 2 * rb;
+  double* GV = lds + RB;
+  double* LV = lds + 2 * RB;
   // zero the pads so that the pitch tail written back is deterministic
-  for (int i = lane; i < 3 * rb; i += 64) lds[i] = 0.0;
+  for (int i = lane; i < 3 * RB; i += 64) lds[i] = 0.0;
   lds_sync();
   load_row<P>(lapl + b * (int64_t)ldx, LV, ldx, lane);
   lds_sync();
-  poisson_wave<P>(A, LV, GV, VV, A.pb[b * 4 + 0], A.pb[b * 4 + 1], A.pb[b * 4 + 2], A.pb[b * 4 + 3], lane);
+  poisson_wave<P, true, 0>(A, LV, GV, VV, A.pb[b * 4 + 0], A.pb[b * 4 + 1], A.pb[b * 4 + 2], A.pb[b * 4 + 3], lane);
+  if (lane == 0) {   // the masked-store sink is not part of the row
+    VV[RB - 1] = 0.0;
+    GV[RB - 1] = 0.0;
+  }
+  lds_sync();
   store_row<P>(v + b * (int64_t)ldx, VV, ldx, lane);
   store_row<P>(gradv + b * (int64_t)ldx, GV, ldx, lane);
 }
@@ -567,8 +682,7 @@ __global__ void charge_row_kernel(const DevArgs A, double* __restrict__ lapl) {
   const int i = (int)(idx - b * A.ldx);
   double acc = 0.0;
   if (i < A.nx) {
-    const double inv_eps = 1.0 / A.eps;
-    for (int k = 0; k < A.N; ++k) acc = __builtin_fma(-A.c[(b * A.N + k) * (int64_t)A.ldx + i], A.q[k] * inv_eps, acc);
+    for (int k = 0; k < A.N; ++k) acc = __builtin_fma(-A.c[(b * A.N + k) * (int64_t)A.ldx + i], A.spec[k].qe, acc);
   }
   lapl[idx] = acc;
 }
@@ -623,44 +737,63 @@ int points_per_lane(int nx) {
   return 0;
 }
 
-size_t step_lds_bytes(int ldx, int P) {
-  int rb = 0;
-  switch (P) {
-    case 1: rb = rowbuf_doubles<1>(ldx); break;
-    case 2: rb = rowbuf_doubles<2>(ldx); break;
-    case 4: rb = rowbuf_doubles<4>(ldx); break;
-    case 8: rb = rowbuf_doubles<8>(ldx); break;
-    case 16: rb = rowbuf_doubles<16>(ldx); break;
-    default: return 0;
-  }
-  return (size_t)3 * rb * sizeof(double);
+int choose_waves_per_grid(int N, int64_t B) {
+  // enough wavefronts to give each of the 1024 SIMDs a few; never more waves than species
+  int w = 1;
+  while (w < 4 && w < N && B * w < 4096) ++w;
+  return w;
 }
 
-hipError_t launch_step(const DevArgs& a, hipStream_t stream) {
-  const int P = points_per_lane(a.nx);
-  const size_t lds = step_lds_bytes(a.ldx, P);
-  const dim3 grid((unsigned)a.B), block(64);
+template <int P>
+static constexpr size_t lds_bytes_for(int W) {
+  return (size_t)(2 + W) * rowbuf_doubles<P>() * sizeof(double);
+}
+
+size_t step_lds_bytes(int P, int W) {
   switch (P) {
-    case 1: hipLaunchKernelGGL(step_kernel<1>, grid, block, lds, stream, a); break;
-    case 2: hipLaunchKernelGGL(step_kernel<2>, grid, block, lds, stream, a); break;
-    case 4: hipLaunchKernelGGL(step_kernel<4>, grid, block, lds, stream, a); break;
-    case 8: hipLaunchKernelGGL(step_kernel<8>, grid, block, lds, stream, a); break;
-    case 16: hipLaunchKernelGGL(step_kernel<16>, grid, block, lds, stream, a); break;
+    case 1: return lds_bytes_for<1>(W);
+    case 2: return lds_bytes_for<2>(W);
+    case 4: return lds_bytes_for<4>(W);
+    case 8: return lds_bytes_for<8>(W);
+    case 16: return lds_bytes_for<16>(W);
+    default: return 0;
+  }
+}
+
+template <int P>
+static hipError_t launch_step_p(const DevArgs& a, int W, hipStream_t stream) {
+  const dim3 grid((unsigned)a.B);
+  const size_t lds = lds_bytes_for<P>(W);
+  switch (W) {
+    case 1: hipLaunchKernelGGL((step_kernel<P, 1>), grid, dim3(64), lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((step_kernel<P, 2>), grid, dim3(128), lds, stream, a); break;
+    case 3: hipLaunchKernelGGL((step_kernel<P, 3>), grid, dim3(192), lds, stream, a); break;
+    case 4: hipLaunchKernelGGL((step_kernel<P, 4>), grid, dim3(256), lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
+hipError_t launch_step(const DevArgs& a, int W, hipStream_t stream) {
+  switch (points_per_lane(a.nx)) {
+    case 1: return launch_step_p<1>(a, W, stream);
+    case 2: return launch_step_p<2>(a, W, stream);
+    case 4: return launch_step_p<4>(a, W, stream);
+    case 8: return launch_step_p<8>(a, W, stream);
+    case 16: return launch_step_p<16>(a, W, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_poisson(const DevArgs& a, const double* lapl, double* v, double* gradv, hipStream_t stream) {
   const int P = points_per_lane(a.nx);
-  const size_t lds = step_lds_bytes(a.ldx, P);
   const dim3 grid((unsigned)a.B), block(64);
   switch (P) {
-    case 1: hipLaunchKernelGGL(poisson_kernel<1>, grid, block, lds, stream, a, lapl, v, gradv); break;
-    case 2: hipLaunchKernelGGL(poisson_kernel<2>, grid, block, lds, stream, a, lapl, v, gradv); break;
-    case 4: hipLaunchKernelGGL(poisson_kernel<4>, grid, block, lds, stream, a, lapl, v, gradv); break;
-    case 8: hipLaunchKernelGGL(poisson_kernel<8>, grid, block, lds, stream, a, lapl, v, gradv); break;
-    case 16: hipLaunchKernelGGL(poisson_kernel<16>, grid, block, lds, stream, a, lapl, v, gradv); break;
+    case 1: hipLaunchKernelGGL(poisson_kernel<1>, grid, block, lds_bytes_for<1>(1), stream, a, lapl, v, gradv); break;
+    case 2: hipLaunchKernelGGL(poisson_kernel<2>, grid, block, lds_bytes_for<2>(1), stream, a, lapl, v, gradv); break;
+    case 4: hipLaunchKernelGGL(poisson_kernel<4>, grid, block, lds_bytes_for<4>(1), stream, a, lapl, v, gradv); break;
+    case 8: hipLaunchKernelGGL(poisson_kernel<8>, grid, block, lds_bytes_for<8>(1), stream, a, lapl, v, gradv); break;
+    case 16: hipLaunchKernelGGL(poisson_kernel<16>, grid, block, lds_bytes_for<16>(1), stream, a, lapl, v, gradv); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
