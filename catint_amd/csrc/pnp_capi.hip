@@ -187,6 +187,10 @@ int pnp_set_species(pnp_handle* h, const double* D, const double* charges) {
     S.e4 = S.ee / 4. / dx;
     S.rdiag = 1.0 / (1.0 + S.s);
     S.oms = 1 - S.s;
+    S.hsr = S.hs * S.rdiag;
+    S.e4r = S.e4 * S.rdiag;
+    S.eer = S.ee * S.rdiag;
+    S.omsr = S.oms * S.rdiag;
     S.qe = charges[k] / eps;
     S.twoD = 2 * D[k];
     S.dm = dt / (2. * dx) * S.mu;                    // :1014

@@ -25,6 +25,8 @@ struct SpecConst {
   double sf;     // D*dt/dx**2   (FTCS :1013)
   double dm;     // dt/(2*dx)*mu (FTCS :1014)
   double Mf;     // FTCS centre weight after the LF handling (:1015, :1021)
+  // the same CN constants divided by the diagonal 1+s (rows are solved with unit diagonal)
+  double hsr, e4r, eer, omsr;
   double pad0, pad1;
 };
 

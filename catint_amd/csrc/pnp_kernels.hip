@@ -32,14 +32,22 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // small device helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double fast_rcp(double x) {
-  // v_rcp_f64 seed + two Newton steps (what hipcc's own fdiv expansion uses, minus the
-  // div_scale/div_fixup range handling that well-conditioned pivots do not need)
+  // v_rcp_f64 seed (measured on gfx950: 4.6e-8 relative) + one Newton step -> 2.2e-15 relative
+  // (tools/probe/rcp_probe.hip).  The pivots of the diagonally dominant systems solved here are
+  // O(1) and well away from 0, so none of hipcc's div_scale/div_fixup range handling is needed; the
+  // parity tolerance against the reference's LU (1e-9) leaves six orders of magnitude of margin.
+  double r = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
+// full-accuracy variant (two Newton steps, 1.1e-16) for the few scalar, wave-uniform quotients
+__device__ __forceinline__ double fast_rcp2(double x) {
   double r = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, r, 1.0);
   r = __builtin_fma(r, e, r);
   e = __builtin_fma(-x, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  return r;
+  return __builtin_fma(r, e, r);
 }
 
 // wave-private LDS hand-off: LDS operations of one wave execute in order, so only the compiler
@@ -153,31 +161,35 @@ __device__ __forceinline__ void store_row(double* __restrict__ g, const double* 
 // Inclusive scan of the wave's 64*P blocked values (lane-major order), in place. REV = suffix scan.
 // base = what the lane's first (REV: last) element inherited from the other lanes, so the exclusive
 // scan is x[j-1] (REV: x[j+1]) inside the lane and `base` at its edge.
+// The cross-lane part is a Hillis-Steele scan through a wave-private LDS strip X (128 doubles: the
+// 64 lane slots sit between two 32-slot zero guards, so no lane needs an edge predicate).
 template <int P, bool REV>
-__device__ __forceinline__ void blocked_scan(double (&x)[P], int lane, double& total, double& base) {
+__device__ __forceinline__ void blocked_scan(double (&x)[P], double* X, int lane, double& total, double& base) {
+  double* XS = X + 32 + lane;
+  XS[(lane < 32) ? -32 : 32] = 0.0;   // guards
+  double inc;
   if (!REV) {
 #pragma unroll
     for (int j = 1; j < P; ++j) x[j] += x[j - 1];
-    double inc = x[P - 1];
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-      double u = __shfl_up(inc, s, 64);
-      inc += (lane >= s) ? u : 0.0;
-    }
-    total = __shfl(inc, 63, 64);
-    base = shfl_up0(inc, 1, lane);
+    inc = x[P - 1];
   } else {
 #pragma unroll
     for (int j = P - 2; j >= 0; --j) x[j] += x[j + 1];
-    double inc = x[0];
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-      double u = __shfl_down(inc, s, 64);
-      inc += (lane + s < 64) ? u : 0.0;
-    }
-    total = __shfl(inc, 0, 64);
-    base = shfl_dn0(inc, 1, lane);
+    inc = x[0];
   }
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    XS[0] = inc;
+    lds_sync();
+    const double u = REV ? XS[s] : XS[-s];
+    lds_sync();
+    inc += u;
+  }
+  XS[0] = inc;
+  lds_sync();
+  total = REV ? X[32] : X[32 + 63];
+  base = REV ? XS[1] : XS[-1];
+  lds_sync();
 #pragma unroll
   for (int j = 0; j < P; ++j) x[j] += base;
 }
@@ -293,12 +305,11 @@ __device__ __forceinline__ void tridiag_wave(double (&a)[P], double (&c)[P], dou
 // Returns v[1] (needed by the Robin wall condition, calculator_old.py:528-532).
 // ------------------------------------------------------------------------------------------------
 template <int P, bool WANT_V, int SHIFT>
-__device__ __forceinline__ double poisson_wave(const DevArgs& A, const double* LV, double* GV, double* VV,
+__device__ __forceinline__ double poisson_wave(const DevArgs& A, double* LV, double* GV, double* VV, double* X,
                                                double vw, double vb, double gw, double gb, int lane) {
   const int nx = A.nx, m = A.m;
   const int r0 = lane * P;
   const double dx = A.dx;
-  constexpr int DUMMY = rowbuf_doubles<P>() - 1;
   double vown[P], gown[P];
   double v1;   // v at grid point 1
   if (A.pb_mode == PNP_PB_DD) {
@@ -307,17 +318,20 @@ __device__ __forceinline__ double poisson_wave(const DevArgs& A, const double* L
     // v_i = vw + i*w_0 + G_i,          G_i = sum_{j=1..i-1} H_j,  w_0 from v_{nx-1} = vb.
     double Hi[P], G[P];
     const double dx2 = dx * dx;
+    // The scans run over all 64*P slots without per-row predicates: LV is zero beyond the row and the
+    // bulk boundary entry (not part of the interior sum) is blanked here; nothing reads it afterwards.
+    if (lane == 0) LV[pidx<P>(nx - 1)] = 0.0;
+    lds_sync();
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
-      const double lv = LV[pidx<P>(r0 + j + 1)];   // beyond the row: zero-initialised LDS
-      Hi[j] = (r0 + j < m) ? lv * dx2 : 0.0;
-    }
+    for (int j = 0; j < P; ++j) Hi[j] = LV[pidx<P>(r0 + j + 1)] * dx2;
     double tot1, baseH;
-    blocked_scan<P, false>(Hi, lane, tot1, baseH);   // Hi[j] = H_{grid r+1}; H_{grid r} = Hi[j-1] | baseH
+    blocked_scan<P, false>(Hi, X, lane, tot1, baseH);   // Hi[j] = H_{grid r+1}; H_{grid r} = Hi[j-1] | baseH
 #pragma unroll
-    for (int j = 0; j < P; ++j) G[j] = (r0 + j < m) ? Hi[j] : 0.0;
-    double totG, baseG;
-    blocked_scan<P, false>(G, lane, totG, baseG);    // G_{grid r+1} = G[j-1] | baseG  (exclusive)
+    for (int j = 0; j < P; ++j) G[j] = Hi[j];
+    double totAll, baseG;
+    blocked_scan<P, false>(G, X, lane, totAll, baseG);  // G_{grid r+1} = G[j-1] | baseG  (exclusive)
+    // the 64*P - m padded slots each carried the full sum tot1: remove them from the grand total
+    const double totG = totAll - (double)(64 * P - m) * tot1;
     const double w0 = (vb - vw - totG) / (double)(nx - 1);
     const double inv2dx = 1.0 / (2 * dx);
 #pragma unroll
@@ -341,22 +355,22 @@ __device__ __forceinline__ double poisson_wave(const DevArgs& A, const double* L
     }
     double tot, base;
     if (g_from_wall) {  // grad_v[i] = grad_v[i-1] + lapl_v[i]*dx, :761
-      blocked_scan<P, false>(t, lane, tot, base);
+      blocked_scan<P, false>(t, X, lane, tot, base);
 #pragma unroll
       for (int j = 0; j < P; ++j) gown[j] = gw + t[j];
     } else {            // grad_v[i] = grad_v[i+1] - lapl_v[i]*dx, :759
-      blocked_scan<P, true>(t, lane, tot, base);
+      blocked_scan<P, true>(t, X, lane, tot, base);
 #pragma unroll
       for (int j = 0; j < P; ++j) gown[j] = gb - t[j];
     }
 #pragma unroll
     for (int j = 0; j < P; ++j) t[j] = (r0 + j < m) ? gown[j] * dx : 0.0;
     if (v_from_wall) {
-      blocked_scan<P, false>(t, lane, tot, base);
+      blocked_scan<P, false>(t, X, lane, tot, base);
 #pragma unroll
       for (int j = 0; j < P; ++j) vown[j] = vw + t[j];
     } else {
-      blocked_scan<P, true>(t, lane, tot, base);
+      blocked_scan<P, true>(t, X, lane, tot, base);
 #pragma unroll
       for (int j = 0; j < P; ++j) vown[j] = vb - t[j];
     }
@@ -364,10 +378,10 @@ __device__ __forceinline__ double poisson_wave(const DevArgs& A, const double* L
   }
 #pragma unroll
   for (int j = 0; j < P; ++j) {
-    const int r = r0 + j;
-    // masked stores without a branch; grad_v[i] lives in slot i+SHIFT
-    GV[(r < m) ? pidx<P>(r + 1 + SHIFT) : DUMMY] = gown[j];
-    if constexpr (WANT_V) VV[(r < m) ? pidx<P>(r + 1) : DUMMY] = vown[j];
+    // grad_v[i] lives in slot i+SHIFT.  Padded rows (r >= m) store finite don't-care values past the
+    // interior; the two end entries are set right below.
+    GV[pidx<P>(r0 + j + 1 + SHIFT)] = gown[j];
+    if constexpr (WANT_V) VV[pidx<P>(r0 + j + 1)] = vown[j];
   }
   lds_sync();
   if (lane == 0) {
@@ -421,7 +435,6 @@ template <int P, int W>
 __global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_kernel(const DevArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int RB = rowbuf_doubles<P>();
-  constexpr int DUMMY = RB - 1;          // sink for masked LDS stores
   constexpr int V1SLOT = RB - 2;         // v[1] broadcast slot inside GV
   constexpr int IT2 = P / (2 * W) + 1;   // coalesced 16-byte chunks owned by one thread
   const int tid = threadIdx.x;
@@ -462,7 +475,8 @@ __global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_
         const double vw = A.pb[b * 4 + 0], vb = A.pb[b * 4 + 1], gw = A.pb[b * 4 + 2], gb = A.pb[b * 4 + 3];
         // grad_v[i] is kept in slot i+1 (slot 0 duplicates grad_v[0]) so that every stencil window
         // below is an affine, clamp-free LDS address
-        const double v1w = poisson_wave<P, false, 1>(A, LV, GV, nullptr, vw, vb, gw, gb, lane);
+        // (the scans use the head of GV as their exchange strip: grad_v of the previous step is dead by now)
+        const double v1w = poisson_wave<P, false, 1>(A, LV, GV, nullptr, GV, vw, vb, gw, gb, lane);
         if (lane == 0) {
           GV[V1SLOT] = v1w;
           // CN indexes grad_v with the interior index r <= nx-3 plus, for the bulk boundary term,
@@ -500,10 +514,10 @@ __global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_
         const double aa = S.mu * (v1 - vz);
         double c0new;
         if (cn) {   // Robin wall condition :528-532
-          const double den = -S.twoD + aa;
-          c0new = (-S.twoD - aa) / den * c1 - 2 * flux * dx / den;
+          const double rden = fast_rcp2(-S.twoD + aa);
+          c0new = (-S.twoD - aa) * rden * c1 - 2 * flux * dx * rden;
         } else {    // :1003-1006
-          c0new = ((S.twoD + aa) * c1 + flux * 2. * dx) / (S.twoD - aa);
+          c0new = ((S.twoD + aa) * c1 + flux * 2. * dx) * fast_rcp2(S.twoD - aa);
         }
         lds_sync();
         // Patch the two boundary slots so that the stencil below needs no per-row special cases:
@@ -516,35 +530,37 @@ __global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_
         lds_sync();
         double x[P];
         if (cn) {
-          const double hs = S.hs, e4 = S.e4, ee = S.ee, rdiag = S.rdiag, oms = S.oms;
+          // every row is divided by the constant diagonal 1+s up front: the scaled constants come
+          // from the species table, so the unit-diagonal rows cost no extra multiplies
+          const double hsr = S.hsr, e4r = S.e4r, eer = S.eer, omsr = S.omsr;
           double ta[P], tc[P];
           {
             // stencil inputs: C[k] at grid r0 .. r0+P+1, e4*grad_v at interior index r0-1 .. r0+P.
-            // grad_v is indexed with the INTERIOR index r (not r+1) as in add_field :483-490; the slot
-            // of interior index nx-2 holds grad_v[-1] (see the Poisson section), index -1 clamps to
+            // grad_v is indexed with the INTERIOR index r (not r+1) as in add_field :483-490; the entry
+            // of interior index nx-2 holds grad_v[-1] (see the Poisson section), index -1 holds
             // grad_v[0]: exactly the two values add_boundary_values uses.
             double cc[P + 2], g4[P + 2];
 #pragma unroll
             for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
 #pragma unroll
-            for (int t = 0; t < P + 2; ++t) g4[t] = e4 * GV[pidx<P>(r0 + t)];   // entry r0-1+t, shifted by one
+            for (int t = 0; t < P + 2; ++t) g4[t] = e4r * GV[pidx<P>(r0 + t)];   // entry r0-1+t, shifted by one
+            const int jmu = (m - 1) % P;              // the last real row is row jmu of lane lm (both wave-uniform)
+            const bool in_lm = lane == (m - 1) / P;
 #pragma unroll
             for (int j = 0; j < P; ++j) {
-              const int r = r0 + j;
-              const double lq = LV[pidx<P>(r)];
+              const double lq = LV[pidx<P>(r0 + j)];
               // B = C[k,1:-1] . B1  (row-vector x matrix, :553):
               //   B[r] = c[r-1]*B1[r-1,r] + c[r]*B1[r,r] + c[r+1]*B1[r+1,r]
-              const double left = cc[j] * (hs + g4[j]);
-              const double right = cc[j + 2] * (hs - g4[j + 2]);
-              const double rhs = left + cc[j + 1] * (oms + ee * lq) + right;
-              const double av = (r == 0) ? 0.0 : (-hs + g4[j + 1]);          // A[r,r-1], :487
-              const double cv = (r == m - 1) ? 0.0 : (-hs - g4[j + 1]);      // A[r,r+1], :490
-              // rows r >= m only see clamped (finite) inputs and row m-1 has cv = 0, so they form a
+              const double left = cc[j] * (hsr + g4[j]);
+              const double right = cc[j + 2] * (hsr - g4[j + 2]);
+              x[j] = left + cc[j + 1] * (omsr + eer * lq) + right;
+              ta[j] = -hsr + g4[j + 1];                                   // A[r,r-1], :487
+              tc[j] = -hsr - g4[j + 1];                                   // A[r,r+1], :490
+              if (j == jmu) tc[j] = in_lm ? 0.0 : tc[j];                  // ... which the last real row lacks
+              // rows r >= m only see finite inputs and row m-1 has no super-diagonal, so they form a
               // benign trailing block that never feeds back into the real unknowns
-              ta[j] = av * rdiag;
-              tc[j] = cv * rdiag;
-              x[j] = rhs * rdiag;
             }
+            if (lane == 0) ta[0] = 0.0;                                   // first row has no sub-diagonal
           }
           __builtin_amdgcn_sched_barrier(0);
           lds_sync();
@@ -573,10 +589,7 @@ __global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_
           }
         }
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-          const int slot = (r0 + j < m) ? pidx<P>(r0 + j + 1) : DUMMY;
-          ROW[slot] = x[j];
-        }
+        for (int j = 0; j < P; ++j) ROW[pidx<P>(r0 + j + 1)] = x[j];   // padded rows land past the row (don't care)
         if (lane == 0) {
           ROW[pidx<P>(0)] = c0new;
           ROW[pidx<P>(nx - 1)] = cL;
@@ -659,14 +672,15 @@ __global__ __launch_bounds__(64) void poisson_kernel(const DevArgs A, const doub
   double* GV = lds + RB;
   double* LV = lds + 2 * RB;
   // zero the pads so that the pitch tail written back is deterministic
-  for (int i = lane; i < 3 * RB; i += 64) lds[i] = 0.0;
+  for (int i = lane; i < 4 * RB; i += 64) lds[i] = 0.0;
   lds_sync();
   load_row<P>(lapl + b * (int64_t)ldx, LV, ldx, lane);
   lds_sync();
-  poisson_wave<P, true, 0>(A, LV, GV, VV, A.pb[b * 4 + 0], A.pb[b * 4 + 1], A.pb[b * 4 + 2], A.pb[b * 4 + 3], lane);
-  if (lane == 0) {   // the masked-store sink is not part of the row
-    VV[RB - 1] = 0.0;
-    GV[RB - 1] = 0.0;
+  poisson_wave<P, true, 0>(A, LV, GV, VV, lds + 3 * RB, A.pb[b * 4 + 0], A.pb[b * 4 + 1], A.pb[b * 4 + 2], A.pb[b * 4 + 3], lane);
+  // padded rows left don't-care values past the row: blank the pitch tail [nx, ldx)
+  if (lane < ldx - A.nx) {
+    VV[pidx<P>(A.nx + lane)] = 0.0;
+    GV[pidx<P>(A.nx + lane)] = 0.0;
   }
   lds_sync();
   store_row<P>(v + b * (int64_t)ldx, VV, ldx, lane);
@@ -789,11 +803,11 @@ hipError_t launch_poisson(const DevArgs& a, const double* lapl, double* v, doubl
   const int P = points_per_lane(a.nx);
   const dim3 grid((unsigned)a.B), block(64);
   switch (P) {
-    case 1: hipLaunchKernelGGL(poisson_kernel<1>, grid, block, lds_bytes_for<1>(1), stream, a, lapl, v, gradv); break;
-    case 2: hipLaunchKernelGGL(poisson_kernel<2>, grid, block, lds_bytes_for<2>(1), stream, a, lapl, v, gradv); break;
-    case 4: hipLaunchKernelGGL(poisson_kernel<4>, grid, block, lds_bytes_for<4>(1), stream, a, lapl, v, gradv); break;
-    case 8: hipLaunchKernelGGL(poisson_kernel<8>, grid, block, lds_bytes_for<8>(1), stream, a, lapl, v, gradv); break;
-    case 16: hipLaunchKernelGGL(poisson_kernel<16>, grid, block, lds_bytes_for<16>(1), stream, a, lapl, v, gradv); break;
+    case 1: hipLaunchKernelGGL(poisson_kernel<1>, grid, block, lds_bytes_for<1>(2), stream, a, lapl, v, gradv); break;
+    case 2: hipLaunchKernelGGL(poisson_kernel<2>, grid, block, lds_bytes_for<2>(2), stream, a, lapl, v, gradv); break;
+    case 4: hipLaunchKernelGGL(poisson_kernel<4>, grid, block, lds_bytes_for<4>(2), stream, a, lapl, v, gradv); break;
+    case 8: hipLaunchKernelGGL(poisson_kernel<8>, grid, block, lds_bytes_for<8>(2), stream, a, lapl, v, gradv); break;
+    case 16: hipLaunchKernelGGL(poisson_kernel<16>, grid, block, lds_bytes_for<16>(2), stream, a, lapl, v, gradv); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
