@@ -27,7 +27,8 @@ struct pnp_handle {
   double *c = nullptr, *lapl[2] = {nullptr, nullptr}, *v = nullptr, *gradv = nullptr, *rates = nullptr;
   double *pb = nullptr, *vzeta = nullptr, *flux = nullptr, *cbulk = nullptr, *csurf = nullptr;
   SpecConst* spec = nullptr;
-  int waves_override = 0;  // CATINT_PNP_WAVES_PER_GRID (tuning / tests)
+  int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
+  int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
   int32_t* status = nullptr;
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
   int64_t dev_bytes = 0;
@@ -140,6 +141,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   HIP_TRYC(dev_alloc(h, &h->spec, (size_t)PNP_MAX_SPECIES));
 #undef HIP_TRYC
   if (const char* e = getenv("CATINT_PNP_WAVES_PER_GRID")) h->waves_override = atoi(e);
+  if (const char* e = getenv("CATINT_PNP_SPECIES_PER_WAVE")) h->species_override = atoi(e);
   DevArgs& a = h->a;
   a.N = N;
   a.nx = cfg->nx;
@@ -298,9 +300,17 @@ static int run_steps(pnp_handle* h, int nsteps) {
     if (nsteps != 1) return fail(h, PNP_EINVAL, "internal: rate terms need one step per launch");
     HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
   }
-  int W = choose_waves_per_grid(a.N, a.B);
-  if (h->waves_override >= 1 && h->waves_override <= 4) W = h->waves_override;
-  HIP_TRY(h, launch_step(a, W, h->stream));
+  int W = 1, G = 1;
+  choose_step_config(a.N, a.B, h->P, &W, &G);
+  if (h->waves_override >= 1 || h->species_override >= 1) {
+    const int w2 = h->waves_override >= 1 ? h->waves_override : W;
+    const int g2 = h->species_override >= 1 ? h->species_override : 1;
+    if (step_config_supported(w2, g2)) {
+      W = w2;
+      G = g2;
+    }
+  }
+  HIP_TRY(h, launch_step(a, W, G, h->stream));
   if (nsteps & 1) h->cur = 1 - h->cur;
   h->steps_done += nsteps;
   return PNP_OK;

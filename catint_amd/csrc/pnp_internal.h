@@ -70,12 +70,13 @@ struct ReactionTable {
 
 // points-per-lane template instance that covers nx (interior m = nx-2 <= 64*P); 0 if unsupported
 int points_per_lane(int nx);
-// waves (species in flight) per operating point chosen for a batch of B lanes
-int choose_waves_per_grid(int N, int64_t B);
-size_t step_lds_bytes(int P, int W);
+// W = waves per operating point, G = species interleaved inside one wave, chosen for a batch of B lanes
+void choose_step_config(int N, int64_t B, int P, int* W, int* G);
+bool step_config_supported(int W, int G);
+size_t step_lds_bytes(int P, int W, int G);
 
 // launchers (all asynchronous on `stream`)
-hipError_t launch_step(const DevArgs& a, int waves_per_grid, hipStream_t stream);
+hipError_t launch_step(const DevArgs& a, int W, int G, hipStream_t stream);
 // lapl[b][i] = -sum_k q_k c[b][k][i]/eps for all nx points (initial charge row, calculator_old.py:767-771)
 hipError_t launch_charge_row(const DevArgs& a, double* lapl, hipStream_t stream);
 // v, grad_v [B][ldx] from a lapl row (get_potential_and_gradient, calculator_old.py:773-803)

@@ -27,6 +27,7 @@ namespace pnp {
 
 // native 16-byte vector (the HIP vector class wrapper keeps register arrays from being promoted)
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -90,9 +91,9 @@ __device__ __forceinline__ int pidx(int i) {
 // masked stores, and the 384-double exchange area of the cyclic reduction.
 template <int P>
 __host__ __device__ constexpr int rowbuf_doubles() {
-  constexpr int LDXMAX = 64 * P + 16;
-  constexpr int need = LDXMAX + LDXMAX / P + 4;
-  constexpr int n = need < 384 ? 384 : need;
+  constexpr int CAP = 128 * (P / 2 + 1);          // whole 1-KiB chunks covering the largest pitch 64P+16
+  constexpr int need = CAP + CAP / P + 4;
+  constexpr int n = need < 388 ? 388 : need;      // >= the 384-double exchange area of the cyclic reduction
   return (n + 1) & ~1;
 }
 
@@ -113,48 +114,48 @@ __device__ __forceinline__ int pair_slot(int lane_slot, int it) {
 template <int P>
 constexpr int PAIR_STEP = (P == 1) ? 2 : 1;
 
-template <int P>
-__device__ __forceinline__ void load_row_issue(const double* __restrict__ g, RowRegs<P>& rr, int ldx, int lane) {
-#pragma unroll
-  for (int it = 0; it < RowRegs<P>::IT; ++it) {
-    const int e = 2 * lane + 128 * it;
-    rr.t[it] = (d2)(0.0);
-    if (e < ldx) rr.t[it] = *reinterpret_cast<const d2*>(g + e);
-  }
+// Global rows are accessed through buffer resources (one 128-bit descriptor per row, built from
+// wave-uniform values): the hardware range check returns 0 for loads and drops stores beyond the row
+// pitch, so the partial last chunk of an odd pitch needs neither a lane predicate nor a branch, and
+// the per-lane address is one 32-bit offset VGPR plus an immediate.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double* row, int ldx) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(row), 0, ldx * 8, 0x00020000);
 }
 
 template <int P>
-__device__ __forceinline__ void load_row_commit(const RowRegs<P>& rr, double* buf, int ldx, int lane) {
-  const int ls = pidx<P>(2 * lane);
+__device__ __forceinline__ void load_row_issue(__amdgpu_buffer_rsrc_t r, RowRegs<P>& rr, int tid_) {
+#pragma unroll
+  for (int it = 0; it < RowRegs<P>::IT; ++it)
+    rr.t[it] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, tid_ * 16 + it * 1024, 0, 0));
+}
+
+template <int P>
+__device__ __forceinline__ void load_row_commit(const RowRegs<P>& rr, double* buf, int tid_) {
+  const int ls = pidx<P>(2 * tid_);
 #pragma unroll
   for (int it = 0; it < RowRegs<P>::IT; ++it) {
-    const int e = 2 * lane + 128 * it;
-    if (e < ldx) {
-      buf[pair_slot<P>(ls, it)] = rr.t[it].x;
-      buf[pair_slot<P>(ls, it) + PAIR_STEP<P>] = rr.t[it].y;
-    }
+    buf[pair_slot<P>(ls, it)] = rr.t[it].x;
+    buf[pair_slot<P>(ls, it) + PAIR_STEP<P>] = rr.t[it].y;
   }
 }
 
 template <int P>
 __device__ __forceinline__ void load_row(const double* __restrict__ g, double* buf, int ldx, int lane) {
   RowRegs<P> rr;
-  load_row_issue<P>(g, rr, ldx, lane);
-  load_row_commit<P>(rr, buf, ldx, lane);
+  load_row_issue<P>(row_rsrc(g, ldx), rr, lane);
+  load_row_commit<P>(rr, buf, lane);
 }
 
 template <int P>
-__device__ __forceinline__ void store_row(double* __restrict__ g, const double* buf, int ldx, int lane) {
-  const int ls = pidx<P>(2 * lane);
+__device__ __forceinline__ void store_row(double* __restrict__ g, const double* buf, int ldx, int tid_) {
+  const int ls = pidx<P>(2 * tid_);
+  const __amdgpu_buffer_rsrc_t r = row_rsrc(g, ldx);
 #pragma unroll
   for (int it = 0; it < RowRegs<P>::IT; ++it) {
-    const int e = 2 * lane + 128 * it;
-    if (e < ldx) {
-      d2 t;
-      t.x = buf[pair_slot<P>(ls, it)];
-      t.y = buf[pair_slot<P>(ls, it) + PAIR_STEP<P>];
-      *reinterpret_cast<d2*>(g + e) = t;
-    }
+    d2 t;
+    t.x = buf[pair_slot<P>(ls, it)];
+    t.y = buf[pair_slot<P>(ls, it) + PAIR_STEP<P>];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), r, tid_ * 16 + it * 1024, 0, 0);
   }
 }
 
@@ -194,109 +195,192 @@ __device__ __forceinline__ void blocked_scan(double (&x)[P], double* X, int lane
   for (int j = 0; j < P; ++j) x[j] += base;
 }
 
+// Forward inclusive blocked scan of x[] with a second, scalar-per-lane quantity w summed over the wave
+// in the same LDS round trips (wtotal = sum over lanes of w).  Used by the Dirichlet-Dirichlet Poisson
+// fast path.  X needs 256 doubles.
+template <int P>
+__device__ __forceinline__ void blocked_scan_sum(double (&x)[P], double w, double* X, int lane, double& total,
+                                                 double& base, double& wtotal) {
+  double* XS = X + 32 + lane;
+  double* XW = XS + 128;
+  if (lane < 32) {   // only the left guards are read by a forward scan
+    XS[-32] = 0.0;
+    XW[-32] = 0.0;
+  }
+#pragma unroll
+  for (int j = 1; j < P; ++j) x[j] += x[j - 1];
+  double inc = x[P - 1];
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    XS[0] = inc;
+    XW[0] = w;
+    lds_sync();
+    const double u = XS[-s];
+    const double uw = XW[-s];
+    lds_sync();
+    inc += u;
+    w += uw;
+  }
+  XS[0] = inc;
+  XW[0] = w;
+  lds_sync();
+  total = X[32 + 63];
+  wtotal = X[128 + 32 + 63];
+  base = XS[-1];
+  lds_sync();
+#pragma unroll
+  for (int j = 0; j < P; ++j) x[j] += base;
+}
+
 // ------------------------------------------------------------------------------------------------
-// Tridiagonal solve of 64*P unknowns held P per lane, rows pre-scaled to unit diagonal:
-//     a[j]*x[r-1] + x[r] + c[j]*x[r+1] = d[j],   r = lane*P + j
+// G independent tridiagonal systems of 64*P unknowns each, held P per lane, rows pre-scaled to unit
+// diagonal:     a[g][j]*x[r-1] + x[r] + c[g][j]*x[r+1] = d[g][j],   r = lane*P + j
 // (a of the wave's first row must be 0; beyond lane 63 the exchange reads zero guards).
-// Everything is done in place in the three P-vectors; the solution overwrites d.
+// Everything is done in place in the three [G][P] arrays; the solutions overwrite d.
+// The G systems (the species a wave advances together -- they are independent because the reference
+// lags the potential) are interleaved statement by statement, so every dependent chain below and
+// every LDS round trip is shared by G systems: instruction-level parallelism instead of occupancy.
 // Stage 1 (per lane, registers): Thomas elimination of the P-1 interior rows against the two
 //   interface unknowns yL = x[last row of lane-1] and y = x[last row of this lane].
 // Stage 2 (across the wave): the 64 interface rows form a tridiagonal system solved by parallel
 //   cyclic reduction in log2(64) = 6 steps.  Neighbour rows at distance s are exchanged through
-//   a wave-private LDS area X (3 arrays of 128 doubles: 32 zero guard slots on either side of the
-//   64 lanes), so one step costs 3 ds_write_b64 + 3 ds_read2_b64 and no select for the edges.
+//   a wave-private LDS strip per system (3 arrays of 128 doubles: 32 zero guard slots on either
+//   side of the 64 lanes), so one step costs 3 LDS writes + 6 reads and no select for the edges.
 // Stage 3: back-substitution of the interior rows.
+// X + g*XSTRIDE is the strip of system g.
 // ------------------------------------------------------------------------------------------------
-template <int P>
-__device__ __forceinline__ void tridiag_wave(double (&a)[P], double (&c)[P], double (&d)[P], double* X, int lane) {
+template <int P, int G>
+__device__ __forceinline__ void tridiag_wave(double (&a)[G][P], double (&c)[G][P], double (&d)[G][P], double* X,
+                                             int XSTRIDE, int lane) {
   // in place: a[i] -> Vs_i, c[i] -> Ws_i, d[i] -> ds_i with x_i = ds_i - Vs_i*yL - Ws_i*y  (i < P-1)
-  double ra, rc, rd;
+  double ra[G], rc[G], rd[G];
   double* XA = X + 32 + lane;
-  double* XC = X + 128 + 32 + lane;
-  double* XD = X + 256 + 32 + lane;
+  double* XC = XA + 128;
+  double* XD = XA + 256;
   {  // zero guards: slots [0,32) and [96,128) of each array
     const int gofs = (lane < 32) ? -32 : 32;
-    XA[gofs] = 0.0;
-    XC[gofs] = 0.0;
-    XD[gofs] = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      XA[g * XSTRIDE + gofs] = 0.0;
+      XC[g * XSTRIDE + gofs] = 0.0;
+      XD[g * XSTRIDE + gofs] = 0.0;
+    }
   }
   if constexpr (P == 1) {
-    ra = a[0];
-    rc = c[0];
-    rd = d[0];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      ra[g] = a[g][0];
+      rc[g] = c[g][0];
+      rd[g] = d[g][0];
+    }
   } else {
 #pragma unroll
     for (int i = 1; i < P - 1; ++i) {
-      const double ai = a[i];
-      const double bb = __builtin_fma(-ai, c[i - 1], 1.0);
-      const double dd = __builtin_fma(-ai, d[i - 1], d[i]);
-      const double vv = -ai * a[i - 1];
-      const double r = fast_rcp(bb);
-      a[i] = vv * r;
-      d[i] = dd * r;
-      c[i] = c[i] * r;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const double ai = a[g][i];
+        const double bb = __builtin_fma(-ai, c[g][i - 1], 1.0);
+        const double dd = __builtin_fma(-ai, d[g][i - 1], d[g][i]);
+        const double vv = -ai * a[g][i - 1];
+        const double r = fast_rcp(bb);
+        a[g][i] = vv * r;
+        d[g][i] = dd * r;
+        c[g][i] = c[g][i] * r;
+      }
     }
 #pragma unroll
     for (int i = P - 3; i >= 0; --i) {
-      const double cs = c[i];
-      d[i] = __builtin_fma(-cs, d[i + 1], d[i]);
-      a[i] = __builtin_fma(-cs, a[i + 1], a[i]);
-      c[i] = -cs * c[i + 1];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const double cs = c[g][i];
+        d[g][i] = __builtin_fma(-cs, d[g][i + 1], d[g][i]);
+        a[g][i] = __builtin_fma(-cs, a[g][i + 1], a[g][i]);
+        c[g][i] = -cs * c[g][i + 1];
+      }
     }
     // first interior row of the next lane closes this lane's interface row
-    XA[0] = a[0];
-    XC[0] = c[0];
-    XD[0] = d[0];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      XA[g * XSTRIDE] = a[g][0];
+      XC[g * XSTRIDE] = c[g][0];
+      XD[g * XSTRIDE] = d[g][0];
+    }
     lds_sync();
-    const double Vn0 = XA[1], Wn0 = XC[1], dn0 = XD[1];   // lane 63 reads the zero guard
+    double Vn0[G], Wn0[G], dn0[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {   // lane 63 reads the zero guard
+      Vn0[g] = XA[g * XSTRIDE + 1];
+      Wn0[g] = XC[g * XSTRIDE + 1];
+      dn0[g] = XD[g * XSTRIDE + 1];
+    }
     lds_sync();
-    const double aL = a[P - 1], cL = c[P - 1];
-    double rb = __builtin_fma(-aL, c[P - 2], 1.0);
-    rb = __builtin_fma(-cL, Vn0, rb);
-    ra = -aL * a[P - 2];
-    rc = -cL * Wn0;
-    rd = __builtin_fma(-aL, d[P - 2], d[P - 1]);
-    rd = __builtin_fma(-cL, dn0, rd);
-    const double rr = fast_rcp(rb);
-    ra *= rr;
-    rc *= rr;
-    rd *= rr;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const double aL = a[g][P - 1], cL = c[g][P - 1];
+      double rb = __builtin_fma(-aL, c[g][P - 2], 1.0);
+      rb = __builtin_fma(-cL, Vn0[g], rb);
+      const double rr = fast_rcp(rb);
+      double t = __builtin_fma(-aL, d[g][P - 2], d[g][P - 1]);
+      t = __builtin_fma(-cL, dn0[g], t);
+      ra[g] = (-aL * a[g][P - 2]) * rr;
+      rc[g] = (-cL * Wn0[g]) * rr;
+      rd[g] = t * rr;
+    }
   }
   // parallel cyclic reduction over the 64 interface rows (unit diagonal kept by renormalising)
 #pragma unroll
   for (int s = 1; s < 64; s <<= 1) {
-    XA[0] = ra;
-    XC[0] = rc;
-    XD[0] = rd;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      XA[g * XSTRIDE] = ra[g];
+      XC[g * XSTRIDE] = rc[g];
+      XD[g * XSTRIDE] = rd[g];
+    }
     lds_sync();
-    const double aL = XA[-s], aR = XA[s];
-    const double cL = XC[-s], cR = XC[s];
-    const double dL = XD[-s], dR = XD[s];
+    double aL[G], aR[G], cL[G], cR[G], dL[G], dR[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      aL[g] = XA[g * XSTRIDE - s];
+      aR[g] = XA[g * XSTRIDE + s];
+      cL[g] = XC[g * XSTRIDE - s];
+      cR[g] = XC[g * XSTRIDE + s];
+      dL[g] = XD[g * XSTRIDE - s];
+      dR[g] = XD[g * XSTRIDE + s];
+    }
     lds_sync();
-    double nb = __builtin_fma(-ra, cL, 1.0);
-    nb = __builtin_fma(-rc, aR, nb);
-    double nd = __builtin_fma(-ra, dL, rd);
-    nd = __builtin_fma(-rc, dR, nd);
-    const double na = -ra * aL;
-    const double nc = -rc * cR;
-    const double rr = fast_rcp(nb);
-    ra = na * rr;
-    rc = nc * rr;
-    rd = nd * rr;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      double nb = __builtin_fma(-ra[g], cL[g], 1.0);
+      nb = __builtin_fma(-rc[g], aR[g], nb);
+      double nd = __builtin_fma(-ra[g], dL[g], rd[g]);
+      nd = __builtin_fma(-rc[g], dR[g], nd);
+      const double na = -ra[g] * aL[g];
+      const double nc = -rc[g] * cR[g];
+      const double rr = fast_rcp(nb);
+      ra[g] = na * rr;
+      rc[g] = nc * rr;
+      rd[g] = nd * rr;
+    }
   }
-  const double y = rd;
   if constexpr (P > 1) {
-    XA[0] = y;
+#pragma unroll
+    for (int g = 0; g < G; ++g) XA[g * XSTRIDE] = rd[g];
     lds_sync();
-    const double yL = XA[-1];   // lane 0 reads the zero guard
+    double yL[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) yL[g] = XA[g * XSTRIDE - 1];   // lane 0 reads the zero guard
     lds_sync();
 #pragma unroll
     for (int i = 0; i < P - 1; ++i) {
-      const double t = __builtin_fma(-a[i], yL, d[i]);
-      d[i] = __builtin_fma(-c[i], y, t);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const double t = __builtin_fma(-a[g][i], yL[g], d[g][i]);
+        d[g][i] = __builtin_fma(-c[g][i], rd[g], t);
+      }
     }
   }
-  d[P - 1] = y;
+#pragma unroll
+  for (int g = 0; g < G; ++g) d[g][P - 1] = rd[g];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -316,7 +400,7 @@ __device__ __forceinline__ double poisson_wave(const DevArgs& A, double* LV, dou
     // v'' = lapl with v[0]=vw, v[nx-1]=vb (solve_poisson :716-730) as two prefix scans:
     // w_i = v_{i+1}-v_i = w_0 + H_i,  H_i = sum_{j=1..i} h_j,  h = lapl*dx^2
     // v_i = vw + i*w_0 + G_i,          G_i = sum_{j=1..i-1} H_j,  w_0 from v_{nx-1} = vb.
-    double Hi[P], G[P];
+    double Hi[P];
     const double dx2 = dx * dx;
     // The scans run over all 64*P slots without per-row predicates: LV is zero beyond the row and the
     // bulk boundary entry (not part of the interior sum) is blanked here; nothing reads it afterwards.
@@ -324,24 +408,37 @@ __device__ __forceinline__ double poisson_wave(const DevArgs& A, double* LV, dou
     lds_sync();
 #pragma unroll
     for (int j = 0; j < P; ++j) Hi[j] = LV[pidx<P>(r0 + j + 1)] * dx2;
-    double tot1, baseH;
-    blocked_scan<P, false>(Hi, X, lane, tot1, baseH);   // Hi[j] = H_{grid r+1}; H_{grid r} = Hi[j-1] | baseH
-#pragma unroll
-    for (int j = 0; j < P; ++j) G[j] = Hi[j];
-    double totAll, baseG;
-    blocked_scan<P, false>(G, X, lane, totAll, baseG);  // G_{grid r+1} = G[j-1] | baseG  (exclusive)
-    // the 64*P - m padded slots each carried the full sum tot1: remove them from the grand total
-    const double totG = totAll - (double)(64 * P - m) * tot1;
-    const double w0 = (vb - vw - totG) / (double)(nx - 1);
+    double tot1, baseH, totG;
     const double inv2dx = 1.0 / (2 * dx);
+    if constexpr (!WANT_V) {
+      // only v[1] and grad_v are needed: G_{nx-1} = sum_r (m - r) h_r is a plain weighted reduction that
+      // rides along with the one scan (half the dependent LDS round trips of the two-scan form)
+      double wsum = 0.0;
+      const double wj0 = (double)(m - r0);
+#pragma unroll
+      for (int j = 0; j < P; ++j) wsum = __builtin_fma(wj0 - (double)j, Hi[j], wsum);
+      blocked_scan_sum<P>(Hi, wsum, X, lane, tot1, baseH, totG);
+    } else {
+      double G[P];
+      blocked_scan<P, false>(Hi, X, lane, tot1, baseH);   // Hi[j] = H_{grid r+1}; H_{grid r} = Hi[j-1] | baseH
+#pragma unroll
+      for (int j = 0; j < P; ++j) G[j] = Hi[j];
+      double totAll, baseG;
+      blocked_scan<P, false>(G, X, lane, totAll, baseG);  // G_{grid r+1} = G[j-1] | baseG  (exclusive)
+      // the 64*P - m padded slots each carried the full sum tot1: remove them from the grand total
+      totG = totAll - (double)(64 * P - m) * tot1;
+      const double w0v = (vb - vw - totG) / (double)(nx - 1);
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const double Gex = (j == 0) ? baseG : G[j > 0 ? j - 1 : 0];
+        vown[j] = vw + (double)(r0 + j + 1) * w0v + Gex;
+      }
+    }
+    const double w0 = (vb - vw - totG) / (double)(nx - 1);
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const double Hx = (j == 0) ? baseH : Hi[j > 0 ? j - 1 : 0];
       gown[j] = inv2dx * ((w0 + Hi[j]) + (w0 + Hx));     // (v[i+1]-v[i-1])/(2dx), :784
-      if constexpr (WANT_V) {
-        const double Gex = (j == 0) ? baseG : G[j > 0 ? j - 1 : 0];
-        vown[j] = vw + (double)(r0 + j + 1) * w0 + Gex;
-      }
     }
     v1 = vw + 1.0 * w0 + 0.0;
   } else {
@@ -428,13 +525,19 @@ __device__ __forceinline__ double poisson_wave(const DevArgs& A, double* LV, dou
 }
 
 // ------------------------------------------------------------------------------------------------
-// The timestep kernel: grid = B workgroups of W waves; dynamic LDS = (2 + W) padded rows
-//   LV (lagged charge row) | GV (grad_v) | ROW[W] (one staged species row per wave)
+// The timestep kernel: grid = B workgroups of W waves, every wave advances G species at a time;
+// dynamic LDS = (2 + W*G) padded rows:  LV (lagged charge row) | GV (grad_v) | ROW[W*G] (staged rows)
 // ------------------------------------------------------------------------------------------------
-template <int P, int W>
-__global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_kernel(const DevArgs A) {
+template <int P, int G>
+constexpr int step_min_waves() {
+  return P <= 2 ? 4 : (P == 4 ? (G == 1 ? 4 : 2) : (P == 8 ? (G == 1 ? 3 : 1) : 1));
+}
+
+template <int P, int W, int G>
+__global__ __launch_bounds__(64 * W, (step_min_waves<P, G>())) void step_kernel(const DevArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int RB = rowbuf_doubles<P>();
+  constexpr int NR = W * G;              // species rows staged per round
   constexpr int V1SLOT = RB - 2;         // v[1] broadcast slot inside GV
   constexpr int IT2 = P / (2 * W) + 1;   // coalesced 16-byte chunks owned by one thread
   const int tid = threadIdx.x;
@@ -445,33 +548,44 @@ __global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_
   double* LV = lds;
   double* GV = lds + RB;
   double* ROWS = lds + 2 * RB;
-  double* ROW = ROWS + wave * RB;
+  double* ROW0 = ROWS + wave * (G * RB);   // this wave's G staged rows: ROW0 + g*RB
   const int r0 = lane * P;
   const double dx = A.dx, dt = A.dt;
 
   double* lin = A.lapl_a + b * (int64_t)ldx;
   double* lout = A.lapl_b + b * (int64_t)ldx;
   double* crow0 = A.c + b * (int64_t)N * ldx;
-  const bool single_round = (N <= W);   // every species row stays staged in LDS between fused steps
-  double chk = 0.0;                     // NaN/Inf detector: sum of (x - x)
-  double mn = 0.0;                      // most negative concentration seen
+  const bool single_round = (N <= NR);   // every species row stays staged in LDS between fused steps
+  const bool cn = (A.method == PNP_METHOD_CRANK_NICOLSON);
+  double chk = 0.0;                      // NaN/Inf detector: sum of (x - x)
+  double mn = 0.0;                       // most negative concentration seen
   // Every LDS slot is finite from here on: rows of padded unknowns (r >= m) read past the row ends.
-  for (int i = tid; i < (2 + W) * RB; i += 64 * W) lds[i] = 0.0;
+  for (int i = tid; i < (2 + NR) * RB; i += 64 * W) lds[i] = 0.0;
   wg_sync<W>();
-  const int ls2 = pidx<P>(2 * tid);     // LDS slot of this thread's first coalesced pair (W = 1: tid = lane)
+  const int ls2 = pidx<P>(2 * tid);      // LDS slot of this thread's first coalesced pair
 
   for (int step = 0; step < A.nsteps; ++step) {
     const bool resident = single_round && step > 0;   // rows (and LV) already in LDS from the last step
-    // ---- 0. put this wave's first species row in flight before anything else ---------------------
-    RowRegs<P> rr;
-    if (!resident && wave < N) load_row_issue<P>(crow0 + (int64_t)wave * ldx, rr, ldx, lane);
+    // ---- 0. all global reads of the first round go out together ------------------------------------
+    if (!resident) {
+      RowRegs<P> rl, rr[G];
+      if (wave == 0 && A.use_mig) load_row_issue<P>(row_rsrc(lin, ldx), rl, lane);
+      if (wave * G < N) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          load_row_issue<P>(row_rsrc(crow0 + (int64_t)min(wave * G + g, N - 1) * ldx, ldx), rr[g], lane);
+      }
+      if (wave == 0 && A.use_mig) load_row_commit<P>(rl, LV, lane);
+      if (wave * G < N) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) load_row_commit<P>(rr[g], ROW0 + g * RB, lane);
+      }
+      lds_sync();
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the staging registers' live range inside the block above
     // ---- 1. lagged potential (wave 0) ------------------------------------------------------------
     if (A.use_mig) {
       if (wave == 0) {
-        if (!resident) {
-          load_row<P>(lin, LV, ldx, lane);
-          lds_sync();
-        }
         const double vw = A.pb[b * 4 + 0], vb = A.pb[b * 4 + 1], gw = A.pb[b * 4 + 2], gb = A.pb[b * 4 + 3];
         // grad_v[i] is kept in slot i+1 (slot 0 duplicates grad_v[0]) so that every stencil window
         // below is an affine, clamp-free LDS address
@@ -481,11 +595,10 @@ __global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_
           GV[V1SLOT] = v1w;
           // CN indexes grad_v with the interior index r <= nx-3 plus, for the bulk boundary term,
           // grad_v[-1]: park the latter in the otherwise unused entry nx-2 (see the stencil below)
-          if (A.method == PNP_METHOD_CRANK_NICOLSON) GV[pidx<P>(nx - 2 + 1)] = GV[pidx<P>(nx - 1 + 1)];
+          if (cn) GV[pidx<P>(nx - 2 + 1)] = GV[pidx<P>(nx - 1 + 1)];
         }
       }
     }
-    if (!resident && wave < N) load_row_commit<P>(rr, ROW, ldx, lane);
     wg_sync<W>();
     const double v1 = A.use_mig ? GV[V1SLOT] : 0.0;
     const double vz = A.vzeta[b];
@@ -494,141 +607,180 @@ __global__ __launch_bounds__(64 * W, (P <= 4 ? 4 : (P == 8 ? 3 : 1))) void step_
 #pragma unroll
     for (int it = 0; it < IT2; ++it) accp[it] = (d2)(0.0);
 
-    // ---- 2. species, W at a time ---------------------------------------------------------------------
-    for (int k0 = 0; k0 < N; k0 += W) {
-      const int k = k0 + wave;
-      if (k < N) {
-        double* crow = crow0 + (int64_t)k * ldx;
-        if (k0 > 0) {   // later rounds: the first round's row was prefetched above
-          load_row<P>(crow, ROW, ldx, lane);
+    // ---- 2. species, W*G at a time ------------------------------------------------------------------
+    for (int k0 = 0; k0 < N; k0 += NR) {
+      const int kw = k0 + wave * G;          // first species of this wave in this round
+      if (kw < N) {
+        int kg[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) kg[g] = min(kw + g, N - 1);   // a short last group recomputes species N-1
+        if (k0 > 0) {   // later rounds: the first round's rows were loaded above
+          RowRegs<P> rr[G];
+#pragma unroll
+          for (int g = 0; g < G; ++g) load_row_issue<P>(row_rsrc(crow0 + (int64_t)kg[g] * ldx, ldx), rr[g], lane);
+#pragma unroll
+          for (int g = 0; g < G; ++g) load_row_commit<P>(rr[g], ROW0 + g * RB, lane);
           lds_sync();
         }
-        const SpecConst& S = A.spec[k];
-        const double flux = A.flux[b * N + k];
-        const double cL = A.cbulk[b * N + k];                // C[k,-1] = C0[(k+1)*nx-1], :540 / :1008
-        const bool cn = (A.method == PNP_METHOD_CRANK_NICOLSON);
         // ---- wall / bulk boundary values ----------------------------------------------------------
-        const double c1 = ROW[pidx<P>(1)];
-        const double c0old = ROW[pidx<P>(0)];
-        const double cLold = ROW[pidx<P>(nx - 1)];
-        const double aa = S.mu * (v1 - vz);
-        double c0new;
-        if (cn) {   // Robin wall condition :528-532
-          const double rden = fast_rcp2(-S.twoD + aa);
-          c0new = (-S.twoD - aa) * rden * c1 - 2 * flux * dx * rden;
-        } else {    // :1003-1006
-          c0new = ((S.twoD + aa) * c1 + flux * 2. * dx) * fast_rcp2(S.twoD - aa);
+        double c0new[G], cLv[G], pat0[G], patL[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const double* ROW = ROW0 + g * RB;
+          const SpecConst& S = A.spec[kg[g]];
+          const double flux = A.flux[b * N + kg[g]];
+          const double cL = A.cbulk[b * N + kg[g]];            // C[k,-1] = C0[(k+1)*nx-1], :540 / :1008
+          const double c1 = ROW[pidx<P>(1)];
+          const double c0old = ROW[pidx<P>(0)];
+          const double cLold = ROW[pidx<P>(nx - 1)];
+          const double aa = S.mu * (v1 - vz);
+          if (cn) {   // Robin wall condition :528-532
+            const double rden = fast_rcp2(-S.twoD + aa);
+            c0new[g] = (-S.twoD - aa) * rden * c1 - 2 * flux * dx * rden;
+          } else {    // :1003-1006
+            c0new[g] = ((S.twoD + aa) * c1 + flux * 2. * dx) * fast_rcp2(S.twoD - aa);
+          }
+          cLv[g] = cL;
+          // Patch the two boundary slots so that the stencil below needs no per-row special cases:
+          //   CN  : add_boundary_values (:496-499) multiplies (C0+C0_old) resp. (C1+C1_old)
+          //   FTCS: the interior update reads the freshly set boundary values (:1010-1011, :1022)
+          pat0[g] = cn ? (c0new[g] + c0old) : c0new[g];
+          patL[g] = cn ? (cL + cLold) : cL;
         }
         lds_sync();
-        // Patch the two boundary slots so that the stencil below needs no per-row special cases:
-        //   CN  : add_boundary_values (:496-499) multiplies (C0+C0_old) resp. (C1+C1_old)
-        //   FTCS: the interior update reads the freshly set boundary values (:1010-1011, :1022)
         if (lane == 0) {
-          ROW[pidx<P>(0)] = cn ? (c0new + c0old) : c0new;
-          ROW[pidx<P>(nx - 1)] = cn ? (cL + cLold) : cL;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            ROW0[g * RB + pidx<P>(0)] = pat0[g];
+            ROW0[g * RB + pidx<P>(nx - 1)] = patL[g];
+          }
         }
         lds_sync();
-        double x[P];
+        double x[G][P];
         if (cn) {
-          // every row is divided by the constant diagonal 1+s up front: the scaled constants come
-          // from the species table, so the unit-diagonal rows cost no extra multiplies
-          const double hsr = S.hsr, e4r = S.e4r, eer = S.eer, omsr = S.omsr;
-          double ta[P], tc[P];
+          double ta[G][P], tc[G][P];
           {
-            // stencil inputs: C[k] at grid r0 .. r0+P+1, e4*grad_v at interior index r0-1 .. r0+P.
-            // grad_v is indexed with the INTERIOR index r (not r+1) as in add_field :483-490; the entry
-            // of interior index nx-2 holds grad_v[-1] (see the Poisson section), index -1 holds
-            // grad_v[0]: exactly the two values add_boundary_values uses.
-            double cc[P + 2], g4[P + 2];
-#pragma unroll
-            for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
-#pragma unroll
-            for (int t = 0; t < P + 2; ++t) g4[t] = e4r * GV[pidx<P>(r0 + t)];   // entry r0-1+t, shifted by one
+            // stencil inputs shared by the G species: grad_v at interior index r0-1 .. r0+P (entry shifted by
+            // one), lapl_v at interior index r0 .. r0+P-1.  grad_v is indexed with the INTERIOR index r (not
+            // r+1) as in add_field :483-490; the entry of interior index nx-2 holds grad_v[-1] (see the
+            // Poisson section), index -1 holds grad_v[0]: exactly what add_boundary_values uses.
             const int jmu = (m - 1) % P;              // the last real row is row jmu of lane lm (both wave-uniform)
             const bool in_lm = lane == (m - 1) / P;
 #pragma unroll
-            for (int j = 0; j < P; ++j) {
-              const double lq = LV[pidx<P>(r0 + j)];
-              // B = C[k,1:-1] . B1  (row-vector x matrix, :553):
-              //   B[r] = c[r-1]*B1[r-1,r] + c[r]*B1[r,r] + c[r+1]*B1[r+1,r]
-              const double left = cc[j] * (hsr + g4[j]);
-              const double right = cc[j + 2] * (hsr - g4[j + 2]);
-              x[j] = left + cc[j + 1] * (omsr + eer * lq) + right;
-              ta[j] = -hsr + g4[j + 1];                                   // A[r,r-1], :487
-              tc[j] = -hsr - g4[j + 1];                                   // A[r,r+1], :490
-              if (j == jmu) tc[j] = in_lm ? 0.0 : tc[j];                  // ... which the last real row lacks
-              // rows r >= m only see finite inputs and row m-1 has no super-diagonal, so they form a
-              // benign trailing block that never feeds back into the real unknowns
+            for (int g = 0; g < G; ++g) {
+              const double* ROW = ROW0 + g * RB;
+              const SpecConst& S = A.spec[kg[g]];
+              // every row is divided by the constant diagonal 1+s up front: the scaled constants come
+              // from the species table, so the unit-diagonal rows cost no extra multiplies
+              const double hsr = S.hsr, e4r = S.e4r, eer = S.eer, omsr = S.omsr;
+              double cc[P + 2], g4[P + 2];
+#pragma unroll
+              for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
+#pragma unroll
+              for (int t = 0; t < P + 2; ++t) g4[t] = e4r * GV[pidx<P>(r0 + t)];
+#pragma unroll
+              for (int j = 0; j < P; ++j) {
+                // B = C[k,1:-1] . B1  (row-vector x matrix, :553):
+                //   B[r] = c[r-1]*B1[r-1,r] + c[r]*B1[r,r] + c[r+1]*B1[r+1,r]
+                const double lq = LV[pidx<P>(r0 + j)];
+                const double left = cc[j] * (hsr + g4[j]);
+                const double right = cc[j + 2] * (hsr - g4[j + 2]);
+                x[g][j] = left + cc[j + 1] * (omsr + eer * lq) + right;
+                ta[g][j] = -hsr + g4[j + 1];                               // A[r,r-1], :487
+                tc[g][j] = -hsr - g4[j + 1];                               // A[r,r+1], :490
+                if (j == jmu) tc[g][j] = in_lm ? 0.0 : tc[g][j];           // ... which the last real row lacks
+                // rows r >= m only see finite inputs and row m-1 has no super-diagonal, so they form a
+                // benign trailing block that never feeds back into the real unknowns
+              }
+              if (lane == 0) ta[g][0] = 0.0;                               // first row has no sub-diagonal
             }
-            if (lane == 0) ta[0] = 0.0;                                   // first row has no sub-diagonal
           }
           __builtin_amdgcn_sched_barrier(0);
           lds_sync();
-          tridiag_wave<P>(ta, tc, x, ROW, lane);              // np.linalg.solve(A,B), :556
+          tridiag_wave<P, G>(ta, tc, x, ROW0, RB, lane);       // np.linalg.solve(A,B), :556
         } else {
           // FTCS :1012-1023
-          const double s = S.sf, dm = S.dm, Mf = S.Mf;
-          double cc[P + 2], gq[P + 2];   // grad_v at grid r0 .. r0+P+1
-#pragma unroll
-          for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
+          double gq[P + 2];   // grad_v at grid r0 .. r0+P+1
 #pragma unroll
           for (int t = 0; t < P + 2; ++t) gq[t] = A.use_mig ? GV[pidx<P>(r0 + t + 1)] : 0.0;
-          lds_sync();
 #pragma unroll
-          for (int j = 0; j < P; ++j) {
-            const int r = r0 + j;                             // grid i = r+1
-            double Wt = s - dm * gq[j + 2] + 0.5;             // grad_v[i+1]
-            double Et = s + dm * gq[j] + 0.5;                 // grad_v[i-1]
-            if (!A.lf) {
-              Wt -= 0.5;
-              Et -= 0.5;
+          for (int g = 0; g < G; ++g) {
+            const double* ROW = ROW0 + g * RB;
+            const SpecConst& S = A.spec[kg[g]];
+            const double sf = S.sf, dm = S.dm, Mf = S.Mf;
+            double cc[P + 2];
+#pragma unroll
+            for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+              double Wt = sf - dm * gq[j + 2] + 0.5;            // grad_v[i+1], grid i = r0+j+1
+              double Et = sf + dm * gq[j] + 0.5;                // grad_v[i-1]
+              if (!A.lf) {
+                Wt -= 0.5;
+                Et -= 0.5;
+              }
+              double val = Et * cc[j] + Mf * cc[j + 1] + Wt * cc[j + 2];
+              if (A.has_rates) val += A.rates[(b * N + kg[g]) * (int64_t)ldx + min(r0 + j + 1, nx - 1)] * dt;
+              x[g][j] = val;
             }
-            double val = Et * cc[j] + Mf * cc[j + 1] + Wt * cc[j + 2];
-            if (A.has_rates) val += A.rates[(b * N + k) * (int64_t)ldx + min(r + 1, nx - 1)] * dt;
-            x[j] = val;
           }
+          lds_sync();
         }
 #pragma unroll
-        for (int j = 0; j < P; ++j) ROW[pidx<P>(r0 + j + 1)] = x[j];   // padded rows land past the row (don't care)
-        if (lane == 0) {
-          ROW[pidx<P>(0)] = c0new;
-          ROW[pidx<P>(nx - 1)] = cL;
+        for (int g = 0; g < G; ++g) {
+          double* ROW = ROW0 + g * RB;
+#pragma unroll
+          for (int j = 0; j < P; ++j) ROW[pidx<P>(r0 + j + 1)] = x[g][j];   // padded rows land past the row (don't care)
         }
-        // the pitch tail [nx, ldx) shares LDS with the reduction's exchange area: keep it zero
-        if (lane < ldx - nx) ROW[pidx<P>(nx + lane)] = 0.0;
+        lds_sync();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          double* ROW = ROW0 + g * RB;
+          if (lane == 0) {
+            ROW[pidx<P>(0)] = c0new[g];
+            ROW[pidx<P>(nx - 1)] = cLv[g];
+          }
+          // the pitch tail [nx, ldx) shares LDS with the reduction's exchange area: keep it zero
+          if (lane < ldx - nx) ROW[pidx<P>(nx + lane)] = 0.0;
+        }
       }
       wg_sync<W>();
       // ---- 3. cooperative epilogue: store the round's rows, fold them into the next charge row ----
-      const int nk = min(W, N - k0);
+      const int nk = min(NR, N - k0);
       for (int w2 = 0; w2 < nk; ++w2) {
         const double* R2 = ROWS + w2 * RB;
         double* grow = crow0 + (int64_t)(k0 + w2) * ldx;
         const double qe = A.spec[k0 + w2].qe;
+        const __amdgpu_buffer_rsrc_t rs = row_rsrc(grow, ldx);
 #pragma unroll
         for (int it = 0; it < IT2; ++it) {
-          const int e = 2 * tid + 128 * W * it;
-          if (e < ldx) {
-            d2 t;
-            t.x = R2[pair_slot<P>(ls2, W * it)];
-            t.y = R2[pair_slot<P>(ls2, W * it) + PAIR_STEP<P>];
-            *reinterpret_cast<d2*>(grow + e) = t;
-            accp[it].x = __builtin_fma(-t.x, qe, accp[it].x);
-            accp[it].y = __builtin_fma(-t.y, qe, accp[it].y);
-            chk += (t.x - t.x) + (t.y - t.y);
-            mn = fmin(mn, fmin(t.x, t.y));
-          }
+          // threads past the staged row (W > 1: the workgroup spans more than one row buffer) read a
+          // clamped, don't-care slot; their global store is dropped by the range check
+          const int sl = min(pair_slot<P>(ls2, W * it), RB - 4);
+          d2 t;
+          t.x = R2[sl];
+          t.y = R2[sl + PAIR_STEP<P>];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), rs, tid * 16 + it * (1024 * W), 0, 0);
+          accp[it].x = __builtin_fma(-t.x, qe, accp[it].x);
+          accp[it].y = __builtin_fma(-t.y, qe, accp[it].y);
+          // beyond the pitch the staged row holds the don't-care values of the padded unknowns
+          const bool inrow = 2 * tid + 128 * W * it < ldx;
+          const double sx = inrow ? t.x : 0.0, sy = inrow ? t.y : 0.0;
+          chk += (sx - sx) + (sy - sy);
+          mn = fmin(mn, fmin(sx, sy));
         }
       }
       wg_sync<W>();
     }
     // ---- 4. charge row of the new state (lagged by the next step) -------------------------------
     const bool keep = single_round && (step + 1 < A.nsteps);
+    {
+      const __amdgpu_buffer_rsrc_t rs = row_rsrc(lout, ldx);
 #pragma unroll
-    for (int it = 0; it < IT2; ++it) {
-      const int e = 2 * tid + 128 * W * it;
-      if (e < ldx) {
-        *reinterpret_cast<d2*>(lout + e) = accp[it];
-        if (keep) {
+      for (int it = 0; it < IT2; ++it) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, accp[it]), rs, tid * 16 + it * (1024 * W), 0, 0);
+        // LV stays zero beyond the row (the Poisson scans run unmasked): only in-row pairs are written
+        if (keep && 2 * tid + 128 * W * it < ldx) {
           LV[pair_slot<P>(ls2, W * it)] = accp[it].x;
           LV[pair_slot<P>(ls2, W * it) + PAIR_STEP<P>] = accp[it].y;
         }
@@ -751,50 +903,64 @@ int points_per_lane(int nx) {
   return 0;
 }
 
-int choose_waves_per_grid(int N, int64_t B) {
-  // enough wavefronts to give each of the 1024 SIMDs a few; never more waves than species
-  int w = 1;
-  while (w < 4 && w < N && B * w < 4096) ++w;
-  return w;
+void choose_step_config(int N, int64_t B, int P, int* W, int* G) {
+  // Small batches: every SIMD should own a few independent dependency chains -- species in different
+  // waves (W) and/or interleaved inside a wave (G).  Large batches: one wave per operating point.
+  int w = 1, g = 1;
+  if (P <= 8) g = (N % 3 == 0) ? 3 : ((N % 2 == 0) ? 2 : 1);
+  if (g > N) g = N;
+  const int wmax = (g == 3) ? 1 : (g == 2 ? 2 : 4);   // instantiated (W,G) pairs: see launch_step_p
+  while (w < wmax && w * g < N && B * w < 2048) ++w;
+  *W = w;
+  *G = g;
 }
 
 template <int P>
-static constexpr size_t lds_bytes_for(int W) {
-  return (size_t)(2 + W) * rowbuf_doubles<P>() * sizeof(double);
+static constexpr size_t lds_bytes_for(int rows) {
+  return (size_t)(2 + rows) * rowbuf_doubles<P>() * sizeof(double);
 }
 
-size_t step_lds_bytes(int P, int W) {
+size_t step_lds_bytes(int P, int W, int G) {
   switch (P) {
-    case 1: return lds_bytes_for<1>(W);
-    case 2: return lds_bytes_for<2>(W);
-    case 4: return lds_bytes_for<4>(W);
-    case 8: return lds_bytes_for<8>(W);
-    case 16: return lds_bytes_for<16>(W);
+    case 1: return lds_bytes_for<1>(W * G);
+    case 2: return lds_bytes_for<2>(W * G);
+    case 4: return lds_bytes_for<4>(W * G);
+    case 8: return lds_bytes_for<8>(W * G);
+    case 16: return lds_bytes_for<16>(W * G);
     default: return 0;
   }
 }
 
 template <int P>
-static hipError_t launch_step_p(const DevArgs& a, int W, hipStream_t stream) {
+static hipError_t launch_step_p(const DevArgs& a, int W, int G, hipStream_t stream) {
   const dim3 grid((unsigned)a.B);
-  const size_t lds = lds_bytes_for<P>(W);
-  switch (W) {
-    case 1: hipLaunchKernelGGL((step_kernel<P, 1>), grid, dim3(64), lds, stream, a); break;
-    case 2: hipLaunchKernelGGL((step_kernel<P, 2>), grid, dim3(128), lds, stream, a); break;
-    case 3: hipLaunchKernelGGL((step_kernel<P, 3>), grid, dim3(192), lds, stream, a); break;
-    case 4: hipLaunchKernelGGL((step_kernel<P, 4>), grid, dim3(256), lds, stream, a); break;
+  const size_t lds = lds_bytes_for<P>(W * G);
+  const int key = W * 10 + G;
+  switch (key) {
+    case 11: hipLaunchKernelGGL((step_kernel<P, 1, 1>), grid, dim3(64), lds, stream, a); break;
+    case 12: hipLaunchKernelGGL((step_kernel<P, 1, 2>), grid, dim3(64), lds, stream, a); break;
+    case 13: hipLaunchKernelGGL((step_kernel<P, 1, 3>), grid, dim3(64), lds, stream, a); break;
+    case 21: hipLaunchKernelGGL((step_kernel<P, 2, 1>), grid, dim3(128), lds, stream, a); break;
+    case 22: hipLaunchKernelGGL((step_kernel<P, 2, 2>), grid, dim3(128), lds, stream, a); break;
+    case 31: hipLaunchKernelGGL((step_kernel<P, 3, 1>), grid, dim3(192), lds, stream, a); break;
+    case 41: hipLaunchKernelGGL((step_kernel<P, 4, 1>), grid, dim3(256), lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t launch_step(const DevArgs& a, int W, hipStream_t stream) {
+bool step_config_supported(int W, int G) {
+  const int key = W * 10 + G;
+  return key == 11 || key == 12 || key == 13 || key == 21 || key == 22 || key == 31 || key == 41;
+}
+
+hipError_t launch_step(const DevArgs& a, int W, int G, hipStream_t stream) {
   switch (points_per_lane(a.nx)) {
-    case 1: return launch_step_p<1>(a, W, stream);
-    case 2: return launch_step_p<2>(a, W, stream);
-    case 4: return launch_step_p<4>(a, W, stream);
-    case 8: return launch_step_p<8>(a, W, stream);
-    case 16: return launch_step_p<16>(a, W, stream);
+    case 1: return launch_step_p<1>(a, W, G, stream);
+    case 2: return launch_step_p<2>(a, W, G, stream);
+    case 4: return launch_step_p<4>(a, W, G, stream);
+    case 8: return launch_step_p<8>(a, W, G, stream);
+    case 16: return launch_step_p<16>(a, W, G, stream);
     default: return hipErrorInvalidValue;
   }
 }

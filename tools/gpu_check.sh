@@ -1,9 +1,12 @@
 #!/bin/bash
-# run on the GPU box: parity for every waves-per-grid variant, then the bench (JSON to gpurun_out/$1.json)
+# run on the GPU box: parity for every (waves-per-grid, species-per-wave) variant, then the bench
 set -o pipefail
 tag=${1:-bench}
 timeout -k 10 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 || exit 1
-for w in 1 2 3 4; do CATINT_PNP_WAVES_PER_GRID=$w timeout -k 10 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 || exit 1; done
+for c in 1,1 1,2 1,3 2,1 2,2 3,1 4,1; do
+  w=${c%,*}; g=${c#*,}
+  CATINT_PNP_WAVES_PER_GRID=$w CATINT_PNP_SPECIES_PER_WAVE=$g timeout -k 10 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 || { echo "FAILED for W=$w G=$g"; exit 1; }
+done
 timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/$tag.json 2> gpurun_out/$tag.err || { tail -5 gpurun_out/$tag.err; exit 1; }
 python - "$tag" <<'PY'
 import json,sys

@@ -1,15 +1,15 @@
 #!/bin/bash
 # dev tool: compile ONE instantiation of step_kernel and print resource usage + instruction mix
 # usage: tools/kexp.sh P W [extra hipcc flags]
-P=$1; W=$2; shift 2
+P=$1; W=$2; G=$3; shift 3
 D=/tmp/asm; mkdir -p $D
 SRC=/root/repo/catint_amd/csrc
-python3 - "$P" "$W" <<PY
+python3 - "$P" "$W" "$G" <<PY
 import sys
-P,W=sys.argv[1],sys.argv[2]
+P,W,G=sys.argv[1],sys.argv[2],sys.argv[3]
 s=open('$SRC/pnp_kernels.hip').read()
 cut=s.index('// host-side launchers')
-s=s[:cut]+"\n*/\ntemplate __global__ void step_kernel<%s,%s>(const DevArgs);\n}\n"%(P,W)
+s=s[:cut]+"\n*/\ntemplate __global__ void step_kernel<%s,%s,%s>(const DevArgs);\n}\n"%(P,W,G)
 # the cut lands inside a comment banner: reopen it
 s=s.replace('// ------------------------------------------------------------------------------------------------\n\n*/','/*\n*/')
 s=s.replace('#include "pnp_internal.h"','#include "$SRC/pnp_internal.h"')
