@@ -1,0 +1,198 @@
+"""Host-side counterpart of the reference's ``Calculator`` for the finite-difference transport path,
+batched over operating points and backed by the HIP library (no CPU fallback).
+
+Reference interface mirrored here (paths relative to /root/reference):
+  Calculator.__init__(transport, dt, tmax, ntout, calc, scale_pb_grid, tau_jacobi, tau_scf, mix_scf, mode)
+                                      catint/calculator.py:55-143 == catint/calculator_old.py:54-157
+  Calculator.integrate_pnp(dx,nx,dt,nt,ntout,method) -> list of flat [N*nx] arrays   calculator_old.py:210
+  Calculator.run()  (descriptor sweep)                                              calculator.py:196-240
+  Calculator.run_scf_cycle / evaluate_accuracy                                      calculator.py:260-406
+The reference runs one descriptor point at a time; here every descriptor point is one lane of the
+GPU batch (`integrate_pnp_batch`, `run`).
+"""
+import copy
+
+import numpy as np
+
+from ._capi import PnpSolver, PnpError
+from .host import pb_mode_from_bound
+from .units import unit_F
+
+CALC_LIST = ['FTCS', 'Crank-Nicolson', 'odeint', 'vode', 'lsoda', 'dopri5', 'dop853', 'odeint', 'odespy', 'comsol']
+GPU_CALCS = ('FTCS', 'Crank-Nicolson')
+
+
+class CalculatorError(ValueError):
+    """Raised where the reference logs an error and calls sys.exit()."""
+
+
+def make_itout(nt, ntout):
+    """Output steps, calculator.py:126-138 == calculator_old.py:140-152."""
+    itout = []
+    for it in range(nt):
+        if it == nt - 1:
+            itout.append(it)
+        elif it > 1 and it % int(nt / float(ntout)) == 0:
+            itout.append(it)
+    return itout
+
+
+class Calculator(object):
+    def __init__(self, transport=None, dt=None, tmax=None, ntout=1, calc=None, scale_pb_grid=None, tau_jacobi=1e-7,
+                 tau_scf=5e-5, mix_scf=0.5, mode='time-dependent', desc_method='external', device=0):
+        if transport is None:
+            raise CalculatorError('No transport object provided for calculator.')
+        self.tp = transport
+        self.mode = mode
+        self.tau_scf = tau_scf
+        self.mix_scf = mix_scf
+        self.device = device
+        if calc is None:
+            calc = self.tp.calc
+        if calc is None:
+            raise CalculatorError('No calculator name given (tp.set_calculator / calc=)')
+        self.tp.ntout = ntout
+        self.tp.desc_method = 'external'
+        # '<name>[--LF|--<method>]', calculator.py:81-91
+        self.use_lax_friedrich = False
+        self.calc_method = None
+        string = calc.split('--')
+        if len(string) > 1:
+            if string[-1] == 'LF':
+                self.use_lax_friedrich = True
+            else:
+                self.calc_method = string[-1]
+        self.calc = string[0]
+        if self.calc not in CALC_LIST:
+            raise CalculatorError('No calculator found with this name. Aborting.')
+        if self.calc not in GPU_CALCS:
+            raise CalculatorError("calculator '%s' is not part of the MI355X transport path "
+                                  "(supported: %s)" % (self.calc, ', '.join(GPU_CALCS)))
+        if scale_pb_grid is not None:
+            raise CalculatorError('scale_pb_grid is broken in the reference (calculator_old.py:686-687) and not supported')
+        self.scale_pb_grid = scale_pb_grid
+        self.tau_jacobi = tau_jacobi
+        # time mesh, calculator.py:105-116
+        if dt is not None:
+            self.tp.dt = dt
+        if tmax is not None:
+            self.tp.tmax = tmax
+        if tmax is not None or dt is not None:
+            self.tp.tmesh = np.arange(0, self.tp.tmax + self.tp.dt, self.tp.dt)
+        else:
+            self.tp.tmesh = np.arange(0, 1, 0.1)
+            self.tp.dt = 0.1
+        self.tp.nt = len(self.tp.tmesh)
+        self.tp.itout = make_itout(self.tp.nt, self.tp.ntout)
+        self.tp.ntout = len(self.tp.itout)
+
+    # ------------------------------------------------------------------------------------------
+    def _solver(self, B, pb_mode, dx, nx, dt):
+        tp = self.tp
+        s = PnpSolver(nspecies=tp.nspecies, nx=nx, dx=dx, dt=dt, beta=tp.beta, eps=tp.eps, D=tp.D, charges=tp.charges,
+                      method=self.calc, pb_mode=pb_mode, lax_friedrich=self.use_lax_friedrich,
+                      use_migration=tp.use_migration, batch_capacity=B, device=self.device)
+        if getattr(tp, 'use_reactions', False) and getattr(tp, 'reactions', None):
+            names = list(tp.species.keys())
+            table = []
+            for r in tp.reactions:
+                rx = tp.reactions[r]
+                if 'rates' not in rx:
+                    continue
+                table.append(([names.index(x) for x in rx['reactants'][0] if x in names],
+                              [names.index(x) for x in rx['reactants'][1] if x in names],
+                              float(rx['rates'][0]), float(rx['rates'][1])))
+            if self.calc == 'FTCS':
+                s.set_reactions(table)
+        elif self.calc == 'FTCS' and getattr(tp, 'reactions', None):
+            # the reference's FTCS always calls get_rates (calculator_old.py:998)
+            names = list(tp.species.keys())
+            table = [([names.index(x) for x in rx['reactants'][0] if x in names],
+                      [names.index(x) for x in rx['reactants'][1] if x in names],
+                      float(rx['rates'][0]), float(rx['rates'][1]))
+                     for rx in tp.reactions.values() if 'rates' in rx]
+            if table:
+                s.set_reactions(table)
+        return s
+
+    def integrate_pnp_batch(self, c0, pb, vzeta, flux, dx=None, nx=None, dt=None, nt=None, itout=None):
+        """All lanes at once: c0 [B][N*nx], pb [B][4] (NaN = unset), vzeta [B], flux [B][N].
+        Returns (cout [n_out][B][N*nx], status [B], (v, grad_v, lapl_v) of the last Poisson solve)."""
+        tp = self.tp
+        dx = tp.dx if dx is None else dx
+        nx = tp.nx if nx is None else nx
+        dt = tp.dt if dt is None else dt
+        nt = tp.nt if nt is None else nt
+        itout = tp.itout if itout is None else itout
+        c0 = np.ascontiguousarray(c0, dtype=np.float64)
+        B = c0.shape[0]
+        pb = np.asarray(pb, dtype=np.float64).reshape(B, 4)
+        modes = {pb_mode_from_bound(p) for p in pb}
+        if len(modes) != 1:
+            raise CalculatorError('all lanes of a batch must use the same pb_bound combination')
+        with self._solver(B, modes.pop(), dx, nx, dt) as s:
+            s.set_batch(c0, pb, vzeta, flux)
+            cout, status = s.integrate(nt, itout)
+            _, v, g, l = s.get_state()
+        return cout, status, (v, g, l)
+
+    def integrate_pnp(self, dx, nx, dt, nt, ntout, method):
+        """Drop-in for the reference's single-operating-point seam (calculator_old.py:210): returns the list
+        of flattened [N*nx] states at tp.itout and stores tp.potential / tp.efield / tp.total_charge
+        (calculator_old.py:816-818)."""
+        tp = self.tp
+        if method != self.calc:
+            raise CalculatorError('integrate_pnp: method %r differs from the calculator %r' % (method, self.calc))
+        cout, status, (v, g, l) = self.integrate_pnp_batch(
+            tp.c0[None, :], tp.pb_array()[None, :], [tp.system['vzeta']], tp.flux_bound[None, :, 0],
+            dx=dx, nx=nx, dt=dt, nt=nt, itout=tp.itout)
+        tp.potential = v[0]
+        tp.efield = -g[0]
+        tp.total_charge = -l[0] * tp.eps
+        self.status = int(status[0])
+        return [cout[i, 0].copy() for i in range(cout.shape[0])]
+
+    # ------------------------------------------------------------------------------------------
+    def run(self):
+        """Descriptor sweep (calculator.py:196-240) with every descriptor point as one GPU lane.
+        Fills tp.alldata[i]['species'|'system'] with the field contract of comsol_reader.py:196-326
+        that the FD path can provide (concentration, surface_concentration, potential, efield,
+        surface_potential, surface_efield, charge_density)."""
+        tp = self.tp
+        keys = list(tp.descriptors.keys())
+        lanes = tp.alldata_names
+        B = len(lanes)
+        pb = np.zeros((B, 4)); vz = np.zeros(B)
+        for i, (v1, v2) in enumerate(lanes):
+            system = dict(tp.system)
+            system[keys[0]] = v1
+            system[keys[1]] = v2
+            if 'phiM' in keys and 'vzeta' not in (keys[0], keys[1]):
+                system['vzeta'] = system['phiM']
+            pb[i] = tp.pb_array(system)
+            vz[i] = system['vzeta']
+        c0 = np.repeat(tp.c0[None, :], B, axis=0)
+        flux = np.repeat(tp.flux_bound[None, :, 0], B, axis=0)
+        cout, status, (v, g, l) = self.integrate_pnp_batch(c0, pb, vz, flux)
+        self.status = status
+        names = list(tp.species.keys())
+        for i in range(B):
+            cfin = cout[-1, i].reshape(tp.nspecies, tp.nx)
+            d = tp.alldata[i]
+            for k, sp in enumerate(names):
+                d['species'][sp] = {'concentration': cfin[k].copy(), 'surface_concentration': float(cfin[k, 0])}
+            d['system'] = {'potential': v[i].copy(), 'efield': -g[i], 'charge_density': -l[i] * tp.eps,
+                           'surface_potential': float(v[i, 0]), 'surface_efield': float(-g[i, 0]),
+                           keys[0]: lanes[i][0], keys[1]: lanes[i][1], 'status': int(status[i])}
+        return cout
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def evaluate_accuracy(par, par_old):
+        """calculator.py:260-283 -- note the division by the SIGNED new value."""
+        acc = -np.inf
+        for k in par:
+            p1, p2 = par[k], par_old[k]
+            if p1 != 0:
+                acc = max(acc, abs(p1 - p2) / p1)
+        return acc

@@ -1,0 +1,116 @@
+"""GPU: BASELINE.json sizes.  configs[1] (batch=1024, 3 species, 512 grid points) against the C oracle on
+a lane subsample, plus size-independent properties on the whole batch; configs[3]-shaped lanes
+(6 species, 1024 points) on a reduced batch; ragged / extreme sizes; status flags."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from catint_amd.synthetic import make_batch
+from catint_amd.host import solver_from_problem
+from catint_amd import PnpSolver, PnpError, PB_DD
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def oracle_steps(p, method, c0, pb, vz, fl, nsteps):
+    c = np.ascontiguousarray(c0.reshape(c0.shape[0], len(p.D), p.nx).copy())
+    pot = CO.steps(p, method, c, pb, vz, fl, nsteps)
+    return c, pot
+
+
+@pytest.mark.parametrize('method,nsteps', [('Crank-Nicolson', 25), ('FTCS', 25)])
+def test_config2_against_oracle_and_properties(method, nsteps):
+    B, N, nx = 1024, 3, 512
+    p, c0, pb, vz, fl = make_batch(B, N, nx, seed=42, phi_max=0.025, dt_factor=1e-4 if method == 'Crank-Nicolson' else 2e-5)
+    with solver_from_problem(p, method, batch_capacity=B) as s:
+        s.set_batch(c0, pb, vz, fl)
+        s.step(nsteps, 1)                      # one launch per timestep
+        c, v, g, l = s.get_state()
+        st = s.get_status()
+        s.set_batch(c0, pb, vz, fl)
+        s.step(nsteps, 0)                      # fused launches
+        c2, v2, g2, l2 = s.get_state()
+        # lane permutation: lanes are independent, so permuting inputs permutes outputs bit for bit
+        perm = np.random.default_rng(1).permutation(B)
+        s.set_batch(c0[perm], pb[perm], vz[perm], fl[perm])
+        s.step(nsteps, 0)
+        c3 = s.get_state(potential=False)
+    assert np.isfinite(c).all() and (st == 0).all()
+    assert np.array_equal(c, c2) and np.array_equal(v, v2) and np.array_equal(g, g2) and np.array_equal(l, l2)
+    assert np.array_equal(c3, c[perm])
+    # Dirichlet bulk value is held (calculator_old.py:540 / :1008); wall potential is the prescribed one
+    assert np.array_equal(c[:, :, -1], c0.reshape(B, N, nx)[:, :, -1])
+    assert np.array_equal(v[:, 0], pb[:, 0]) and np.array_equal(v[:, -1], pb[:, 1])
+    # charge row consistency: lapl_v of the LAST Poisson solve belongs to the state one step earlier,
+    # so advance the oracle on a subsample and compare everything
+    sub = np.arange(0, B, 37)
+    ref, (rv, rg, rl) = oracle_steps(p, method, c0[sub], pb[sub], vz[sub], fl[sub], nsteps)
+    assert relerr(c[sub], ref) < RTOL
+    assert relerr(v[sub], rv) < RTOL and relerr(g[sub], rg) < RTOL and relerr(l[sub], rl) < RTOL
+
+
+def test_config4_shape_lanes():
+    """6 species, 1024 grid points (BASELINE configs[3] per-lane shape) on a reduced batch."""
+    B, N, nx = 96, 6, 1024
+    p, c0, pb, vz, fl = make_batch(B, N, nx, seed=7, phi_max=0.02, dt_factor=1e-4)
+    with solver_from_problem(p, 'Crank-Nicolson', batch_capacity=B) as s:
+        s.set_batch(c0, pb, vz, fl)
+        s.step(12)
+        c, v, g, l = s.get_state()
+    ref, (rv, rg, rl) = oracle_steps(p, 'Crank-Nicolson', c0, pb, vz, fl, 12)
+    assert relerr(c, ref) < RTOL and relerr(v, rv) < RTOL and relerr(g, rg) < RTOL
+
+
+@pytest.mark.parametrize('nx', [5, 6, 66, 67, 130, 131, 258, 259, 513, 514, 515, 1025, 1026])
+def test_ragged_grid_sizes(nx):
+    """every points-per-lane instantiation at its edges, incl. the reference's odd mesh sizes (513, 1025)"""
+    B, N = 5, 2
+    p, c0, pb, vz, fl = make_batch(B, N, nx, seed=nx, phi_max=0.02, dt_factor=1e-4)
+    rng = np.random.default_rng(nx)
+    c0 = c0 * (1 + 0.05 * rng.uniform(-1, 1, c0.shape))
+    fl = rng.uniform(-1e-4, 1e-4, fl.shape)
+    for method in ('Crank-Nicolson', 'FTCS'):
+        p.dt = p.dt if method == 'Crank-Nicolson' else p.dt * 0.2
+        with solver_from_problem(p, method, batch_capacity=B) as s:
+            s.set_batch(c0, pb, vz, fl)
+            s.step(6)
+            c, v, g, l = s.get_state()
+        ref, (rv, rg, rl) = oracle_steps(p, method, c0, pb, vz, fl, 6)
+        assert relerr(c, ref) < RTOL, (nx, method)
+        assert relerr(v, rv) < RTOL and relerr(g, rg) < RTOL and relerr(l, rl) < RTOL
+
+
+def test_limits_and_errors():
+    p, c0, pb, vz, fl = make_batch(2, 2, 64)
+    for bad_nx in (4, 1027, 4096):
+        with pytest.raises(PnpError):
+            PnpSolver(2, bad_nx, p.dx, p.dt, p.beta, p.eps, p.D, p.charges)
+    with pytest.raises(PnpError):
+        PnpSolver(17, 64, p.dx, p.dt, p.beta, p.eps, np.ones(17), np.ones(17))
+    with pytest.raises(PnpError):
+        PnpSolver(2, 64, p.dx, p.dt, p.beta, p.eps, p.D, p.charges, method='vode')
+    s = PnpSolver(2, 64, p.dx, p.dt, p.beta, p.eps, p.D, p.charges, batch_capacity=2)
+    with pytest.raises(PnpError):
+        s.step(1)                                  # no batch yet
+    with pytest.raises(PnpError):
+        s.set_batch(np.zeros((3, 128)), np.zeros((3, 4)), np.zeros(3), np.zeros((3, 2)))   # over capacity
+    s.close()
+
+
+def test_status_flags_nan_and_negative():
+    p, c0, pb, vz, fl = make_batch(4, 2, 64, phi_max=0.01)
+    c0 = c0.copy()
+    c0[1, 10] = np.nan                 # lane 1 poisoned
+    c0[2, :64] = -1.0                  # lane 2 negative concentration
+    with solver_from_problem(p, 'Crank-Nicolson', batch_capacity=4) as s:
+        s.set_batch(c0, pb, vz, fl)
+        s.step(2)
+        st = s.get_status()
+        c = s.get_state(potential=False)
+    assert st[0] == 0 and st[3] == 0 and st[1] == 2 and st[2] == 3
+    assert np.isfinite(c[0]).all() and np.isfinite(c[3]).all()   # no cross-lane contamination
