@@ -40,31 +40,36 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline sample length')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
+    ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'hbm_traffic_latest.json'),
+                    help='rocprofv3 PMC result (tools/pmc_traffic.py) for this workload; merged into roofline.traffic')
     return ap.parse_args()
 
 
 def cpu_baseline(prob, c0, pb, vz, fl, method, target_s):
-    """The oracle (C port of the reference algorithm, Thomas solves) on all host cores."""
+    """The oracle (C port of the reference algorithm, Thomas solves) on the host cores this process may use."""
     from oracle import c_oracle as CO
     CO.load()
-    cores = CO.max_threads()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, CO.max_threads()))
     B = c0.shape[0]
     N, nx = prob.N, prob.nx
     c = c0.reshape(B, N, nx).copy()
-    # calibrate on a short run, then size the sample
+    CO.steps(prob, method, c, pb, vz, fl, 2, want_potential=False, nthreads=cores)     # spin up the thread pool
     t0 = time.perf_counter()
-    CO.steps(prob, method, c, pb, vz, fl, 5, want_potential=False)
-    t1 = time.perf_counter() - t0
-    rate = B * 5 / max(t1, 1e-9)
-    nsteps = int(max(10, min(5000, target_s * rate / B)))
+    CO.steps(prob, method, c, pb, vz, fl, 20, want_potential=False, nthreads=cores)
+    rate = B * 20 / max(time.perf_counter() - t0, 1e-9)
+    nsteps = int(max(20, min(20000, target_s * rate / B)))
     c = c0.reshape(B, N, nx).copy()
     t0 = time.perf_counter()
-    CO.steps(prob, method, c, pb, vz, fl, nsteps, want_potential=False)
+    CO.steps(prob, method, c, pb, vz, fl, nsteps, want_potential=False, nthreads=cores)
     dt = time.perf_counter() - t0
     return {
         'value': B * nsteps / dt, 'unit': 'timesteps/s', 'cores': cores, 'kind': 'port',
-        'sample': '%d lanes x %d steps of the same workload, C restatement (oracle/pnp_oracle.c, banded Thomas, OpenMP) '
-                  'in %.1f s' % (B, nsteps, dt),
+        'sample': '%d lanes x %d steps of the same workload, C restatement of the reference algorithm '
+                  '(oracle/pnp_oracle.c: banded Thomas instead of dense LU, OpenMP over lanes) in %.1f s' % (B, nsteps, dt),
     }
 
 
@@ -146,13 +151,14 @@ def main():
     cs, vs, es = solver.get_surface()
     gather_ms = None
     if dist is not None:
-        obs = torch.from_numpy(np.concatenate([cs, vs[:, None], es[:, None]], axis=1)).cuda()
-        out = torch.empty((world,) + tuple(obs.shape), dtype=obs.dtype, device='cuda')
+        from catint_amd.parallel import gather_observables
+        obs = np.concatenate([cs, vs[:, None], es[:, None]], axis=1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.all_gather_into_tensor(out, obs)
+        curve = gather_observables(obs, world * B, dist, device=torch.device('cuda', local_rank))
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t0) * 1e3
+        assert curve.shape == (world * B, N + 2)
 
     if rank == 0:
         alg_bytes_per_launch = 16.0 * (N + 1) * nx * B * args.steps_per_launch   # 2*8*(N+1)*nx per point-step
@@ -172,6 +178,16 @@ def main():
                          'launch_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg_bytes_per_launch},
             'lanes_ok': int((status == 0).sum()), 'lanes_total': int(B),
         }
+        # measured HBM bytes per launch come from a separate rocprofv3 --pmc pass of this same command
+        # (profiles/, MI355X_MICROARCH.md HBM section: FETCH_SIZE doubled on gfx950); null when absent
+        try:
+            tj = json.load(open(args.traffic_json))
+            if (tj.get('batch'), tj.get('nspecies'), tj.get('nx'), tj.get('steps_per_launch')) == \
+                    (B, N, nx, args.steps_per_launch) and tj.get('method') == args.method:
+                out['roofline']['traffic'] = tj['hbm_bytes_per_launch']
+                out['roofline']['traffic_source'] = tj.get('source')
+        except Exception:
+            pass
         if fused:
             out['fused'] = fused
         if gather_ms is not None:
