@@ -29,6 +29,7 @@ struct pnp_handle {
   SpecConst* spec = nullptr;
   int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
   int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
+  int kernel_override = 0;   // CATINT_PNP_KERNEL = 2 (LDS-staged) | 3 (register-resident)
   int32_t* status = nullptr;
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
   int64_t dev_bytes = 0;
@@ -142,6 +143,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
 #undef HIP_TRYC
   if (const char* e = getenv("CATINT_PNP_WAVES_PER_GRID")) h->waves_override = atoi(e);
   if (const char* e = getenv("CATINT_PNP_SPECIES_PER_WAVE")) h->species_override = atoi(e);
+  if (const char* e = getenv("CATINT_PNP_KERNEL")) h->kernel_override = atoi(e);
   DevArgs& a = h->a;
   a.N = N;
   a.nx = cfg->nx;
@@ -302,15 +304,27 @@ static int run_steps(pnp_handle* h, int nsteps) {
   }
   int W = 1, G = 1;
   choose_step_config(a.N, a.B, h->P, &W, &G);
-  if (h->waves_override >= 1 || h->species_override >= 1) {
-    const int w2 = h->waves_override >= 1 ? h->waves_override : W;
-    const int g2 = h->species_override >= 1 ? h->species_override : 1;
-    if (step_config_supported(w2, g2)) {
-      W = w2;
-      G = g2;
+  // Measured on MI355X: with fewer lanes than SIMDs x 2 the LDS-staged kernel with three
+  // interleaved species per wave has the shortest critical path; once the batch oversubscribes the chip the
+  // register-resident kernel (one species at a time, 3 waves/SIMD) wins because the LDS pipe stops being shared.
+  bool use3 = step3_applicable(a) && a.B >= 2048;
+  if (h->kernel_override == 2) use3 = false;
+  if (h->kernel_override == 3) use3 = step3_applicable(a);
+  if (use3) {
+    int g3 = 1;
+    if (h->species_override >= 1 && h->species_override <= 3) g3 = h->species_override;
+    HIP_TRY(h, launch_step3(a, g3, h->stream));
+  } else {
+    if (h->waves_override >= 1 || h->species_override >= 1) {
+      const int w2 = h->waves_override >= 1 ? h->waves_override : W;
+      const int g2 = h->species_override >= 1 ? h->species_override : 1;
+      if (step_config_supported(w2, g2)) {
+        W = w2;
+        G = g2;
+      }
     }
+    HIP_TRY(h, launch_step(a, W, G, h->stream));
   }
-  HIP_TRY(h, launch_step(a, W, G, h->stream));
   if (nsteps & 1) h->cur = 1 - h->cur;
   h->steps_done += nsteps;
   return PNP_OK;

@@ -1,11 +1,14 @@
 #!/bin/bash
-# run on the GPU box: parity for every (waves-per-grid, species-per-wave) variant, then the bench
+# run on the GPU box: parity for every kernel variant, then the bench (JSON to gpurun_out/$1.json)
 set -o pipefail
 tag=${1:-bench}
-timeout -k 10 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 || exit 1
+timeout -k 10 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 || exit 1
+for g in 1 2 3; do
+  CATINT_PNP_KERNEL=3 CATINT_PNP_SPECIES_PER_WAVE=$g timeout -k 10 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 || { echo "FAILED for kernel3 G=$g"; exit 1; }
+done
 for c in 1,1 1,2 1,3 2,1 2,2 3,1 4,1; do
   w=${c%,*}; g=${c#*,}
-  CATINT_PNP_WAVES_PER_GRID=$w CATINT_PNP_SPECIES_PER_WAVE=$g timeout -k 10 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 || { echo "FAILED for W=$w G=$g"; exit 1; }
+  CATINT_PNP_KERNEL=2 CATINT_PNP_WAVES_PER_GRID=$w CATINT_PNP_SPECIES_PER_WAVE=$g timeout -k 10 400 python -m pytest tests/test_gpu_parity_golden.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -1 || { echo "FAILED for kernel2 W=$w G=$g"; exit 1; }
 done
 timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/$tag.json 2> gpurun_out/$tag.err || { tail -5 gpurun_out/$tag.err; exit 1; }
 python - "$tag" <<'PY'
