@@ -850,13 +850,13 @@ __device__ __forceinline__ double read_lane(double v, int l) {   // l wave-unifo
   return __hiloint2double(hi, lo);
 }
 
-// value of a blocked array at wave-uniform interior index q (lane q/P, row q%P)
+// value of a blocked array at wave-uniform interior index q (lane q/P, row q%P).  Written with per-lane
+// compares on purpose: a wave-uniform register index makes LLVM spill the array to scratch.
 template <int P>
-__device__ __forceinline__ double pick_blocked(const double (&a)[P], int q) {
-  const int jq = q % P;
-  double v = a[0];
+__device__ __forceinline__ double pick_blocked(const double (&a)[P], int r0, int q) {
+  double v = 0.0;
 #pragma unroll
-  for (int j = 1; j < P; ++j) v = (j == jq) ? a[j] : v;
+  for (int j = 0; j < P; ++j) v = (r0 + j == q) ? a[j] : v;
   return read_lane(v, q / P);
 }
 
@@ -888,7 +888,7 @@ constexpr int step3_min_waves() {
   return P == 2 ? 4 : (P == 4 ? (G == 1 ? 4 : 2) : (P == 8 ? (G == 1 ? 3 : 1) : 1));
 }
 
-template <int P, int G>
+template <int P, int G, bool CN>
 __global__ __launch_bounds__(64, (step3_min_waves<P, G>())) void step_kernel3(const DevArgs A) {
   static_assert(P >= 2 && P % 2 == 0, "window loads need an even P");
   extern __shared__ __attribute__((aligned(16))) double lds[];   // G strips of 384 doubles
@@ -897,18 +897,13 @@ __global__ __launch_bounds__(64, (step3_min_waves<P, G>())) void step_kernel3(co
   const int64_t b = blockIdx.x;
   const int nx = A.nx, m = A.m, ldx = A.ldx, N = A.N;
   const int r0 = lane * P;
-  const double dx = A.dx, dt = A.dt;
-  const bool cn = (A.method == PNP_METHOD_CRANK_NICOLSON);
+  const double dx = A.dx;
+  constexpr bool cn = CN;
   double* lin = A.lapl_a + b * (int64_t)ldx;
   double* lout = A.lapl_b + b * (int64_t)ldx;
   double* crow0 = A.c + b * (int64_t)N * ldx;
   const double vw = A.pb[b * 4 + 0], vb = A.pb[b * 4 + 1];
   const double vz = A.vzeta[b];
-  // wave-uniform positions: last real row m-1 = row jmu of lane lm; the bulk point nx-1 = interior index m
-  const int lm = (m - 1) / P, jmu = (m - 1) % P;
-  const bool in_lm = lane == lm;
-  const int lq = m / P, jq = m % P;
-  const bool in_lq = lane == lq;
   const bool single_round = (N <= G);
   double chk = 0.0, mn = 0.0;
 
@@ -927,16 +922,18 @@ __global__ __launch_bounds__(64, (step3_min_waves<P, G>())) void step_kernel3(co
     if (A.use_mig) {
       double Hi[P];
       const double dx2 = dx * dx;
-      double wsum = 0.0;
-      const double wj0 = (double)(m - r0);
+      double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         double h = lw[j + 1] * dx2;                       // grid r0+j+1; pads and out-of-range are 0
-        if (j == jq) h = in_lq ? 0.0 : h;                 // the bulk point is not part of the interior sum
+        h = (r0 + j == m) ? 0.0 : h;                      // the bulk point is not part of the interior sum
         Hi[j] = h;
-        wsum = __builtin_fma(wj0 - (double)j, h, wsum);   // G_{nx-1} = sum_r (m - r) h_r
+        s0 += h;
+        s1 = __builtin_fma((double)j, h, s1);
       }
-      const double hm1 = pick_blocked<P>(Hi, m - 1), hm2 = pick_blocked<P>(Hi, m - 2);
+      // G_{nx-1} = sum_r (m - r) h_r, this lane's share: (m - r0) * sum_j h_j - sum_j j*h_j
+      const double wsum = __builtin_fma((double)(m - r0), s0, -s1);
+      const double hm1 = pick_blocked<P>(Hi, r0, m - 1), hm2 = pick_blocked<P>(Hi, r0, m - 2);
       const double h0 = read_lane(Hi[0], 0), h1 = read_lane(Hi[1], 0);
 #pragma unroll
       for (int j = 1; j < P; ++j) Hi[j] += Hi[j - 1];
@@ -971,8 +968,8 @@ __global__ __launch_bounds__(64, (step3_min_waves<P, G>())) void step_kernel3(co
       // the bulk boundary term uses grad_v[-1] (:498): CN reads it at interior index nx-2, FTCS at grid nx-1
 #pragma unroll
       for (int t = 2; t < P + 3; ++t) {
-        if (t == jmu + 2 && cn) gx[t] = in_lm ? g_last : gx[t];
-        if (t == jmu + 3) gx[t] = in_lm ? g_last : gx[t];
+        const int idx = r0 - 1 + t;                        // gx[t] = grad_v[idx]
+        gx[t] = ((cn && idx == nx - 2) || idx == nx - 1) ? g_last : gx[t];
       }
     } else {
 #pragma unroll
@@ -1017,8 +1014,7 @@ __global__ __launch_bounds__(64, (step3_min_waves<P, G>())) void step_kernel3(co
         const double patL = cn ? (cL + cL) : cL;
         cc[g][0] = (lane == 0) ? pat0 : cc[g][0];
 #pragma unroll
-        for (int t = 2; t < P + 2; ++t)
-          if (t == jmu + 2) cc[g][t] = in_lm ? patL : cc[g][t];
+        for (int t = 2; t < P + 2; ++t) cc[g][t] = (r0 + t == nx - 1) ? patL : cc[g][t];
       }
       if (cn) {
         double ta[G][P], tc[G][P];
@@ -1036,8 +1032,7 @@ __global__ __launch_bounds__(64, (step3_min_waves<P, G>())) void step_kernel3(co
             const double right = cc[g][j + 2] * (hsr - gp);
             x[g][j] = left + cc[g][j + 1] * (omsr + eer * lw[j]) + right;
             ta[g][j] = -hsr + g0;                                        // A[r,r-1], :487
-            tc[g][j] = -hsr - g0;                                        // A[r,r+1], :490
-            if (j == jmu) tc[g][j] = in_lm ? 0.0 : tc[g][j];             // the last real row has no super-diagonal
+            tc[g][j] = (r0 + j == m - 1) ? 0.0 : (-hsr - g0);            // A[r,r+1], :490; none in the last real row
           }
           ta[g][0] = (lane == 0) ? 0.0 : ta[g][0];                       // the first row has no sub-diagonal
         }
@@ -1268,10 +1263,14 @@ template <int P>
 static hipError_t launch_step3_p(const DevArgs& a, int G, hipStream_t stream) {
   const dim3 grid((unsigned)a.B), block(64);
   const size_t lds = (size_t)G * 384 * sizeof(double);
-  switch (G) {
-    case 1: hipLaunchKernelGGL((step_kernel3<P, 1>), grid, block, lds, stream, a); break;
-    case 2: hipLaunchKernelGGL((step_kernel3<P, 2>), grid, block, lds, stream, a); break;
-    case 3: hipLaunchKernelGGL((step_kernel3<P, 3>), grid, block, lds, stream, a); break;
+  const bool cn = a.method == PNP_METHOD_CRANK_NICOLSON;
+  switch (G * 2 + (cn ? 1 : 0)) {
+    case 3: hipLaunchKernelGGL((step_kernel3<P, 1, true>), grid, block, lds, stream, a); break;
+    case 5: hipLaunchKernelGGL((step_kernel3<P, 2, true>), grid, block, lds, stream, a); break;
+    case 7: hipLaunchKernelGGL((step_kernel3<P, 3, true>), grid, block, lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((step_kernel3<P, 1, false>), grid, block, lds, stream, a); break;
+    case 4: hipLaunchKernelGGL((step_kernel3<P, 2, false>), grid, block, lds, stream, a); break;
+    case 6: hipLaunchKernelGGL((step_kernel3<P, 3, false>), grid, block, lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
