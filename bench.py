@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline sample length')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
+    ap.add_argument('--large-batch', type=int, default=8192,
+                    help='extra (non-headline) timed run at this batch size to show the oversubscribed regime; 0 = skip')
     ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'hbm_traffic_latest.json'),
                     help='rocprofv3 PMC result (tools/pmc_traffic.py) for this workload; merged into roofline.traffic')
     return ap.parse_args()
@@ -59,8 +61,8 @@ def cpu_baseline(prob, c0, pb, vz, fl, method, target_s):
     c = c0.reshape(B, N, nx).copy()
     CO.steps(prob, method, c, pb, vz, fl, 2, want_potential=False, nthreads=cores)     # spin up the thread pool
     t0 = time.perf_counter()
-    CO.steps(prob, method, c, pb, vz, fl, 20, want_potential=False, nthreads=cores)
-    rate = B * 20 / max(time.perf_counter() - t0, 1e-9)
+    CO.steps(prob, method, c, pb, vz, fl, 200, want_potential=False, nthreads=cores)
+    rate = B * 200 / max(time.perf_counter() - t0, 1e-9)
     nsteps = int(max(20, min(20000, target_s * rate / B)))
     c = c0.reshape(B, N, nx).copy()
     t0 = time.perf_counter()
@@ -159,6 +161,28 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t0) * 1e3
         assert curve.shape == (world * B, N + 2)
+    solver.close()
+
+    # oversubscribed regime (not the headline): same lanes-shape, many more of them than SIMDs
+    large = None
+    if world == 1 and args.large_batch > 0 and args.steps_per_launch == 1:
+        LB = args.large_batch
+        lp, lc0, lpb, lvz, lfl = make_batch(LB, N, nx, seed=77, phi_max=0.025, dt_factor=1e-4)
+        s2 = solver_from_problem(lp, args.method, batch_capacity=LB, device=local_rank)
+        s2.set_batch(lc0, lpb, lvz, lfl)
+        s2.step(5, 1)
+        s2.set_batch(lc0, lpb, lvz, lfl)
+        ls = max(10, min(args.steps, 50))
+        s2.synchronize()
+        s2.timer_start()
+        s2.step(ls, 1)
+        lms = s2.timer_stop()
+        lok = int((s2.get_status() == 0).sum())
+        s2.close()
+        lsec = lms * 1e-3 / ls
+        large = {'batch': LB, 'steps': ls, 'timesteps_per_s': LB / lsec, 'launch_us': lsec * 1e6,
+                 'achieved_GBs': 16.0 * (N + 1) * nx * LB / lsec / 1e9,
+                 'frac': 16.0 * (N + 1) * nx * LB / lsec / 1e9 / HBM_PEAK_GBS, 'lanes_ok': lok}
 
     if rank == 0:
         alg_bytes_per_launch = 16.0 * (N + 1) * nx * B * args.steps_per_launch   # 2*8*(N+1)*nx per point-step
@@ -174,7 +198,7 @@ def main():
                        'parallelism': 'batch-sharded x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'pnp::step_kernel<%d>' % next(P for P in (1, 2, 4, 8, 16) if nx - 2 <= 64 * P),
+                         'kernel': 'pnp::step_kernel (P=%d points/lane)' % next(P for P in (1, 2, 4, 8, 16) if nx - 2 <= 64 * P),
                          'launch_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg_bytes_per_launch},
             'lanes_ok': int((status == 0).sum()), 'lanes_total': int(B),
         }
@@ -190,6 +214,8 @@ def main():
             pass
         if fused:
             out['fused'] = fused
+        if large:
+            out['large_batch'] = large
         if gather_ms is not None:
             out['gather_ms'] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
@@ -198,7 +224,6 @@ def main():
                 cb['reference_faithful_dense_1core'] = cpu_reference_faithful(prob, c0, pb, vz, fl, args.method)
             out['cpu_baseline'] = cb
         print(json.dumps(out))
-    solver.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
