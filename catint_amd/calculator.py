@@ -187,6 +187,120 @@ class Calculator(object):
         return cout
 
     # ------------------------------------------------------------------------------------------
+    def _lane_inputs(self):
+        """Per-lane pb / vzeta for the descriptor lattice (calculator.py:204-219)."""
+        tp = self.tp
+        keys = list(tp.descriptors.keys())
+        lanes = tp.alldata_names
+        B = len(lanes)
+        pb = np.zeros((B, 4)); vz = np.zeros(B); phiM = np.zeros(B)
+        for i, (v1, v2) in enumerate(lanes):
+            system = dict(tp.system)
+            system[keys[0]] = v1
+            system[keys[1]] = v2
+            if 'phiM' in keys:
+                system['vzeta'] = system['phiM']
+            pb[i] = tp.pb_array(system)
+            vz[i] = system['vzeta']
+            phiM[i] = system['phiM']
+        return pb, vz, phiM
+
+    def run_scf_cycle(self, flux_callback, nel=None, nprod=None, max_iter=1000, transport_fn=None):
+        """Batched counterpart of the reference's SCF outer loop (catint/calculator.py:294-406): kinetics
+        (`flux_callback`, the seam where CatMAP sat, catmap_wrapper.py:106) <-> transport, once per iteration, for
+        every descriptor point at the same time.  Each lane carries its own mixing factor, iteration bookkeeping
+        and convergence flag; converged lanes are frozen (their surface state and fluxes stop changing) but keep
+        riding in the batch.
+
+        flux_callback(state) -> flux [B][N] in mol m^-2 s^-1 (educts negative, calculator.py:415-432), where
+        state = {'surface_concentration' [B][N], 'surface_pH' [B], 'phiM' [B], 'surface_potential' [B],
+                 'surface_efield' [B], 'istep'}.
+        transport_fn(flux) -> (csurf [B][N], vsurf [B], esurf [B]) replaces the GPU solve (host-logic tests).
+        Returns a dict with the per-lane results and bookkeeping."""
+        tp = self.tp
+        names = list(tp.species.keys())
+        N = tp.nspecies
+        pb, vz, phiM = self._lane_inputs()
+        B = len(phiM)
+        nel = np.ones(N) if nel is None else np.asarray(nel, float)
+        nprod = np.ones(N) if nprod is None else np.asarray(nprod, float)
+        sc = np.repeat(np.array([[tp.species[sp]['surface_concentration'] for sp in names]], float), B, axis=0)
+        flux = np.repeat(tp.flux_bound[None, :, 0], B, axis=0).astype(float)
+        mix = np.full(B, float(self.mix_scf))
+        acc = np.full(B, np.inf)
+        step_to_check = np.zeros(B, int)
+        active = np.ones(B, bool)
+        surface_pH = np.full(B, float(tp.system.get('bulk_pH', 7.0)))
+        vsurf = phiM.copy(); esurf = np.zeros(B)
+        sc_old = sc.copy(); cd_old = None
+        iH = names.index('H+') if 'H+' in names else None
+        iOH = names.index('OH-') if 'OH-' in names else None
+        solver = None
+        c0 = np.repeat(tp.c0[None, :], B, axis=0)
+        if transport_fn is None:
+            solver = self._solver(B, pb_mode_from_bound(pb[0]), tp.dx, tp.nx, tp.dt)
+        istep = 0
+        history = []
+        try:
+            while active.any() and istep < max_iter:       # :316
+                istep += 1
+                dec = active & (istep - step_to_check > 40)                                  # :319-323
+                mix[dec] *= 0.9
+                step_to_check[dec] = istep
+                if istep > 2:                                                               # :328-338
+                    mixed = np.where(sc < 0.0, sc_old, mix[:, None] * sc + (1. - mix[:, None]) * sc_old)
+                else:                                                                       # :341-344
+                    mixed = np.where(sc < 0.0, 1e-20, sc)
+                sc = np.where(active[:, None], mixed, sc)
+                if iH is not None:                                                          # :346-359
+                    ok = active & (sc[:, iH] > 0.0)
+                    surface_pH[ok] = -np.log10(sc[ok, iH] / 1000.)
+                elif iOH is not None:
+                    ok = active & (sc[:, iOH] > 0.0)
+                    surface_pH[ok] = 14 + np.log10(sc[ok, iOH] / 1000.)
+                sc_old = np.where(active[:, None], sc, sc_old)                              # :362-364
+                newflux = np.asarray(flux_callback({'surface_concentration': sc.copy(), 'surface_pH': surface_pH.copy(),
+                                                    'phiM': phiM, 'surface_potential': vsurf.copy(),
+                                                    'surface_efield': esurf.copy(), 'istep': istep}), float)
+                flux = np.where(active[:, None], newflux.reshape(B, N), flux)               # :373
+                if transport_fn is not None:                                                # :385 run_single_step
+                    cs, vs, es = transport_fn(flux)
+                    status = np.zeros(B, np.int32)
+                else:
+                    solver.set_batch(c0, pb, vz, flux)
+                    n_first = 1 if self.calc == 'Crank-Nicolson' else 0
+                    solver.step(tp.nt - n_first)
+                    cs, vs, es = solver.get_surface()
+                    status = solver.get_status()
+                sc = np.where(active[:, None], cs, sc)
+                vsurf = np.where(active, vs, vsurf)
+                esurf = np.where(active, es, esurf)
+                cd = flux * nel[None, :] * unit_F / nprod[None, :] / 10.                    # mA/cm^2, :389-400
+                if istep > 1:                                                               # :401-402, signed quirk :274
+                    with np.errstate(divide='ignore', invalid='ignore'):
+                        err = np.where(cd != 0, np.abs(cd - cd_old) / cd, -np.inf)
+                    acc = np.where(active, err.max(axis=1), acc)
+                cd_old = cd if cd_old is None else np.where(active[:, None], cd, cd_old)
+                history.append(acc.copy())
+                active = active & ((acc > self.tau_scf) | (sc < 0.0).any(axis=1))
+        finally:
+            if solver is not None:
+                solver.close()
+        for i in range(B):
+            d = tp.alldata[i]
+            d.setdefault('species', {}); d.setdefault('system', {})
+            for k, sp in enumerate(names):
+                d['species'].setdefault(sp, {})
+                d['species'][sp]['surface_concentration'] = float(sc[i, k])
+                d['species'][sp]['flux'] = float(flux[i, k])
+                d['species'][sp]['electrode_current_density'] = float(flux[i, k] * nel[k] * unit_F / nprod[k] / 10.)
+            d['system'].update({'surface_pH': float(surface_pH[i]), 'surface_potential': float(vsurf[i]),
+                                'surface_efield': float(esurf[i]), 'phiM': float(phiM[i])})
+        return {'surface_concentration': sc, 'flux': flux, 'current_density': flux * nel * unit_F / nprod / 10.,
+                'surface_pH': surface_pH, 'accuracy': acc, 'converged': ~active, 'iterations': istep, 'mix': mix,
+                'history': np.array(history)}
+
+    # ------------------------------------------------------------------------------------------
     @staticmethod
     def evaluate_accuracy(par, par_old):
         """calculator.py:260-283 -- note the division by the SIGNED new value."""
