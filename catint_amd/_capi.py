@@ -28,7 +28,7 @@ STATUS_OK, STATUS_NAN, STATUS_NEGATIVE = 0, 2, 3
 # every symbol include/catint_pnp.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     'pnp_create', 'pnp_destroy', 'pnp_last_error', 'pnp_version', 'pnp_set_species', 'pnp_set_reactions',
-    'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_get_state',
+    'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch',
 ]
@@ -84,6 +84,7 @@ def load_library():
     lib.pnp_set_pb.argtypes = [vp, dp, dp]
     lib.pnp_step.argtypes = [vp, C.c_int32, C.c_int32]
     lib.pnp_integrate.argtypes = [vp, C.c_int32, ip, C.c_int32, dp, ip]
+    lib.pnp_mol_rhs.argtypes = [vp, dp, dp]
     lib.pnp_get_state.argtypes = [vp, dp, dp, dp, dp]
     lib.pnp_get_surface.argtypes = [vp, dp, dp, dp]
     lib.pnp_get_status.argtypes = [vp, ip]
@@ -91,7 +92,7 @@ def load_library():
     lib.pnp_timer_start.argtypes = [vp]
     lib.pnp_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     for name in ('pnp_set_species', 'pnp_set_reactions', 'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step',
-                 'pnp_integrate', 'pnp_get_state', 'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize',
+                 'pnp_integrate', 'pnp_mol_rhs', 'pnp_get_state', 'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize',
                  'pnp_timer_start', 'pnp_timer_stop'):
         getattr(lib, name).restype = C.c_int
     lib.pnp_device_bytes.argtypes = [vp]
@@ -206,6 +207,13 @@ class PnpSolver(object):
         status = np.zeros(self.B, np.int32)
         self._check(self._lib.pnp_integrate(self._h, int(nt), _iptr(itout), len(itout), _dptr(cout), _iptr(status)))
         return cout, status
+
+    def mol_rhs(self, c):
+        """ode_func for the current batch: c [B][N*nx] -> dc/dt [B][N*nx] (calculator_old.py:827-935)."""
+        c = _f64(np.asarray(c, dtype=np.float64).reshape(self.B, self.N * self.nx))
+        out = np.zeros_like(c)
+        self._check(self._lib.pnp_mol_rhs(self._h, _dptr(c), _dptr(out)))
+        return out
 
     # -- read-back -------------------------------------------------------------------------
     def get_state(self, potential=True):

@@ -20,6 +20,7 @@ from .units import unit_F
 
 CALC_LIST = ['FTCS', 'Crank-Nicolson', 'odeint', 'vode', 'lsoda', 'dopri5', 'dop853', 'odeint', 'odespy', 'comsol']
 GPU_CALCS = ('FTCS', 'Crank-Nicolson')
+MOL_CALCS = ('odeint', 'lsoda', 'dopri5', 'dop853')   # method of lines: scipy driver, RHS on the GPU
 
 
 class CalculatorError(ValueError):
@@ -65,9 +66,9 @@ class Calculator(object):
         self.calc = string[0]
         if self.calc not in CALC_LIST:
             raise CalculatorError('No calculator found with this name. Aborting.')
-        if self.calc not in GPU_CALCS:
+        if self.calc not in GPU_CALCS + MOL_CALCS:
             raise CalculatorError("calculator '%s' is not part of the MI355X transport path "
-                                  "(supported: %s)" % (self.calc, ', '.join(GPU_CALCS)))
+                                  "(supported: %s)" % (self.calc, ', '.join(GPU_CALCS + MOL_CALCS)))
         if scale_pb_grid is not None:
             raise CalculatorError('scale_pb_grid is broken in the reference (calculator_old.py:686-687) and not supported')
         self.scale_pb_grid = scale_pb_grid
@@ -89,8 +90,10 @@ class Calculator(object):
     # ------------------------------------------------------------------------------------------
     def _solver(self, B, pb_mode, dx, nx, dt):
         tp = self.tp
+        # the method-of-lines calculators only use the handle for its RHS kernel; 'FTCS' carries the rate table
         s = PnpSolver(nspecies=tp.nspecies, nx=nx, dx=dx, dt=dt, beta=tp.beta, eps=tp.eps, D=tp.D, charges=tp.charges,
-                      method=self.calc, pb_mode=pb_mode, lax_friedrich=self.use_lax_friedrich,
+                      method=self.calc if self.calc in GPU_CALCS else 'FTCS', pb_mode=pb_mode,
+                      lax_friedrich=self.use_lax_friedrich,
                       use_migration=tp.use_migration, batch_capacity=B, device=self.device)
         if getattr(tp, 'use_reactions', False) and getattr(tp, 'reactions', None):
             names = list(tp.species.keys())
@@ -102,7 +105,7 @@ class Calculator(object):
                 table.append(([names.index(x) for x in rx['reactants'][0] if x in names],
                               [names.index(x) for x in rx['reactants'][1] if x in names],
                               float(rx['rates'][0]), float(rx['rates'][1])))
-            if self.calc == 'FTCS':
+            if self.calc != 'Crank-Nicolson':
                 s.set_reactions(table)
         elif self.calc == 'FTCS' and getattr(tp, 'reactions', None):
             # the reference's FTCS always calls get_rates (calculator_old.py:998)
@@ -143,6 +146,8 @@ class Calculator(object):
         tp = self.tp
         if method != self.calc:
             raise CalculatorError('integrate_pnp: method %r differs from the calculator %r' % (method, self.calc))
+        if self.calc in MOL_CALCS:
+            return self._integrate_mol(dx, nx, dt, nt)
         cout, status, (v, g, l) = self.integrate_pnp_batch(
             tp.c0[None, :], tp.pb_array()[None, :], [tp.system['vzeta']], tp.flux_bound[None, :, 0],
             dx=dx, nx=nx, dt=dt, nt=nt, itout=tp.itout)
@@ -151,6 +156,33 @@ class Calculator(object):
         tp.total_charge = -l[0] * tp.eps
         self.status = int(status[0])
         return [cout[i, 0].copy() for i in range(cout.shape[0])]
+
+    def _integrate_mol(self, dx, nx, dt, nt):
+        """integrate_odeint (calculator_old.py:821-973): scipy's integrators driving the method-of-lines RHS,
+        with the RHS (ode_func :827-935) evaluated by the HIP kernel.  Output indexing follows the reference:
+        odeint/lsoda return the state at tmesh[n]; the `ode` family appends r.integrate(r.t+dt), so entry n
+        is the state at (n+1)*dt (:959-963)."""
+        import scipy.integrate as integrate
+        tp = self.tp
+        pb = tp.pb_array()[None, :]
+        with self._solver(1, pb_mode_from_bound(pb[0]), dx, nx, dt) as s:
+            s.set_batch(tp.c0[None, :], pb, [tp.system['vzeta']], tp.flux_bound[None, :, 0])
+
+            def f_ty(t, c):
+                return s.mol_rhs(c[None, :])[0]
+
+            if self.calc in ('lsoda', 'odeint'):     # :946-948
+                sol = integrate.odeint(lambda c, t: f_ty(t, c), tp.c0, tp.tmesh, ml=tp.nspecies, mu=tp.nspecies)
+            else:                                    # :955-963 (the reference's nsteps=10000 branch)
+                r = integrate.ode(f_ty).set_integrator(self.calc, nsteps=10000)
+                r.set_initial_value(tp.c0)
+                sol = []
+                while r.successful() and r.t < nt * dt:
+                    sol.append(r.integrate(r.t + dt))
+                sol = np.array(sol)
+            c, v, g, l = s.get_state()
+        self.status = 0
+        return [np.array(sol[n, :]) for n in range(0, nt) if n in tp.itout and n < len(sol)]
 
     # ------------------------------------------------------------------------------------------
     def run(self):

@@ -26,6 +26,7 @@ struct pnp_handle {
   // device buffers (capacity-sized)
   double *c = nullptr, *lapl[2] = {nullptr, nullptr}, *v = nullptr, *gradv = nullptr, *rates = nullptr;
   double *pb = nullptr, *vzeta = nullptr, *flux = nullptr, *cbulk = nullptr, *csurf = nullptr;
+  double *ytmp = nullptr, *ftmp = nullptr;   // method-of-lines scratch: state in, derivative out
   SpecConst* spec = nullptr;
   int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
   int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
@@ -71,7 +72,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp})
     if (p) hipFree(p);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -391,6 +392,31 @@ static int ensure_potential_buffers(pnp_handle* h) {
     HIP_TRY(h, dev_alloc(h, &h->v, (size_t)h->cfg.batch_capacity * h->a.ldx));
     HIP_TRY(h, dev_alloc(h, &h->gradv, (size_t)h->cfg.batch_capacity * h->a.ldx));
   }
+  return PNP_OK;
+}
+
+int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
+  if (!h || !c || !dcdt) return fail(h, PNP_EINVAL, "pnp_mol_rhs: null argument");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_mol_rhs: call pnp_set_batch first");
+  hipSetDevice(h->cfg.device);
+  const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
+  const int64_t B = h->B;
+  const size_t cnt = (size_t)h->cfg.batch_capacity * N * ldx;
+  if (!h->ytmp) {
+    HIP_TRY(h, dev_alloc(h, &h->ytmp, cnt));
+    HIP_TRY(h, dev_alloc(h, &h->ftmp, cnt));
+    HIP_TRY(h, hipMemsetAsync(h->ytmp, 0, cnt * sizeof(double), h->stream));
+  }
+  const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
+  HIP_TRY(h, hipMemcpy2DAsync(h->ytmp, dp, c, w, w, (size_t)B * N, hipMemcpyHostToDevice, h->stream));
+  DevArgs a = h->a;
+  if (a.has_rates) {
+    a.c = h->ytmp;   // get_rates(C) of the state being differentiated (calculator_old.py:872-873)
+    HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
+  }
+  HIP_TRY(h, launch_mol_rhs(a, h->ytmp, h->ftmp, h->stream));
+  HIP_TRY(h, hipMemcpy2DAsync(dcdt, w, h->ftmp, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return PNP_OK;
 }
 

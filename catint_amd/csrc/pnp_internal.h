@@ -86,6 +86,8 @@ hipError_t launch_charge_row(const DevArgs& a, double* lapl, hipStream_t stream)
 hipError_t launch_poisson(const DevArgs& a, const double* lapl, double* v, double* gradv, hipStream_t stream);
 // rates[b][k][i] (get_rates, calculator_old.py:159-208)
 hipError_t launch_rates(const DevArgs& a, const ReactionTable& rt, double* rates, hipStream_t stream);
+// method-of-lines RHS (ode_func, calculator_old.py:827-935): dydt[b][k][i] from y[b][k][i]
+hipError_t launch_mol_rhs(const DevArgs& a, const double* y, double* dydt, hipStream_t stream);
 // surface gather: csurf[B][N] = c[b][k][0]
 hipError_t launch_surface(const DevArgs& a, double* csurf, hipStream_t stream);
 

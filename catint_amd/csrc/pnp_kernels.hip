@@ -1144,6 +1144,99 @@ __global__ __launch_bounds__(64) void poisson_kernel(const DevArgs A, const doub
   store_row<P>(gradv + b * (int64_t)ldx, GV, ldx, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Method-of-lines right-hand side, ode_func (calculator_old.py:827-935): dydt[b][k][i] for a batch of
+// states y[b][k][i].  One wave per operating point, rows staged through LDS like step_kernel; every
+// Poisson boundary combination is supported.  LDS = 3 padded rows (LV | GV | ROW).
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(64) void mol_rhs_kernel(const DevArgs A, const double* __restrict__ y,
+                                                      double* __restrict__ dydt) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int RB = rowbuf_doubles<P>();
+  constexpr int IT = RowRegs<P>::IT;
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int nx = A.nx, m = A.m, ldx = A.ldx, N = A.N;
+  double* LV = lds;
+  double* GV = lds + RB;
+  double* ROW = lds + 2 * RB;
+  const int r0 = lane * P;
+  const double dx = A.dx, dt = A.dt;
+  const double* yrow0 = y + b * (int64_t)N * ldx;
+  double* orow0 = dydt + b * (int64_t)N * ldx;
+  for (int i = lane; i < 3 * RB; i += 64) lds[i] = 0.0;
+  lds_sync();
+  const int ls = pidx<P>(2 * lane);
+  if (A.use_mig) {
+    // charge row of the state (:767-771), accumulated in species order at the coalesced positions
+    d2 acc[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) acc[it] = (d2)(0.0);
+    for (int k = 0; k < N; ++k) {
+      RowRegs<P> rr;
+      load_row_issue<P>(row_rsrc(yrow0 + (int64_t)k * ldx, ldx), rr, lane);
+      const double qe = A.spec[k].qe;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        acc[it].x = __builtin_fma(-rr.t[it].x, qe, acc[it].x);
+        acc[it].y = __builtin_fma(-rr.t[it].y, qe, acc[it].y);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      if (2 * lane + 128 * it < ldx) {
+        LV[pair_slot<P>(ls, it)] = acc[it].x;
+        LV[pair_slot<P>(ls, it) + PAIR_STEP<P>] = acc[it].y;
+      }
+    }
+    lds_sync();
+    poisson_wave<P, false, 1>(A, LV, GV, nullptr, ROW, A.pb[b * 4 + 0], A.pb[b * 4 + 1], A.pb[b * 4 + 2], A.pb[b * 4 + 3], lane);
+  }
+  double gq[P + 2];   // grad_v at grid r0 .. r0+P+1 (slot = index+1)
+#pragma unroll
+  for (int t = 0; t < P + 2; ++t) gq[t] = A.use_mig ? GV[pidx<P>(r0 + t + 1)] : 0.0;
+  const double g1 = A.use_mig ? GV[pidx<P>(1 + 1)] : 0.0;   // grad_v[1]
+  lds_sync();
+  for (int k = 0; k < N; ++k) {
+    load_row<P>(yrow0 + (int64_t)k * ldx, ROW, ldx, lane);
+    lds_sync();
+    double cc[P + 2];
+#pragma unroll
+    for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
+    const double c0 = ROW[pidx<P>(0)], c1 = ROW[pidx<P>(1)], c2 = ROW[pidx<P>(2)];
+    lds_sync();
+    const SpecConst& S = A.spec[k];
+    const double flux = A.flux[b * N + k];
+    const double bq = A.beta * S.q;
+    double out[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {   // grid i = r0+j+1, :916-927
+      const double d2c = (cc[j + 2] - 2 * cc[j + 1] + cc[j]) / (dx * dx);
+      const double dcg = (cc[j + 2] * gq[j + 2] - cc[j] * gq[j]) / (2. * dx);
+      const double corr = A.lf ? d2c * (dx * dx) / dt / 2. : 0.0;
+      double v = corr + S.D * (d2c + bq * dcg);
+      if (A.has_rates) v += A.rates[(b * N + k) * (int64_t)ldx + min(r0 + j + 1, nx - 1)];
+      out[j] = v;
+    }
+    // wall cell :897-915 (no rate term), bulk point :886
+    const double corr0 = A.lf ? (c1 - c0) / dt : 0.0;
+    const double w0 = corr0 + (S.D * ((c2 - c0) / (2. * dx) + bq * c1 * g1) - flux) / dx;
+#pragma unroll
+    for (int j = 0; j < P; ++j) ROW[pidx<P>(r0 + j + 1)] = out[j];
+    lds_sync();
+    if (lane == 0) {
+      ROW[pidx<P>(0)] = w0;
+      ROW[pidx<P>(nx - 1)] = 0.0;
+    }
+    if (lane < ldx - nx) ROW[pidx<P>(nx + lane)] = 0.0;
+    lds_sync();
+    store_row<P>(orow0 + (int64_t)k * ldx, ROW, ldx, lane);
+    lds_sync();
+  }
+  (void)m;
+}
+
 // lapl[b][i] = -sum_k q_k c[b][k][i]/eps  (:767-771), thread per grid point
 __global__ void charge_row_kernel(const DevArgs A, double* __restrict__ lapl) {
   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1312,6 +1405,20 @@ hipError_t launch_poisson(const DevArgs& a, const double* lapl, double* v, doubl
     case 4: hipLaunchKernelGGL(poisson_kernel<4>, grid, block, lds_bytes_for<4>(2), stream, a, lapl, v, gradv); break;
     case 8: hipLaunchKernelGGL(poisson_kernel<8>, grid, block, lds_bytes_for<8>(2), stream, a, lapl, v, gradv); break;
     case 16: hipLaunchKernelGGL(poisson_kernel<16>, grid, block, lds_bytes_for<16>(2), stream, a, lapl, v, gradv); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_mol_rhs(const DevArgs& a, const double* y, double* dydt, hipStream_t stream) {
+  const int P = points_per_lane(a.nx);
+  const dim3 grid((unsigned)a.B), block(64);
+  switch (P) {
+    case 1: hipLaunchKernelGGL(mol_rhs_kernel<1>, grid, block, lds_bytes_for<1>(1), stream, a, y, dydt); break;
+    case 2: hipLaunchKernelGGL(mol_rhs_kernel<2>, grid, block, lds_bytes_for<2>(1), stream, a, y, dydt); break;
+    case 4: hipLaunchKernelGGL(mol_rhs_kernel<4>, grid, block, lds_bytes_for<4>(1), stream, a, y, dydt); break;
+    case 8: hipLaunchKernelGGL(mol_rhs_kernel<8>, grid, block, lds_bytes_for<8>(1), stream, a, y, dydt); break;
+    case 16: hipLaunchKernelGGL(mol_rhs_kernel<16>, grid, block, lds_bytes_for<16>(1), stream, a, y, dydt); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

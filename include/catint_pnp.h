@@ -121,6 +121,12 @@ int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch);
 int pnp_integrate(pnp_handle* h, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
                   int32_t* status);
 
+/* Method-of-lines right-hand side, ode_func (calculator_old.py:827-935), for the B lanes of the current batch
+ * (their pb / flux / species / reactions): dcdt[B][N][nx] = f(c[B][N][nx]).  The reference hands this function
+ * to scipy.integrate.odeint / ode ('odeint','lsoda','dopri5','dop853', calculator_old.py:946-963); the host side
+ * (catint_amd/calculator.py) does the same with this entry point.  The state on the device is not touched. */
+int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt);
+
 /* ---- read-back ------------------------------------------------------------------------------ */
 /* Any pointer may be NULL. c[B][N][nx]; v, grad_v, lapl_v [B][nx] are the Poisson solve of the
  * most recent step = tp.potential, -tp.efield, -tp.total_charge/eps (calculator_old.py:816-818). */

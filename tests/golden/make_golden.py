@@ -176,6 +176,8 @@ CASES = [
     # --- method of lines (App. F.2): trajectory + RHS samples -------------------------------
     dict(name='odeint_dd_n2_nx50', method='odeint', species=None, phiM=-0.025, L=5e-8, nx=50,
          pb_bound=DD, dt=1e-10, tmax=1e-9, ntout=2, capture_rhs=True),
+    dict(name='dopri5_dd_n2_nx50', method='dopri5', species=None, phiM=-0.025, L=5e-8, nx=50,
+         pb_bound=DD, dt=1e-11, tmax=1e-10, ntout=2),
     dict(name='odeint_dd_n3_nx40_flux_LF', method='odeint--LF', species=K_CL_HCO3, phiM=0.02, L=2e-8, nx=40,
          pb_bound=DD, dt=2e-11, tmax=2e-10, ntout=2, flux_bound=[[0, 1e-3]], capture_rhs=True,
          c0_perturb={'seed': 19, 'amp': 0.05}),

@@ -116,3 +116,30 @@ def test_scf_cycle_on_gpu_converges_and_is_lane_consistent():
     out1 = calc1.run_scf_cycle(lambda st: flux_cb({'phiM': np.array(phis), 'surface_concentration':
                                                     np.repeat(st['surface_concentration'], 4, axis=0)})[2:3], max_iter=200)
     assert np.allclose(out1['surface_concentration'][0], out['surface_concentration'][2], rtol=1e-10)
+
+
+@pytest.mark.parametrize('name', ['odeint_dd_n2_nx50', 'odeint_dd_n3_nx40_flux_LF', 'dopri5_dd_n2_nx50'])
+def test_method_of_lines_rhs_and_trajectories(name):
+    """ode_func (calculator_old.py:827-935) on the GPU: the RHS against the reference's own RHS samples
+    (rtol 1e-11 of the max-norm; the device sums in a different order), and the scipy-driven trajectories
+    against the reference trajectories to the integrators' own tolerances (odeint rtol 1.5e-8, dopri5 1e-6)."""
+    from catint_amd.host import solver_from_problem
+    d = np.load(os.path.join(GOLDEN, name + '.npz'))
+    p, c0, nt, itout, method = R.problem_from_golden(d)
+    if 'rhs_states' in d:
+        with solver_from_problem(p, 'FTCS', batch_capacity=3) as s:
+            s.set_batch(d['rhs_states'], np.stack([p.pb] * 3), [p.vzeta] * 3, np.stack([p.flux_bound] * 3))
+            f = s.mol_rhs(d['rhs_states'])
+        for a, b in zip(f, d['rhs_values']):
+            assert relerr(a, b) < 1e-11
+    tp = transport_from_fixture(d)
+    tp.c0 = d['c0'].copy()
+    tp.flux_bound = d['flux_bound'].copy()
+    tp.system['vzeta'] = float(d['vzeta'])
+    ntout = next(n for n in range(1, 8) if make_itout(int(d['nt']), n) == [int(i) for i in d['itout']])
+    calc = Calculator(transport=tp, calc=str(d['method']), dt=float(d['dt']), tmax=float(d['tmax']), ntout=ntout)
+    cout = calc.integrate_pnp(tp.dx, tp.nx, tp.dt, tp.nt, tp.ntout, calc.calc)
+    assert len(cout) == len(d['cout'])
+    tol = 1e-5 if 'dopri5' in name else 1e-6
+    for a, b in zip(cout, d['cout']):
+        assert relerr(a, b) < tol
