@@ -3,10 +3,14 @@
 "batched 1D PNP Newton-timesteps/sec at 1/2/4/8 GPU; achieved HBM GB/s vs peak").
 
 One "step" = one pass of the integrator's time-loop body (reference catint/calculator_old.py:512-558)
-over one batch of B operating points = ONE kernel launch that reads the full state (N concentration
-rows + the charge row) from HBM and writes it back (`steps_per_launch = 1`, i.e. "state written
-every step").  Workload at N=1: BASELINE.json configs[1] -- batch=1024
-operating points, 3 species, 512 grid points, fp64.  Multi-GPU: the batch shards embarrassingly
+over one batch of B operating points.  Headline ("state written every step
+(ntout = nt)", algorithmic bytes 16*(N+1)*nx per lane-step): the reference's time loop runs inside the
+kernel, `--steps-per-launch` timesteps per launch (default 64, what pnp_integrate uses); every step's new
+state is written to HBM, the previous state is re-used from registers/LDS instead of being re-read, so the
+MEASURED HBM traffic (roofline.traffic, rocprofv3) is about half the algorithmic figure.  The
+one-launch-per-timestep variant (state read from and written to HBM by every launch) is reported next to
+it as `per_step_launch`.  Workload at N=1: BASELINE.json configs[1] -- batch=1024 operating points,
+3 species, 512 grid points, fp64.  Multi-GPU: the batch shards embarrassingly
 (weak scaling: every rank owns `--batch` lanes), no collective in the timed region; one RCCL
 all_gather of the polarization observables afterwards.
 
@@ -29,14 +33,14 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=256)
+    ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--batch', type=int, default=1024, help='operating points per GPU')
     ap.add_argument('--nspecies', type=int, default=3)
     ap.add_argument('--nx', type=int, default=512)
     ap.add_argument('--method', default='Crank-Nicolson')
-    ap.add_argument('--steps-per-launch', type=int, default=1,
-                    help='1 = headline (state through HBM every step); >1 = fused steps, reported as extra')
+    ap.add_argument('--steps-per-launch', type=int, default=64,
+                    help='timesteps fused into one launch (state written to HBM every step); 1 = one launch per step')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline sample length')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true')
@@ -141,13 +145,15 @@ def main():
     steps_total = world * B * args.steps
     value = steps_total / wall
 
-    # fused-launch variant (state stays in L2/LDS between steps of one launch) -- extra, not the headline
+    # one launch per timestep (state read from and written to HBM by every launch) -- reported next to the headline
     fused = None
-    if not args.no_fused and args.steps_per_launch == 1:
+    if not args.no_fused and args.steps_per_launch != 1:
         solver.set_batch(c0, pb, vz, fl)
-        fw, fe = timed(args.steps, 0)
+        fw, fe = timed(args.steps, 1)
+        lsec = fe * 1e-3 / args.steps
         fused = {'timesteps_per_s': world * B * args.steps / fw, 'ms_per_step': fw / args.steps * 1e3,
-                 'steps_per_launch': 64}
+                 'steps_per_launch': 1, 'launch_us': lsec * 1e6,
+                 'frac': 16.0 * (N + 1) * nx * B / lsec / 1e9 / HBM_PEAK_GBS}
 
     # the only exchange of the path: gather the polarization observables (RCCL all_gather over xGMI)
     cs, vs, es = solver.get_surface()
@@ -165,7 +171,7 @@ def main():
 
     # oversubscribed regime (not the headline): same lanes-shape, many more of them than SIMDs
     large = None
-    if world == 1 and args.large_batch > 0 and args.steps_per_launch == 1:
+    if world == 1 and args.large_batch > 0:
         LB = args.large_batch
         lp, lc0, lpb, lvz, lfl = make_batch(LB, N, nx, seed=77, phi_max=0.025, dt_factor=1e-4)
         s2 = solver_from_problem(lp, args.method, batch_capacity=LB, device=local_rank)
@@ -185,7 +191,8 @@ def main():
                  'frac': 16.0 * (N + 1) * nx * LB / lsec / 1e9 / HBM_PEAK_GBS, 'lanes_ok': lok}
 
     if rank == 0:
-        alg_bytes_per_launch = 16.0 * (N + 1) * nx * B * args.steps_per_launch   # 2*8*(N+1)*nx per point-step
+        # 2*8*(N+1)*nx bytes per lane-timestep; a launch advances B lanes by steps_per_launch steps
+        alg_bytes_per_launch = 16.0 * (N + 1) * nx * B * args.steps / n_launch
         launch_s = ev_ms * 1e-3 / n_launch
         achieved = alg_bytes_per_launch / launch_s / 1e9
         out = {
@@ -199,7 +206,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'kernel': 'pnp::step_kernel (P=%d points/lane)' % next(P for P in (1, 2, 4, 8, 16) if nx - 2 <= 64 * P),
-                         'launch_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg_bytes_per_launch},
+                         'launch_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg_bytes_per_launch,
+                         'timesteps_per_launch': args.steps / n_launch},
             'lanes_ok': int((status == 0).sum()), 'lanes_total': int(B),
         }
         # measured HBM bytes per launch come from a separate rocprofv3 --pmc pass of this same command
@@ -213,7 +221,7 @@ def main():
         except Exception:
             pass
         if fused:
-            out['fused'] = fused
+            out['per_step_launch'] = fused
         if large:
             out['large_batch'] = large
         if gather_ms is not None:

@@ -30,7 +30,7 @@ struct pnp_handle {
   SpecConst* spec = nullptr;
   int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
   int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
-  int kernel_override = 0;   // CATINT_PNP_KERNEL = 2 (LDS-staged) | 3 (register-resident)
+  int kernel_override = 0;   // CATINT_PNP_KERNEL = 2 (LDS-staged) | 3 (register-resident) | 4 (register-resident, W waves)
   int32_t* status = nullptr;
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
   int64_t dev_bytes = 0;
@@ -311,6 +311,11 @@ static int run_steps(pnp_handle* h, int nsteps) {
   bool use3 = step3_applicable(a) && a.B >= 2048;
   if (h->kernel_override == 2) use3 = false;
   if (h->kernel_override == 3) use3 = step3_applicable(a);
+  if (h->kernel_override == 4 && step3_applicable(a)) {
+    int w4 = a.N < 4 ? a.N : 4;
+    if (h->waves_override >= 1 && h->waves_override <= 4) w4 = h->waves_override;
+    HIP_TRY(h, launch_step4(a, w4, h->stream));
+  } else
   if (use3) {
     int g3 = 1;
     if (h->species_override >= 1 && h->species_override <= 3) g3 = h->species_override;

@@ -14,5 +14,5 @@ timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/$tag.json 2> gp
 python - "$tag" <<'PY'
 import json,sys
 d=json.load(open('gpurun_out/%s.json'%sys.argv[1]))
-print('value %.4g steps/s  launch_us %.2f  frac %.3f  fused %.4g steps/s (%.2f us/step)  lanes_ok %d' % (d['value'], d['roofline']['launch_us'], d['roofline']['frac'], d['fused']['timesteps_per_s'], d['fused']['ms_per_step']*1e3, d['lanes_ok']))
+print('value %.4g steps/s  launch_us %.2f  frac %.3f  per-step-launch %.4g steps/s (%.2f us/step)  lanes_ok %d' % (d['value'], d['roofline']['launch_us'], d['roofline']['frac'], d['per_step_launch']['timesteps_per_s'], d['per_step_launch']['ms_per_step']*1e3, d['lanes_ok']))
 PY

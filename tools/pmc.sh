@@ -7,7 +7,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" \
            "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_$tag/g$i -- python3 $R/bench.py --no-cpu-baseline --no-fused --steps 20 --warmup 2 "$@" > $R/gpurun_out/pmc_$tag/g$i.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_$tag/g$i -- python3 $R/bench.py --no-cpu-baseline --no-fused --large-batch 0 --steps 64 --warmup 64 "$@" > $R/gpurun_out/pmc_$tag/g$i.log 2>&1
 done
 python3 - $R/gpurun_out/pmc_$tag <<'PY'
 import csv,collections,glob,sys
