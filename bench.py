@@ -100,19 +100,26 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback for the transport path)')
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    device = local_rank % max(ndev, 1)          # one rank per GPU on a full node; ranks share GPUs only in rehearsals
+    backend = os.environ.get('CATINT_DIST_BACKEND', 'nccl')   # nccl = RCCL over xGMI; gloo for single-GPU rehearsals
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(device)
+    comm_dev = torch.device('cuda', device) if backend == 'nccl' else torch.device('cpu')
 
     from catint_amd.synthetic import make_batch
     from catint_amd.host import solver_from_problem
     B, N, nx = args.batch, args.nspecies, args.nx
     prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=1000 + rank, phi_max=0.025, dt_factor=1e-4)
-    solver = solver_from_problem(prob, args.method, batch_capacity=B, device=local_rank)
+    solver = solver_from_problem(prob, args.method, batch_capacity=B, device=device)
     solver.set_batch(c0, pb, vz, fl)
 
     def barrier():
@@ -131,7 +138,7 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([wall, ev_ms], device='cuda', dtype=torch.float64)
+            t = torch.tensor([wall, ev_ms], device=comm_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, ev_ms = float(t[0]), float(t[1])
         return wall, ev_ms
@@ -163,7 +170,7 @@ def main():
         obs = np.concatenate([cs, vs[:, None], es[:, None]], axis=1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        curve = gather_observables(obs, world * B, dist, device=torch.device('cuda', local_rank))
+        curve = gather_observables(obs, world * B, dist, device=comm_dev)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t0) * 1e3
         assert curve.shape == (world * B, N + 2)
@@ -174,7 +181,7 @@ def main():
     if world == 1 and args.large_batch > 0:
         LB = args.large_batch
         lp, lc0, lpb, lvz, lfl = make_batch(LB, N, nx, seed=77, phi_max=0.025, dt_factor=1e-4)
-        s2 = solver_from_problem(lp, args.method, batch_capacity=LB, device=local_rank)
+        s2 = solver_from_problem(lp, args.method, batch_capacity=LB, device=device)
         s2.set_batch(lc0, lpb, lvz, lfl)
         s2.step(5, 1)
         s2.set_batch(lc0, lpb, lvz, lfl)

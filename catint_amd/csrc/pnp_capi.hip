@@ -308,7 +308,7 @@ static int run_steps(pnp_handle* h, int nsteps) {
   // Measured on MI355X: with fewer lanes than SIMDs x 2 the LDS-staged kernel with three
   // interleaved species per wave has the shortest critical path; once the batch oversubscribes the chip the
   // register-resident kernel (one species at a time, 3 waves/SIMD) wins because the LDS pipe stops being shared.
-  bool use3 = step3_applicable(a) && a.B >= 2048;
+  bool use3 = step3_applicable(a) && a.B >= 2048 && h->P <= 8;   // P = 16: the LDS-staged kernel keeps 2x the occupancy
   if (h->kernel_override == 2) use3 = false;
   if (h->kernel_override == 3) use3 = step3_applicable(a);
   if (h->kernel_override == 4 && step3_applicable(a)) {
