@@ -199,7 +199,7 @@ class Calculator(object):
             system = dict(tp.system)
             system[keys[0]] = v1
             system[keys[1]] = v2
-            if 'phiM' in keys and 'vzeta' not in (keys[0], keys[1]):
+            if 'phiM' in keys and 'vzeta' not in (keys[0], keys[1]) and getattr(tp, 'vzeta_follows_phiM', True):
                 system['vzeta'] = system['phiM']
             pb[i] = tp.pb_array(system)
             vz[i] = system['vzeta']
@@ -230,7 +230,7 @@ class Calculator(object):
             system = dict(tp.system)
             system[keys[0]] = v1
             system[keys[1]] = v2
-            if 'phiM' in keys:
+            if 'phiM' in keys and getattr(tp, 'vzeta_follows_phiM', True):
                 system['vzeta'] = system['phiM']
             pb[i] = tp.pb_array(system)
             vz[i] = system['vzeta']
@@ -262,6 +262,7 @@ class Calculator(object):
         acc = np.full(B, np.inf)
         step_to_check = np.zeros(B, int)
         active = np.ones(B, bool)
+        failed = np.zeros(B, bool)      # NaN in the transport solve: the reference's nan_in_surface() (calculator.py:409-414)
         surface_pH = np.full(B, float(tp.system.get('bulk_pH', 7.0)))
         vsurf = phiM.copy(); esurf = np.zeros(B)
         sc_old = sc.copy(); cd_old = None
@@ -314,7 +315,9 @@ class Calculator(object):
                     acc = np.where(active, err.max(axis=1), acc)
                 cd_old = cd if cd_old is None else np.where(active[:, None], cd, cd_old)
                 history.append(acc.copy())
-                active = active & ((acc > self.tau_scf) | (sc < 0.0).any(axis=1))
+                bad = active & (~np.isfinite(cs).all(axis=1) | (status == 2))
+                failed |= bad
+                active = active & ~bad & ((acc > self.tau_scf) | (sc < 0.0).any(axis=1))
         finally:
             if solver is not None:
                 solver.close()
@@ -329,7 +332,8 @@ class Calculator(object):
             d['system'].update({'surface_pH': float(surface_pH[i]), 'surface_potential': float(vsurf[i]),
                                 'surface_efield': float(esurf[i]), 'phiM': float(phiM[i])})
         return {'surface_concentration': sc, 'flux': flux, 'current_density': flux * nel * unit_F / nprod / 10.,
-                'surface_pH': surface_pH, 'accuracy': acc, 'converged': ~active, 'iterations': istep, 'mix': mix,
+                'surface_pH': surface_pH, 'accuracy': acc, 'converged': ~active & ~failed, 'failed': failed,
+                'iterations': istep, 'mix': mix,
                 'history': np.array(history)}
 
     # ------------------------------------------------------------------------------------------

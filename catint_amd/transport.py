@@ -124,7 +124,10 @@ class Transport(object):
                 self.pb_bound[key1][key2] = self.system['phiM'] if isinstance(v, str) and v == 'phiM' else v
         self._pb_symbolic = {k1: {k2: pb_bound.get(k1, {}).get(k2, None) for k2 in ('wall', 'bulk')}
                              for k1 in ('potential', 'gradient')}
-        self.system.setdefault('vzeta', self.system['phiM'])   # read by the legacy integrators (calculator_old.py:529)
+        # vzeta is read by the legacy integrators' wall condition (calculator_old.py:529, :1003) but is not a key of
+        # today's Transport: unless the caller sets it, it follows phiM (also per lane in a phiM sweep)
+        self.vzeta_follows_phiM = 'vzeta' not in self.system
+        self.system.setdefault('vzeta', self.system['phiM'])
         self.reactions = {}
         self.use_reactions = False
         self.calc = None

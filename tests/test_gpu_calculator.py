@@ -143,3 +143,19 @@ def test_method_of_lines_rhs_and_trajectories(name):
     tol = 1e-5 if 'dopri5' in name else 1e-6
     for a, b in zip(cout, d['cout']):
         assert relerr(a, b) < tol
+
+
+def test_co2r_polarization_example_runs_and_saturates():
+    """examples/co2r_polarization_sweep.py (BASELINE configs[2] shape, reduced): the Tafel current grows with
+    overpotential while CO2 depletes at the wall; every lane converges."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'co2r', os.path.join(os.path.dirname(GOLDEN), '..', 'examples', 'co2r_polarization_sweep.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(['--lanes', '24', '--tmax', '0.02', '--dt', '5e-6', '--mix-scf', '0.3', '--tau-scf', '1e-3'])
+    assert out['converged'].all()
+    j = out['current_density'][:, 3]
+    assert (j > 0).all() and (np.diff(j) >= -1e-12).all()           # more negative phiM -> larger CO current
+    assert out['surface_concentration'][-1, 1] < out['surface_concentration'][0, 1]   # CO2 depletes at the wall
+    assert (out['surface_concentration'][:, 2] > 6.31e-05).all()     # OH- is produced at the wall
