@@ -30,7 +30,7 @@ struct pnp_handle {
   SpecConst* spec = nullptr;
   int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
   int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
-  int kernel_override = 0;   // CATINT_PNP_KERNEL = 2 (LDS-staged) | 3 (register-resident) | 4 (register-resident, W waves)
+  int kernel_override = 0;   // CATINT_PNP_KERNEL = 2 (LDS-staged step_kernel) | 4 (register-resident step_kernel_rr)
   int32_t* status = nullptr;
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
   int64_t dev_bytes = 0;
@@ -303,24 +303,20 @@ static int run_steps(pnp_handle* h, int nsteps) {
     if (nsteps != 1) return fail(h, PNP_EINVAL, "internal: rate terms need one step per launch");
     HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
   }
-  int W = 1, G = 1;
-  choose_step_config(a.N, a.B, h->P, &W, &G);
-  // Measured on MI355X: with fewer lanes than SIMDs x 2 the LDS-staged kernel with three
-  // interleaved species per wave has the shortest critical path; once the batch oversubscribes the chip the
-  // register-resident kernel (one species at a time, 3 waves/SIMD) wins because the LDS pipe stops being shared.
-  bool use3 = step3_applicable(a) && a.B >= 2048 && h->P <= 8;   // P = 16: the LDS-staged kernel keeps 2x the occupancy
-  if (h->kernel_override == 2) use3 = false;
-  if (h->kernel_override == 3) use3 = step3_applicable(a);
-  if (h->kernel_override == 4 && step3_applicable(a)) {
-    int w4 = a.N < 4 ? a.N : 4;
-    if (h->waves_override >= 1 && h->waves_override <= 4) w4 = h->waves_override;
-    HIP_TRY(h, launch_step4(a, w4, h->stream));
-  } else
-  if (use3) {
-    int g3 = 1;
-    if (h->species_override >= 1 && h->species_override <= 3) g3 = h->species_override;
-    HIP_TRY(h, launch_step3(a, g3, h->stream));
+  // Measured on MI355X: while the batch has fewer lanes than ~2 per SIMD the LDS-staged
+  // kernel with three interleaved species per wave has the shortest critical path; once the batch
+  // oversubscribes the chip the register-resident kernel (one wave per lane, 3 waves/SIMD) wins because the
+  // LDS pipe stops being the shared bottleneck.  P = 16 keeps the LDS-staged kernel (twice the occupancy).
+  bool rr = step_rr_applicable(a) && a.B >= 2048 && h->P <= 8;
+  if (h->kernel_override == 2) rr = false;
+  if (h->kernel_override == 4) rr = step_rr_applicable(a);
+  if (rr) {
+    int w = 1;
+    if (h->waves_override >= 1 && h->waves_override <= 4) w = h->waves_override;
+    HIP_TRY(h, launch_step_rr(a, w, h->stream));
   } else {
+    int W = 1, G = 1;
+    choose_step_config(a.N, a.B, h->P, &W, &G);
     if (h->waves_override >= 1 || h->species_override >= 1) {
       const int w2 = h->waves_override >= 1 ? h->waves_override : W;
       const int g2 = h->species_override >= 1 ? h->species_override : 1;

@@ -77,11 +77,10 @@ size_t step_lds_bytes(int P, int W, int G);
 
 // launchers (all asynchronous on `stream`)
 hipError_t launch_step(const DevArgs& a, int W, int G, hipStream_t stream);
-// register-resident variant (step_kernel3): one wave per operating point, G species interleaved
-bool step3_applicable(const DevArgs& a);
-hipError_t launch_step3(const DevArgs& a, int G, hipStream_t stream);
-// register-resident variant with W species-parallel waves per operating point (step_kernel4)
-hipError_t launch_step4(const DevArgs& a, int W, hipStream_t stream);
+// register-resident kernel (step_kernel_rr): W species-parallel waves per operating point;
+// applicable to the Dirichlet/Dirichlet Poisson branch with an even number of points per lane
+bool step_rr_applicable(const DevArgs& a);
+hipError_t launch_step_rr(const DevArgs& a, int W, hipStream_t stream);
 // lapl[b][i] = -sum_k q_k c[b][k][i]/eps for all nx points (initial charge row, calculator_old.py:767-771)
 hipError_t launch_charge_row(const DevArgs& a, double* lapl, hipStream_t stream);
 // v, grad_v [B][ldx] from a lapl row (get_potential_and_gradient, calculator_old.py:773-803)

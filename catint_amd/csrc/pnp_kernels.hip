@@ -812,16 +812,15 @@ __global__ __launch_bounds__(64 * W, (step_min_waves<P, G>())) void step_kernel(
 }
 
 // ================================================================================================
-// step_kernel3<P,G>: register-resident variant for the Dirichlet/Dirichlet Poisson branch.
-//   * one wave per operating point; lane l loads its window of P+2 grid points (own P interior rows
-//     plus one halo point on either side) of every row straight into registers with 16-byte
-//     buffer loads (each lane reads a contiguous, 16-B aligned 8*(P+2)-byte piece; the P+2 pieces of a
-//     row tile it exactly, so HBM traffic stays algorithmic);
+// Register-resident kernel family (step_kernel_rr) for the Dirichlet/Dirichlet Poisson branch.
+//   * lane l loads its window of P+2 grid points (own P interior rows plus one halo point on either
+//     side) of a row straight into registers with 16-byte buffer loads (each lane reads a contiguous,
+//     16-B aligned piece; the windows tile the row, so HBM traffic stays algorithmic);
 //   * the Poisson prefix scan and every neighbour exchange use DPP (row_shr / row_bcast / wave_shr /
-//     wave_shl) -- no LDS round trips; LDS is used only for the 6-step cyclic-reduction strips;
-//   * G species are advanced together with their dependent chains interleaved (ILP instead of waves);
-//   * in fused launches with N <= G the state never leaves the registers between timesteps (the new
-//     rows are still written to HBM every step).
+//     wave_shl) -- no LDS round trips; LDS is used only for the 6-step cyclic-reduction strips and the
+//     once-per-step meeting of the waves of a workgroup;
+//   * in fused launches with one species per wave the state never leaves the registers between
+//     timesteps (the new rows are still written to HBM every step).
 // ================================================================================================
 template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ double dpp_f64(double old, double x) {
@@ -883,254 +882,22 @@ __device__ __forceinline__ void store_rows(__amdgpu_buffer_rsrc_t r, const doubl
   }
 }
 
-template <int P, int G>
-constexpr int step3_min_waves() {
-  return P == 2 ? 4 : (P == 4 ? (G == 1 ? 4 : 2) : (P == 8 ? (G == 1 ? 3 : 1) : 1));
-}
-
-template <int P, int G, bool CN>
-__global__ __launch_bounds__(64, (step3_min_waves<P, G>())) void step_kernel3(const DevArgs A) {
-  static_assert(P >= 2 && P % 2 == 0, "window loads need an even P");
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // G strips of 384 doubles
-  constexpr int XS = 384;
-  const int lane = threadIdx.x;
-  const int64_t b = blockIdx.x;
-  const int nx = A.nx, m = A.m, ldx = A.ldx, N = A.N;
-  const int r0 = lane * P;
-  const double dx = A.dx;
-  constexpr bool cn = CN;
-  double* lin = A.lapl_a + b * (int64_t)ldx;
-  double* lout = A.lapl_b + b * (int64_t)ldx;
-  double* crow0 = A.c + b * (int64_t)N * ldx;
-  const double vw = A.pb[b * 4 + 0], vb = A.pb[b * 4 + 1];
-  const double vz = A.vzeta[b];
-  const bool single_round = (N <= G);
-  double chk = 0.0, mn = 0.0;
-
-  double lw[P + 2];        // lagged charge row window: lapl_v[r0 + t]
-  double cc[G][P + 2];     // concentration windows of the species in flight: C[k][r0 + t]
-  for (int step = 0; step < A.nsteps; ++step) {
-    const bool resident = single_round && step > 0;
-    if (!resident) {
-      if (A.use_mig) load_window<P>(row_rsrc(lin, ldx), lw, lane);
-#pragma unroll
-      for (int g = 0; g < G; ++g) load_window<P>(row_rsrc(crow0 + (int64_t)min(g, N - 1) * ldx, ldx), cc[g], lane);
-    }
-    // ---- 1. lagged potential: v'' = lapl, v[0] = vw, v[nx-1] = vb  (calculator_old.py:716-730, :780-786) ----
-    double gx[P + 3];   // grad_v[r0 - 1 + t]
-    double v1 = 0.0;
-    if (A.use_mig) {
-      double Hi[P];
-      const double dx2 = dx * dx;
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        double h = lw[j + 1] * dx2;                       // grid r0+j+1; pads and out-of-range are 0
-        h = (r0 + j == m) ? 0.0 : h;                      // the bulk point is not part of the interior sum
-        Hi[j] = h;
-        s0 += h;
-        s1 = __builtin_fma((double)j, h, s1);
-      }
-      // G_{nx-1} = sum_r (m - r) h_r, this lane's share: (m - r0) * sum_j h_j - sum_j j*h_j
-      const double wsum = __builtin_fma((double)(m - r0), s0, -s1);
-      const double hm1 = pick_blocked<P>(Hi, r0, m - 1), hm2 = pick_blocked<P>(Hi, r0, m - 2);
-      const double h0 = read_lane(Hi[0], 0), h1 = read_lane(Hi[1], 0);
-#pragma unroll
-      for (int j = 1; j < P; ++j) Hi[j] += Hi[j - 1];
-      const double incT = wave_scan_incl(Hi[P - 1]);
-      const double incW = wave_scan_incl(wsum);
-      const double base = from_prev_lane(0.0, incT);
-      const double tot1 = read_lane(incT, 63), totG = read_lane(incW, 63);
-#pragma unroll
-      for (int j = 0; j < P; ++j) Hi[j] += base;          // Hi[j] = H_{grid r0+j+1}
-      const double w0 = (vb - vw - totG) / (double)(nx - 1);
-      v1 = vw + w0;
-      const double inv2dx = 1.0 / (2 * dx);
-      double gown[P];                                     // grad_v[r0+j+1] = (v[i+1]-v[i-1])/(2dx), :784
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        const double Hx = (j == 0) ? base : Hi[j > 0 ? j - 1 : 0];
-        gown[j] = inv2dx * ((w0 + Hi[j]) + (w0 + Hx));
-      }
-      // extrapolated ends :785-786 from the first / last two interior charges
-      const double g1 = inv2dx * ((w0 + h0) + (w0 + 0.0));
-      const double g2 = inv2dx * ((w0 + (h0 + h1)) + (w0 + h0));
-      const double g_first = g1 + (g1 - g2);
-      const double Hm1 = tot1 - hm1, Hm2 = Hm1 - hm2;     // H_{nx-3}, H_{nx-4}; H_{nx-2} = tot1
-      const double gm1 = inv2dx * ((w0 + tot1) + (w0 + Hm1));
-      const double gm2 = inv2dx * ((w0 + Hm1) + (w0 + Hm2));
-      const double g_last = gm1 + (gm1 - gm2);
-#pragma unroll
-      for (int t = 2; t < P + 2; ++t) gx[t] = gown[t - 2];
-      gx[1] = from_prev_lane(g_first, gown[P - 1]);       // grad_v[r0]    (lane 0: grad_v[0])
-      gx[0] = from_prev_lane(g_first, gown[P - 2]);       // grad_v[r0-1]  (lane 0: index -1 -> grad_v[0], :496)
-      gx[P + 2] = from_next_lane(0.0, gown[0]);           // grad_v[r0+P+1]
-      // the bulk boundary term uses grad_v[-1] (:498): CN reads it at interior index nx-2, FTCS at grid nx-1
-#pragma unroll
-      for (int t = 2; t < P + 3; ++t) {
-        const int idx = r0 - 1 + t;                        // gx[t] = grad_v[idx]
-        gx[t] = ((cn && idx == nx - 2) || idx == nx - 1) ? g_last : gx[t];
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < P + 3; ++t) gx[t] = 0.0;
-    }
-
-    double acc[P];            // next charge row at the own rows
-#pragma unroll
-    for (int j = 0; j < P; ++j) acc[j] = 0.0;
-    double acc0 = 0.0, accL = 0.0;
-
-    // ---- 2. species, G at a time --------------------------------------------------------------------
-    for (int k0 = 0; k0 < N; k0 += G) {
-      int kg[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) kg[g] = min(k0 + g, N - 1);     // a short last group recomputes species N-1
-      if (k0 > 0) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) load_window<P>(row_rsrc(crow0 + (int64_t)kg[g] * ldx, ldx), cc[g], lane);
-      }
-      double c0new[G], cLv[G], qe[G];
-      double x[G][P];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const SpecConst& S = A.spec[kg[g]];
-        const double flux = A.flux[b * N + kg[g]];
-        const double cL = A.cbulk[b * N + kg[g]];            // C[k,-1] = C0[(k+1)*nx-1] (:540 / :1008) -- also COLD[k,-1]
-        const double c0old = read_lane(cc[g][0], 0);
-        const double c1 = read_lane(cc[g][1], 0);
-        const double aa = S.mu * (v1 - vz);
-        if (cn) {   // Robin wall condition :528-532
-          const double rden = fast_rcp2(-S.twoD + aa);
-          c0new[g] = (-S.twoD - aa) * rden * c1 - 2 * flux * dx * rden;
-        } else {    // :1003-1006
-          c0new[g] = ((S.twoD + aa) * c1 + flux * 2. * dx) * fast_rcp2(S.twoD - aa);
-        }
-        cLv[g] = cL;
-        qe[g] = S.qe;
-        // boundary entries of the window: CN multiplies (C0+C0_old) / (C1+C1_old) (:496-499); FTCS reads the
-        // freshly set boundary values (:1010-1011, :1022)
-        const double pat0 = cn ? (c0new[g] + c0old) : c0new[g];
-        const double patL = cn ? (cL + cL) : cL;
-        cc[g][0] = (lane == 0) ? pat0 : cc[g][0];
-#pragma unroll
-        for (int t = 2; t < P + 2; ++t) cc[g][t] = (r0 + t == nx - 1) ? patL : cc[g][t];
-      }
-      if (cn) {
-        double ta[G][P], tc[G][P];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const SpecConst& S = A.spec[kg[g]];
-          // rows are divided by the constant diagonal 1+s up front (constants pre-scaled on the host)
-          const double hsr = S.hsr, e4r = S.e4r, eer = S.eer, omsr = S.omsr;
-#pragma unroll
-          for (int j = 0; j < P; ++j) {
-            // grad_v / lapl_v carry the INTERIOR index r (add_field :483-490); RHS = C[k,1:-1] . B1 (:553):
-            //   B[r] = c[r-1]*B1[r-1,r] + c[r]*B1[r,r] + c[r+1]*B1[r+1,r]
-            const double gm = e4r * gx[j], g0 = e4r * gx[j + 1], gp = e4r * gx[j + 2];
-            const double left = cc[g][j] * (hsr + gm);
-            const double right = cc[g][j + 2] * (hsr - gp);
-            x[g][j] = left + cc[g][j + 1] * (omsr + eer * lw[j]) + right;
-            ta[g][j] = -hsr + g0;                                        // A[r,r-1], :487
-            tc[g][j] = (r0 + j == m - 1) ? 0.0 : (-hsr - g0);            // A[r,r+1], :490; none in the last real row
-          }
-          ta[g][0] = (lane == 0) ? 0.0 : ta[g][0];                       // the first row has no sub-diagonal
-        }
-        tridiag_wave<P, G>(ta, tc, x, lds, XS, lane);                    // np.linalg.solve(A,B), :556
-      } else {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const SpecConst& S = A.spec[kg[g]];
-          const double sf = S.sf, dm = S.dm, Mf = S.Mf;
-#pragma unroll
-          for (int j = 0; j < P; ++j) {                                  // grid i = r0+j+1, :1012-1022
-            double Wt = sf - dm * gx[j + 3] + 0.5;                       // grad_v[i+1]
-            double Et = sf + dm * gx[j + 1] + 0.5;                       // grad_v[i-1]
-            if (!A.lf) {
-              Wt -= 0.5;
-              Et -= 0.5;
-            }
-            x[g][j] = Et * cc[g][j] + Mf * cc[g][j + 1] + Wt * cc[g][j + 2];
-          }
-        }
-      }
-      // ---- 3. results: HBM, next charge row, status, (fused) next windows ---------------------------
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (k0 + g < N) {
-          double* grow = crow0 + (int64_t)kg[g] * ldx;
-          store_rows<P>(__builtin_amdgcn_make_buffer_rsrc(grow, 0, (nx - 1) * 8, 0x00020000), x[g], lane);
-          if (lane == 0) grow[0] = c0new[g];
-#pragma unroll
-          for (int j = 0; j < P; ++j) {
-            const bool real = r0 + j < m;
-            const double xv = real ? x[g][j] : 0.0;
-            acc[j] = __builtin_fma(-xv, qe[g], acc[j]);
-            chk += xv - xv;
-            mn = fmin(mn, xv);
-          }
-          chk += c0new[g] - c0new[g];
-          mn = fmin(mn, c0new[g]);
-          acc0 = __builtin_fma(-c0new[g], qe[g], acc0);
-          accL = __builtin_fma(-cLv[g], qe[g], accL);
-        }
-        if (single_round) {   // next step's window from registers: own rows + one DPP hop for each halo point
-#pragma unroll
-          for (int j = 0; j < P; ++j) cc[g][j + 1] = x[g][j];
-          cc[g][0] = from_prev_lane(c0new[g], x[g][P - 1]);
-          cc[g][P + 1] = from_next_lane(0.0, x[g][0]);
-        }
-      }
-    }
-    // ---- 4. charge row of the new state ------------------------------------------------------------------
-    {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(lout, 0, (nx - 1) * 8, 0x00020000);
-      store_rows<P>(rs, acc, lane);
-      if (lane == 0) {
-        lout[0] = acc0;
-        lout[nx - 1] = accL;
-      }
-      if (single_round) {
-#pragma unroll
-        for (int j = 0; j < P; ++j) lw[j + 1] = acc[j];
-        lw[0] = from_prev_lane(acc0, acc[P - 1]);
-        lw[P + 1] = 0.0;
-      }
-    }
-    double* tmp = lin;
-    lin = lout;
-    lout = tmp;
-    if (!single_round && step + 1 < A.nsteps) {
-      // the next step re-reads rows this wave has just written (other lanes' pieces included)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-  }
-  const unsigned long long nan_mask = __ballot(chk != chk);
-  const unsigned long long neg_mask = __ballot(mn < 0.0);
-  if (lane == 0) {
-    int st = PNP_STATUS_OK;
-    if (neg_mask) st = PNP_STATUS_NEGATIVE;
-    if (nan_mask) st = PNP_STATUS_NAN;
-    if (st) atomicMax(&A.status[b], st);
-  }
-}
-
 // ================================================================================================
-// step_kernel4<P,W,CN>: the register-resident kernel with W waves per operating point.
-// A lone wave issues fp64 VALU at about half rate (measured: ~8 cycles per instruction for one wave per
-// SIMD, ~4 with two or more), so small batches want several waves per SIMD.  Here wave w advances species
+// step_kernel_rr<P,W,CN>: W waves per operating point.
+// One wave issues an fp64 VALU instruction only every ~8.5 cycles while the SIMD can take one every ~2.2
+// (tools/probe/f64_rate.hip), so throughput needs >= 4 waves per SIMD and small batches want their work
+// spread over several waves.  Here wave w advances species
 // w, w+W, ... on its own: every wave loads the lagged charge window, runs the (cheap, DPP-only) Poisson
 // scan redundantly, solves its species, and the waves meet exactly once per timestep to add up their
 // contributions to the next charge row through a ping-pong LDS buffer (one s_barrier, LDS-only fences).
 // ================================================================================================
 template <int P, int W>
-constexpr int step4_min_waves() {
+constexpr int step_rr_min_waves() {
   return P <= 4 ? 4 : (P == 8 ? 3 : 1);
 }
 
 template <int P, int W, bool CN>
-__global__ __launch_bounds__(64 * W, (step4_min_waves<P, W>())) void step_kernel4(const DevArgs A) {
+__global__ __launch_bounds__(64 * W, (step_rr_min_waves<P, W>())) void step_kernel_rr(const DevArgs A) {
   static_assert(P >= 2 && P % 2 == 0, "window loads need an even P");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int XS = 384;                      // cyclic-reduction strip of one wave
@@ -1601,64 +1368,37 @@ bool step_config_supported(int W, int G) {
   return key == 11 || key == 12 || key == 13 || key == 21 || key == 22 || key == 31 || key == 41;
 }
 
-template <int P>
-static hipError_t launch_step3_p(const DevArgs& a, int G, hipStream_t stream) {
-  const dim3 grid((unsigned)a.B), block(64);
-  const size_t lds = (size_t)G * 384 * sizeof(double);
-  const bool cn = a.method == PNP_METHOD_CRANK_NICOLSON;
-  switch (G * 2 + (cn ? 1 : 0)) {
-    case 3: hipLaunchKernelGGL((step_kernel3<P, 1, true>), grid, block, lds, stream, a); break;
-    case 5: hipLaunchKernelGGL((step_kernel3<P, 2, true>), grid, block, lds, stream, a); break;
-    case 7: hipLaunchKernelGGL((step_kernel3<P, 3, true>), grid, block, lds, stream, a); break;
-    case 2: hipLaunchKernelGGL((step_kernel3<P, 1, false>), grid, block, lds, stream, a); break;
-    case 4: hipLaunchKernelGGL((step_kernel3<P, 2, false>), grid, block, lds, stream, a); break;
-    case 6: hipLaunchKernelGGL((step_kernel3<P, 3, false>), grid, block, lds, stream, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
 // register-resident kernel: Dirichlet/Dirichlet Poisson, even P, no FTCS rate term
-bool step3_applicable(const DevArgs& a) {
+bool step_rr_applicable(const DevArgs& a) {
   const int P = points_per_lane(a.nx);
   return a.pb_mode == PNP_PB_DD && P >= 2 && !a.has_rates && a.nx >= 6;
 }
 
-hipError_t launch_step3(const DevArgs& a, int G, hipStream_t stream) {
-  switch (points_per_lane(a.nx)) {
-    case 2: return launch_step3_p<2>(a, G, stream);
-    case 4: return launch_step3_p<4>(a, G, stream);
-    case 8: return launch_step3_p<8>(a, G, stream);
-    case 16: return launch_step3_p<16>(a, G, stream);
-    default: return hipErrorInvalidValue;
-  }
-}
-
 template <int P>
-static hipError_t launch_step4_p(const DevArgs& a, int W, hipStream_t stream) {
+static hipError_t launch_step_rr_p(const DevArgs& a, int W, hipStream_t stream) {
   const dim3 grid((unsigned)a.B);
   const size_t lds = (size_t)(W * 384 + 2 * W * (64 * P + 2)) * sizeof(double);
   const bool cn = a.method == PNP_METHOD_CRANK_NICOLSON;
   switch (W * 2 + (cn ? 1 : 0)) {
-    case 3: hipLaunchKernelGGL((step_kernel4<P, 1, true>), grid, dim3(64), lds, stream, a); break;
-    case 5: hipLaunchKernelGGL((step_kernel4<P, 2, true>), grid, dim3(128), lds, stream, a); break;
-    case 7: hipLaunchKernelGGL((step_kernel4<P, 3, true>), grid, dim3(192), lds, stream, a); break;
-    case 9: hipLaunchKernelGGL((step_kernel4<P, 4, true>), grid, dim3(256), lds, stream, a); break;
-    case 2: hipLaunchKernelGGL((step_kernel4<P, 1, false>), grid, dim3(64), lds, stream, a); break;
-    case 4: hipLaunchKernelGGL((step_kernel4<P, 2, false>), grid, dim3(128), lds, stream, a); break;
-    case 6: hipLaunchKernelGGL((step_kernel4<P, 3, false>), grid, dim3(192), lds, stream, a); break;
-    case 8: hipLaunchKernelGGL((step_kernel4<P, 4, false>), grid, dim3(256), lds, stream, a); break;
+    case 3: hipLaunchKernelGGL((step_kernel_rr<P, 1, true>), grid, dim3(64), lds, stream, a); break;
+    case 5: hipLaunchKernelGGL((step_kernel_rr<P, 2, true>), grid, dim3(128), lds, stream, a); break;
+    case 7: hipLaunchKernelGGL((step_kernel_rr<P, 3, true>), grid, dim3(192), lds, stream, a); break;
+    case 9: hipLaunchKernelGGL((step_kernel_rr<P, 4, true>), grid, dim3(256), lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((step_kernel_rr<P, 1, false>), grid, dim3(64), lds, stream, a); break;
+    case 4: hipLaunchKernelGGL((step_kernel_rr<P, 2, false>), grid, dim3(128), lds, stream, a); break;
+    case 6: hipLaunchKernelGGL((step_kernel_rr<P, 3, false>), grid, dim3(192), lds, stream, a); break;
+    case 8: hipLaunchKernelGGL((step_kernel_rr<P, 4, false>), grid, dim3(256), lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t launch_step4(const DevArgs& a, int W, hipStream_t stream) {
+hipError_t launch_step_rr(const DevArgs& a, int W, hipStream_t stream) {
   switch (points_per_lane(a.nx)) {
-    case 2: return launch_step4_p<2>(a, W, stream);
-    case 4: return launch_step4_p<4>(a, W, stream);
-    case 8: return launch_step4_p<8>(a, W, stream);
-    case 16: return launch_step4_p<16>(a, W, stream);
+    case 2: return launch_step_rr_p<2>(a, W, stream);
+    case 4: return launch_step_rr_p<4>(a, W, stream);
+    case 8: return launch_step_rr_p<8>(a, W, stream);
+    case 16: return launch_step_rr_p<16>(a, W, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool: compile ONE kernel instantiation and print resource usage + instruction mix
-# usage: tools/kexp.sh "step_kernel3<8,3>" [extra hipcc flags]
+# usage: tools/kexp.sh "step_kernel_rr<8,3,true>" [extra hipcc flags]
 INST=$1; shift
 D=/tmp/asm; mkdir -p $D
 SRC=/root/repo/catint_amd/csrc
