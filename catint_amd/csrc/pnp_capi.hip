@@ -68,15 +68,15 @@ const char* pnp_last_error(const pnp_handle* h) { return h ? h->err.c_str() : g_
 
 void pnp_destroy(pnp_handle* h) {
   if (!h) return;
-  hipSetDevice(h->cfg.device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
                   (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp})
-    if (p) hipFree(p);
-  if (h->ev0) hipEventDestroy(h->ev0);
-  if (h->ev1) hipEventDestroy(h->ev1);
-  if (h->stream) hipStreamDestroy(h->stream);
+    if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -202,7 +202,7 @@ int pnp_set_species(pnp_handle* h, const double* D, const double* charges) {
     S.Mf = -2. * D[k] * dt / (dx * dx);              // :1015
     if (!h->a.lf) S.Mf += 1;                         // :1021
   }
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipMemcpyAsync(h->spec, sc, sizeof(sc), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->have_species = true;
@@ -237,7 +237,7 @@ int pnp_set_reactions(pnp_handle* h, int32_t nreactions, const int32_t* n_lhs, c
     rt.kr[r] = kr[r];
   }
   if (nreactions > 0 && !h->rates) {
-    hipSetDevice(h->cfg.device);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, dev_alloc(h, &h->rates, (size_t)h->cfg.batch_capacity * h->a.N * h->a.ldx));
     HIP_TRY(h, hipMemsetAsync(h->rates, 0, (size_t)h->cfg.batch_capacity * h->a.N * h->a.ldx * sizeof(double), h->stream));
   }
@@ -249,7 +249,7 @@ int pnp_set_reactions(pnp_handle* h, int32_t nreactions, const int32_t* n_lhs, c
 int pnp_set_flux(pnp_handle* h, const double* flux) {
   if (!h || !flux) return fail(h, PNP_EINVAL, "pnp_set_flux: null argument");
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_set_flux: call pnp_set_batch first");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipMemcpyAsync(h->flux, flux, (size_t)h->B * h->a.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return PNP_OK;
@@ -258,7 +258,7 @@ int pnp_set_flux(pnp_handle* h, const double* flux) {
 int pnp_set_pb(pnp_handle* h, const double* pb, const double* vzeta) {
   if (!h || !pb || !vzeta) return fail(h, PNP_EINVAL, "pnp_set_pb: null argument");
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_set_pb: call pnp_set_batch first");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipMemcpyAsync(h->pb, pb, (size_t)h->B * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->vzeta, vzeta, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -269,7 +269,7 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   if (!h || !c0 || !pb || !vzeta || !flux) return fail(h, PNP_EINVAL, "pnp_set_batch: null argument");
   if (!h->have_species) return fail(h, PNP_ESTATE, "pnp_set_batch: call pnp_set_species first");
   if (B < 1 || B > h->cfg.batch_capacity) return fail(h, PNP_EINVAL, "pnp_set_batch: B outside [1, batch_capacity]");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
   h->B = B;
   h->a.B = B;
@@ -336,7 +336,7 @@ int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch) {
   if (!h) return PNP_EINVAL;
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_step: call pnp_set_batch first");
   if (nsteps < 0) return fail(h, PNP_EINVAL, "pnp_step: nsteps < 0");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   int spl = steps_per_launch <= 0 ? 64 : steps_per_launch;
   if (h->a.has_rates) spl = 1;
   int left = nsteps;
@@ -353,7 +353,7 @@ int pnp_integrate(pnp_handle* h, int32_t nt, const int32_t* itout, int32_t n_out
   if (!h) return PNP_EINVAL;
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_integrate: call pnp_set_batch first");
   if (nt < 1 || n_out < 0 || (n_out > 0 && (!itout || !cout))) return fail(h, PNP_EINVAL, "pnp_integrate: bad arguments");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
   const int64_t B = h->B;
   // CN: for n in range(1,nt) (calculator_old.py:512);  FTCS: for n in range(0,nt) (:990)
@@ -399,7 +399,7 @@ static int ensure_potential_buffers(pnp_handle* h) {
 int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
   if (!h || !c || !dcdt) return fail(h, PNP_EINVAL, "pnp_mol_rhs: null argument");
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_mol_rhs: call pnp_set_batch first");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
   const int64_t B = h->B;
   const size_t cnt = (size_t)h->cfg.batch_capacity * N * ldx;
@@ -424,7 +424,7 @@ int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
 int pnp_get_state(pnp_handle* h, double* c, double* v, double* grad_v, double* lapl_v) {
   if (!h) return PNP_EINVAL;
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_get_state: call pnp_set_batch first");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
   const int64_t B = h->B;
   const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
@@ -446,7 +446,7 @@ int pnp_get_state(pnp_handle* h, double* c, double* v, double* grad_v, double* l
 int pnp_get_surface(pnp_handle* h, double* csurf, double* vsurf, double* esurf) {
   if (!h) return PNP_EINVAL;
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_get_surface: call pnp_set_batch first");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int64_t B = h->B;
   const int ldx = h->a.ldx;
   if (csurf) {
@@ -471,7 +471,7 @@ int pnp_get_surface(pnp_handle* h, double* csurf, double* vsurf, double* esurf) 
 int pnp_get_status(pnp_handle* h, int32_t* status) {
   if (!h || !status) return fail(h, PNP_EINVAL, "pnp_get_status: null argument");
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_get_status: call pnp_set_batch first");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipMemcpyAsync(status, h->status, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return PNP_OK;
@@ -479,21 +479,21 @@ int pnp_get_status(pnp_handle* h, int32_t* status) {
 
 int pnp_synchronize(pnp_handle* h) {
   if (!h) return PNP_EINVAL;
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return PNP_OK;
 }
 
 int pnp_timer_start(pnp_handle* h) {
   if (!h) return PNP_EINVAL;
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
   return PNP_OK;
 }
 
 int pnp_timer_stop(pnp_handle* h, float* elapsed_ms) {
   if (!h || !elapsed_ms) return fail(h, PNP_EINVAL, "pnp_timer_stop: null argument");
-  hipSetDevice(h->cfg.device);
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
   HIP_TRY(h, hipEventSynchronize(h->ev1));
   HIP_TRY(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));

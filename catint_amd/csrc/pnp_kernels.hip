@@ -71,15 +71,6 @@ __device__ __forceinline__ void wg_sync() {
   }
 }
 
-__device__ __forceinline__ double shfl_up0(double v, int s, int lane) {
-  double t = __shfl_up(v, s, 64);
-  return lane >= s ? t : 0.0;
-}
-__device__ __forceinline__ double shfl_dn0(double v, int s, int lane) {
-  double t = __shfl_down(v, s, 64);
-  return lane + s < 64 ? t : 0.0;
-}
-
 // padded LDS index of grid point i: one pad double per P points makes the blocked access
 // (lane stride P doubles) hit 64 distinct banks for ds_read_b64 / ds_write_b64.
 template <int P>

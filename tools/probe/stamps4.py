@@ -16,9 +16,9 @@ s.set_batch(c0, pb, vz, fl)
 s.step(nfuse, nfuse)
 s.set_batch(c0, pb, vz, fl)
 s.step(nfuse, nfuse)
-buf = (C.c_ulonglong * (16 * 256))()
+buf = (C.c_ulonglong * (4096 + 4 * 65536))()
 _capi.load_library().pnp_debug_dump(s._h, buf)
-t = np.array(buf, dtype=np.uint64).reshape(4, 64, 16).astype(np.int64)
+t = np.array(buf, dtype=np.uint64)[:4096].reshape(4, 64, 16).astype(np.int64)
 names = ['loads+poisson', 'bc+assembly', 'tridiag', 'results', 'exchange', 'charge row']
 for w in range(W):
     for st in range(2, nfuse):
