@@ -105,7 +105,7 @@ def main():
     ndev = torch.cuda.device_count()
     device = local_rank % max(ndev, 1)          # one rank per GPU on a full node; ranks share GPUs only in rehearsals
     backend = os.environ.get('CATINT_DIST_BACKEND', 'nccl')   # nccl = RCCL over xGMI; gloo for single-GPU rehearsals
-    if world > 1:
+    if world > 1 or os.environ.get('CATINT_FORCE_DIST'):     # the env hook lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         torch.cuda.set_device(device)
         if backend == 'nccl':
