@@ -212,7 +212,7 @@ def main():
                        'parallelism': 'batch-sharded x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'pnp::step_kernel (P=%d points/lane)' % next(P for P in (1, 2, 4, 8, 16) if nx - 2 <= 64 * P),
+                         'kernel': 'pnp::step_kernel* (P=%d points/lane)' % next((P for P in (1, 2, 4, 8, 16) if nx - 2 <= 64 * P), 16),
                          'launch_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg_bytes_per_launch,
                          'timesteps_per_launch': args.steps / n_launch},
             'lanes_ok': int((status == 0).sum()), 'lanes_total': int(B),

@@ -89,7 +89,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
     return fail(nullptr, PNP_EINVAL, "pnp_create: nspecies out of range [1,16]");
   const int P = points_per_lane(cfg->nx);
   if (P == 0)
-    return fail(nullptr, PNP_EINVAL, "pnp_create: nx must be in [5, 1026] (one grid per wavefront, <=16 points per lane)");
+    return fail(nullptr, PNP_EINVAL, "pnp_create: nx must be in [5, 4098] (<=16 points per lane, <=4 waves per system)");
   if (cfg->method != PNP_METHOD_CRANK_NICOLSON && cfg->method != PNP_METHOD_FTCS)
     return fail(nullptr, PNP_EINVAL, "pnp_create: no calculator found with this method");  // calculator_old.py:109-111
   if (cfg->pb_mode < PNP_PB_DD || cfg->pb_mode > PNP_PB_VBULK_GBULK)
@@ -307,6 +307,12 @@ static int run_steps(pnp_handle* h, int nsteps) {
   // kernel with three interleaved species per wave has the shortest critical path; once the batch
   // oversubscribes the chip the register-resident kernel (one wave per lane, 3 waves/SIMD) wins because the
   // LDS pipe stops being the shared bottleneck.  P = 16 keeps the LDS-staged kernel (twice the occupancy).
+  if (waves_per_system(a.nx) > 1) {
+    HIP_TRY(h, launch_step_mw(a, h->stream));
+    if (nsteps & 1) h->cur = 1 - h->cur;
+    h->steps_done += nsteps;
+    return PNP_OK;
+  }
   bool rr = step_rr_applicable(a) && a.B >= 2048 && h->P <= 8;
   if (h->kernel_override == 2) rr = false;
   if (h->kernel_override == 4) rr = step_rr_applicable(a);
@@ -398,6 +404,7 @@ static int ensure_potential_buffers(pnp_handle* h) {
 
 int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
   if (!h || !c || !dcdt) return fail(h, PNP_EINVAL, "pnp_mol_rhs: null argument");
+  if (waves_per_system(h->a.nx) > 1) return fail(h, PNP_EINVAL, "pnp_mol_rhs: nx > 1026 is not supported by the method-of-lines RHS");
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_mol_rhs: call pnp_set_batch first");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;

@@ -68,8 +68,11 @@ struct ReactionTable {
   double kr[PNP_MAX_REACTIONS];
 };
 
-// points-per-lane template instance that covers nx (interior m = nx-2 <= 64*P); 0 if unsupported
+// points-per-lane template instance that covers nx (interior m = nx-2 <= 64*P*waves_per_system); 0 if unsupported
 int points_per_lane(int nx);
+// waves cooperating on one tridiagonal system: 1 up to nx = 1026, 2 up to 2050, 4 up to 4098
+int waves_per_system(int nx);
+hipError_t launch_step_mw(const DevArgs& a, hipStream_t stream);
 // W = waves per operating point, G = species interleaved inside one wave, chosen for a batch of B lanes
 void choose_step_config(int N, int64_t B, int P, int* W, int* G);
 bool step_config_supported(int W, int G);

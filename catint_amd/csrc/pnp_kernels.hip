@@ -1123,6 +1123,465 @@ __global__ __launch_bounds__(64 * W, (step_rr_min_waves<P, W>())) void step_kern
   }
 }
 
+// ================================================================================================
+// Systems spanning several waves (nx up to 64*16*4 + 2 = 4098): step_kernel_mw<P,WY>.
+// A workgroup of WY waves owns one operating point; thread t = wave*64 + lane owns rows t*P .. t*P+P-1 of
+// EVERY tridiagonal system (one species at a time).  The algorithm is step_kernel's with the wave-level
+// pieces lifted to the workgroup: rows are staged cooperatively, the blocked scans add the totals of the
+// preceding waves, and the cyclic reduction runs over the 64*WY interface rows through one shared,
+// ping-pong LDS strip with an s_barrier per step.  Throughput is secondary here (one workgroup per CU);
+// this kernel exists so that no grid size of the reference is out of reach.
+// ================================================================================================
+template <int P, int WY>
+__host__ __device__ constexpr int rowbuf_mw_doubles() {
+  constexpr int CAP = 128 * WY * (P / 2 + 1);
+  return (CAP + CAP / P + 4 + 1) & ~1;
+}
+template <int WY>
+__host__ __device__ constexpr int xch_doubles() {      // [2 ping-pong][3 arrays][guard | 64*WY | guard]
+  return 2 * 3 * (2 * 64 * WY);
+}
+
+// workgroup-wide inclusive blocked scan: per-wave scan, then the totals of the other waves
+template <int P, int WY, bool REV>
+__device__ __forceinline__ void blocked_scan_wg(double (&x)[P], double* strip_w, double* tots, int lane, int wave,
+                                                double& total, double& base) {
+  double wt, wb;
+  blocked_scan<P, REV>(x, strip_w, lane, wt, wb);
+  if (lane == 0) tots[wave] = wt;
+  wg_sync<2>();
+  double off = 0.0, all = 0.0;
+#pragma unroll
+  for (int w2 = 0; w2 < WY; ++w2) {
+    const double t = tots[w2];
+    all += t;
+    off += (REV ? (w2 > wave) : (w2 < wave)) ? t : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < P; ++j) x[j] += off;
+  total = all;
+  base = wb + off;
+  wg_sync<2>();
+}
+
+// Poisson for a workgroup (all five boundary combinations); mirrors poisson_wave.
+template <int P, int WY, bool WANT_V, int SHIFT>
+__device__ __forceinline__ double poisson_wg(const DevArgs& A, double* LV, double* GV, double* VV, double* strip_w,
+                                             double* scal, double vw, double vb, double gw, double gb, int lane, int wave) {
+  const int nx = A.nx, m = A.m;
+  const int tid = wave * 64 + lane;
+  const int r0 = tid * P;
+  const double dx = A.dx;
+  double vown[P], gown[P];
+  double* tots = scal;          // WY doubles
+  if (A.pb_mode == PNP_PB_DD) {
+    double Hi[P], G[P];
+    const double dx2 = dx * dx;
+    if (tid == 0) LV[pidx<P>(nx - 1)] = 0.0;    // the bulk point is not part of the interior sums
+    wg_sync<2>();
+#pragma unroll
+    for (int j = 0; j < P; ++j) Hi[j] = LV[pidx<P>(r0 + j + 1)] * dx2;
+    double tot1, baseH;
+    blocked_scan_wg<P, WY, false>(Hi, strip_w, tots, lane, wave, tot1, baseH);
+#pragma unroll
+    for (int j = 0; j < P; ++j) G[j] = Hi[j];
+    double totAll, baseG;
+    blocked_scan_wg<P, WY, false>(G, strip_w, tots, lane, wave, totAll, baseG);
+    const double totG = totAll - (double)(64 * WY * P - m) * tot1;
+    const double w0 = (vb - vw - totG) / (double)(nx - 1);
+    const double inv2dx = 1.0 / (2 * dx);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const double Hx = (j == 0) ? baseH : Hi[j > 0 ? j - 1 : 0];
+      const double Gex = (j == 0) ? baseG : G[j > 0 ? j - 1 : 0];
+      gown[j] = inv2dx * ((w0 + Hi[j]) + (w0 + Hx));
+      vown[j] = vw + (double)(r0 + j + 1) * w0 + Gex;
+    }
+  } else {
+    const bool g_from_wall = (A.pb_mode == PNP_PB_GWALL_VBULK) || (A.pb_mode == PNP_PB_VWALL_GWALL);
+    const bool v_from_wall = (A.pb_mode == PNP_PB_VWALL_GBULK) || (A.pb_mode == PNP_PB_VWALL_GWALL);
+    double t[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const double lv = LV[pidx<P>(r0 + j + 1)];
+      t[j] = (r0 + j < m) ? lv * dx : 0.0;
+    }
+    double tot, base;
+    if (g_from_wall) {
+      blocked_scan_wg<P, WY, false>(t, strip_w, tots, lane, wave, tot, base);
+#pragma unroll
+      for (int j = 0; j < P; ++j) gown[j] = gw + t[j];
+    } else {
+      blocked_scan_wg<P, WY, true>(t, strip_w, tots, lane, wave, tot, base);
+#pragma unroll
+      for (int j = 0; j < P; ++j) gown[j] = gb - t[j];
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) t[j] = (r0 + j < m) ? gown[j] * dx : 0.0;
+    if (v_from_wall) {
+      blocked_scan_wg<P, WY, false>(t, strip_w, tots, lane, wave, tot, base);
+#pragma unroll
+      for (int j = 0; j < P; ++j) vown[j] = vw + t[j];
+    } else {
+      blocked_scan_wg<P, WY, true>(t, strip_w, tots, lane, wave, tot, base);
+#pragma unroll
+      for (int j = 0; j < P; ++j) vown[j] = vb - t[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    GV[pidx<P>(r0 + j + 1 + SHIFT)] = gown[j];
+    if constexpr (WANT_V) VV[pidx<P>(r0 + j + 1)] = vown[j];
+  }
+  if (tid == 0) scal[WY] = vown[0];     // v[1]
+  wg_sync<2>();
+  if (tid == 0) {
+    const double g1 = GV[pidx<P>(1 + SHIFT)], g2 = GV[pidx<P>(2 + SHIFT)];
+    const double gm1 = GV[pidx<P>(nx - 2 + SHIFT)], gm2 = GV[pidx<P>(nx - 3 + SHIFT)];
+    double g0, gl;
+    if (A.pb_mode == PNP_PB_DD) {
+      g0 = g1 + (g1 - g2);
+      gl = gm1 + (gm1 - gm2);
+    } else if (A.pb_mode == PNP_PB_GWALL_VBULK || A.pb_mode == PNP_PB_VWALL_GWALL) {
+      g0 = gw;
+      gl = gm1 + (gm1 - gm2);
+    } else {
+      gl = gb;
+      g0 = g1 + (g1 - g2);
+    }
+    GV[pidx<P>(0 + SHIFT)] = g0;
+    GV[pidx<P>(nx - 1 + SHIFT)] = gl;
+    if constexpr (SHIFT == 1) {
+      GV[pidx<P>(0)] = g0;
+      GV[pidx<P>(nx + 1)] = gl;
+    }
+    if constexpr (WANT_V) {
+      const double v1 = VV[pidx<P>(1)], v2 = VV[pidx<P>(2)];
+      const double vm1 = VV[pidx<P>(nx - 2)], vm2 = VV[pidx<P>(nx - 3)];
+      double v0, vl;
+      if (A.pb_mode == PNP_PB_DD) {
+        v0 = vw;
+        vl = vb;
+      } else if (A.pb_mode == PNP_PB_VWALL_GBULK || A.pb_mode == PNP_PB_VWALL_GWALL) {
+        v0 = vw;
+        vl = vm1 + (vm1 - vm2);
+      } else {
+        vl = vb;
+        v0 = v1 + (v1 - v2);
+      }
+      VV[pidx<P>(0)] = v0;
+      VV[pidx<P>(nx - 1)] = vl;
+    }
+  }
+  wg_sync<2>();
+  return scal[WY];
+}
+
+// tridiagonal solve of 64*WY*P unknowns, P per thread (rows pre-scaled to unit diagonal), in place.
+template <int P, int WY>
+__device__ __forceinline__ void tridiag_wg(double (&a)[P], double (&c)[P], double (&d)[P], double* XCH, int tid) {
+  constexpr int NL = 64 * WY;          // interface rows
+  constexpr int ARR = 2 * NL;          // guard | NL | guard, guards of NL/2
+  constexpr int GD = NL / 2;
+  auto buf = [&](int e, int arr) { return XCH + ((e & 1) * 3 + arr) * ARR + GD + tid; };
+  {  // zero guards of both ping-pong buffers: NL threads cover the 2*GD guard slots of each array
+    const int gofs = (tid < GD) ? -GD : GD;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int arr = 0; arr < 3; ++arr) buf(e, arr)[gofs] = 0.0;
+  }
+  int e = 0;
+#pragma unroll
+  for (int i = 1; i < P - 1; ++i) {
+    const double ai = a[i];
+    const double bb = __builtin_fma(-ai, c[i - 1], 1.0);
+    const double dd = __builtin_fma(-ai, d[i - 1], d[i]);
+    const double vv = -ai * a[i - 1];
+    const double r = fast_rcp(bb);
+    a[i] = vv * r;
+    d[i] = dd * r;
+    c[i] = c[i] * r;
+  }
+#pragma unroll
+  for (int i = P - 3; i >= 0; --i) {
+    const double cs = c[i];
+    d[i] = __builtin_fma(-cs, d[i + 1], d[i]);
+    a[i] = __builtin_fma(-cs, a[i + 1], a[i]);
+    c[i] = -cs * c[i + 1];
+  }
+  buf(e, 0)[0] = a[0];
+  buf(e, 1)[0] = c[0];
+  buf(e, 2)[0] = d[0];
+  wg_sync<2>();
+  const double Vn0 = buf(e, 0)[1], Wn0 = buf(e, 1)[1], dn0 = buf(e, 2)[1];
+  ++e;
+  double ra, rc, rd;
+  {
+    const double aL = a[P - 1], cL = c[P - 1];
+    double rb = __builtin_fma(-aL, c[P - 2], 1.0);
+    rb = __builtin_fma(-cL, Vn0, rb);
+    const double rr = fast_rcp(rb);
+    double t = __builtin_fma(-aL, d[P - 2], d[P - 1]);
+    t = __builtin_fma(-cL, dn0, t);
+    ra = (-aL * a[P - 2]) * rr;
+    rc = (-cL * Wn0) * rr;
+    rd = t * rr;
+  }
+#pragma unroll
+  for (int s = 1; s < NL; s <<= 1) {
+    buf(e, 0)[0] = ra;
+    buf(e, 1)[0] = rc;
+    buf(e, 2)[0] = rd;
+    wg_sync<2>();
+    const double aL = buf(e, 0)[-s], aR = buf(e, 0)[s];
+    const double cL = buf(e, 1)[-s], cR = buf(e, 1)[s];
+    const double dL = buf(e, 2)[-s], dR = buf(e, 2)[s];
+    ++e;
+    double nb = __builtin_fma(-ra, cL, 1.0);
+    nb = __builtin_fma(-rc, aR, nb);
+    double nd = __builtin_fma(-ra, dL, rd);
+    nd = __builtin_fma(-rc, dR, nd);
+    const double na = -ra * aL;
+    const double nc = -rc * cR;
+    const double rr = fast_rcp(nb);
+    ra = na * rr;
+    rc = nc * rr;
+    rd = nd * rr;
+  }
+  buf(e, 0)[0] = rd;
+  wg_sync<2>();
+  const double yL = buf(e, 0)[-1];
+#pragma unroll
+  for (int i = 0; i < P - 1; ++i) {
+    const double t = __builtin_fma(-a[i], yL, d[i]);
+    d[i] = __builtin_fma(-c[i], rd, t);
+  }
+  d[P - 1] = rd;
+  wg_sync<2>();   // the strips are free again
+}
+
+template <int P, int WY>
+__global__ __launch_bounds__(64 * WY, 1) void step_kernel_mw(const DevArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int RB = rowbuf_mw_doubles<P, WY>();
+  constexpr int IT = P / 2 + 1;          // coalesced 16-byte chunks owned by one thread
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = blockIdx.x;
+  const int nx = A.nx, m = A.m, ldx = A.ldx, N = A.N;
+  double* LV = lds;
+  double* GV = lds + RB;
+  double* ROW = lds + 2 * RB;
+  double* XCH = lds + 3 * RB;
+  double* strip_w = XCH + xch_doubles<WY>() + wave * 256;     // per-wave scan strip
+  double* scal = XCH + xch_doubles<WY>() + WY * 256;          // WY wave totals + v[1]
+  const int r0 = tid * P;
+  const double dx = A.dx, dt = A.dt;
+  double* lin = A.lapl_a + b * (int64_t)ldx;
+  double* lout = A.lapl_b + b * (int64_t)ldx;
+  double* crow0 = A.c + b * (int64_t)N * ldx;
+  const bool cn = (A.method == PNP_METHOD_CRANK_NICOLSON);
+  const double vw = A.pb[b * 4 + 0], vb = A.pb[b * 4 + 1], gw = A.pb[b * 4 + 2], gb = A.pb[b * 4 + 3];
+  const double vz = A.vzeta[b];
+  double chk = 0.0, mn = 0.0;
+  for (int i = tid; i < 3 * RB + xch_doubles<WY>() + WY * 256 + WY + 2; i += 64 * WY) lds[i] = 0.0;
+  wg_sync<2>();
+  const int ls2 = pidx<P>(2 * tid);
+
+  for (int step = 0; step < A.nsteps; ++step) {
+    // ---- 1. lagged potential ---------------------------------------------------------------------
+    double v1 = 0.0;
+    if (A.use_mig) {
+      const __amdgpu_buffer_rsrc_t rl = row_rsrc(lin, ldx);
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const d2 t = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rl, tid * 16 + it * (1024 * WY), 0, 0));
+        LV[pair_slot<P>(ls2, WY * it)] = t.x;
+        LV[pair_slot<P>(ls2, WY * it) + PAIR_STEP<P>] = t.y;
+      }
+      wg_sync<2>();
+      v1 = poisson_wg<P, WY, false, 1>(A, LV, GV, nullptr, strip_w, scal, vw, vb, gw, gb, lane, wave);
+      if (tid == 0 && cn) GV[pidx<P>(nx - 2 + 1)] = GV[pidx<P>(nx - 1 + 1)];
+      wg_sync<2>();
+    }
+    d2 accp[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) accp[it] = (d2)(0.0);
+
+    // ---- 2. species, one at a time, all waves together ------------------------------------------------
+    for (int k = 0; k < N; ++k) {
+      double* grow = crow0 + (int64_t)k * ldx;
+      const __amdgpu_buffer_rsrc_t rs = row_rsrc(grow, ldx);
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const d2 t = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16 + it * (1024 * WY), 0, 0));
+        ROW[pair_slot<P>(ls2, WY * it)] = t.x;
+        ROW[pair_slot<P>(ls2, WY * it) + PAIR_STEP<P>] = t.y;
+      }
+      wg_sync<2>();
+      const SpecConst& S = A.spec[k];
+      const double flux = A.flux[b * N + k];
+      const double cL = A.cbulk[b * N + k];
+      const double c1 = ROW[pidx<P>(1)], c0old = ROW[pidx<P>(0)], cLold = ROW[pidx<P>(nx - 1)];
+      const double aa = S.mu * (v1 - vz);
+      double c0new;
+      if (cn) {
+        const double rden = fast_rcp2(-S.twoD + aa);
+        c0new = (-S.twoD - aa) * rden * c1 - 2 * flux * dx * rden;
+      } else {
+        c0new = ((S.twoD + aa) * c1 + flux * 2. * dx) * fast_rcp2(S.twoD - aa);
+      }
+      wg_sync<2>();
+      if (tid == 0) {
+        ROW[pidx<P>(0)] = cn ? (c0new + c0old) : c0new;
+        ROW[pidx<P>(nx - 1)] = cn ? (cL + cLold) : cL;
+      }
+      wg_sync<2>();
+      double x[P];
+      if (cn) {
+        const double hsr = S.hsr, e4r = S.e4r, eer = S.eer, omsr = S.omsr;
+        double ta[P], tc[P], cc[P + 2], g4[P + 2];
+#pragma unroll
+        for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
+#pragma unroll
+        for (int t = 0; t < P + 2; ++t) g4[t] = e4r * GV[pidx<P>(r0 + t)];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const double lq = LV[pidx<P>(r0 + j)];
+          const double left = cc[j] * (hsr + g4[j]);
+          const double right = cc[j + 2] * (hsr - g4[j + 2]);
+          x[j] = left + cc[j + 1] * (omsr + eer * lq) + right;
+          ta[j] = -hsr + g4[j + 1];
+          tc[j] = (r0 + j == m - 1) ? 0.0 : (-hsr - g4[j + 1]);
+        }
+        ta[0] = (tid == 0) ? 0.0 : ta[0];
+        wg_sync<2>();
+        tridiag_wg<P, WY>(ta, tc, x, XCH, tid);
+      } else {
+        const double sf = S.sf, dm = S.dm, Mf = S.Mf;
+        double cc[P + 2], gq[P + 2];
+#pragma unroll
+        for (int t = 0; t < P + 2; ++t) cc[t] = ROW[pidx<P>(r0 + t)];
+#pragma unroll
+        for (int t = 0; t < P + 2; ++t) gq[t] = A.use_mig ? GV[pidx<P>(r0 + t + 1)] : 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          double Wt = sf - dm * gq[j + 2] + 0.5;
+          double Et = sf + dm * gq[j] + 0.5;
+          if (!A.lf) {
+            Wt -= 0.5;
+            Et -= 0.5;
+          }
+          double val = Et * cc[j] + Mf * cc[j + 1] + Wt * cc[j + 2];
+          if (A.has_rates) val += A.rates[(b * N + k) * (int64_t)ldx + min(r0 + j + 1, nx - 1)] * dt;
+          x[j] = val;
+        }
+        wg_sync<2>();
+      }
+#pragma unroll
+      for (int j = 0; j < P; ++j) ROW[pidx<P>(r0 + j + 1)] = x[j];
+      wg_sync<2>();
+      if (tid == 0) {
+        ROW[pidx<P>(0)] = c0new;
+        ROW[pidx<P>(nx - 1)] = cL;
+      }
+      if (tid < ldx - nx) ROW[pidx<P>(nx + tid)] = 0.0;
+      wg_sync<2>();
+      const double qe = S.qe;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int sl = min(pair_slot<P>(ls2, WY * it), RB - 4);
+        d2 t;
+        t.x = ROW[sl];
+        t.y = ROW[sl + PAIR_STEP<P>];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), rs, tid * 16 + it * (1024 * WY), 0, 0);
+        accp[it].x = __builtin_fma(-t.x, qe, accp[it].x);
+        accp[it].y = __builtin_fma(-t.y, qe, accp[it].y);
+        const bool inrow = 2 * tid + 128 * WY * it < ldx;
+        const double sx = inrow ? t.x : 0.0, sy = inrow ? t.y : 0.0;
+        chk += (sx - sx) + (sy - sy);
+        mn = fmin(mn, fmin(sx, sy));
+      }
+      wg_sync<2>();
+    }
+    // ---- 3. charge row of the new state --------------------------------------------------------------
+    {
+      const __amdgpu_buffer_rsrc_t rs = row_rsrc(lout, ldx);
+#pragma unroll
+      for (int it = 0; it < IT; ++it)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, accp[it]), rs, tid * 16 + it * (1024 * WY), 0, 0);
+    }
+    double* tmp = lin;
+    lin = lout;
+    lout = tmp;
+    if (step + 1 < A.nsteps) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+  const unsigned long long nan_mask = __ballot(chk != chk);
+  const unsigned long long neg_mask = __ballot(mn < 0.0);
+  if (lane == 0) {
+    int st = PNP_STATUS_OK;
+    if (neg_mask) st = PNP_STATUS_NEGATIVE;
+    if (nan_mask) st = PNP_STATUS_NAN;
+    if (st) atomicMax(&A.status[b], st);
+  }
+}
+
+// read-back of v / grad_v for the multi-wave grid sizes
+template <int P, int WY>
+__global__ __launch_bounds__(64 * WY, 1) void poisson_kernel_mw(const DevArgs A, const double* __restrict__ lapl,
+                                                               double* __restrict__ v, double* __restrict__ gradv) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int RB = rowbuf_mw_doubles<P, WY>();
+  constexpr int IT = P / 2 + 1;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = blockIdx.x;
+  const int ldx = A.ldx, nx = A.nx;
+  double* LV = lds;
+  double* GV = lds + RB;
+  double* VV = lds + 2 * RB;
+  double* XCH = lds + 3 * RB;
+  double* strip_w = XCH + xch_doubles<WY>() + wave * 256;
+  double* scal = XCH + xch_doubles<WY>() + WY * 256;
+  for (int i = tid; i < 3 * RB + xch_doubles<WY>() + WY * 256 + WY + 2; i += 64 * WY) lds[i] = 0.0;
+  wg_sync<2>();
+  const int ls2 = pidx<P>(2 * tid);
+  const __amdgpu_buffer_rsrc_t rl = row_rsrc(lapl + b * (int64_t)ldx, ldx);
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const d2 t = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rl, tid * 16 + it * (1024 * WY), 0, 0));
+    LV[pair_slot<P>(ls2, WY * it)] = t.x;
+    LV[pair_slot<P>(ls2, WY * it) + PAIR_STEP<P>] = t.y;
+  }
+  wg_sync<2>();
+  poisson_wg<P, WY, true, 0>(A, LV, GV, VV, strip_w, scal, A.pb[b * 4 + 0], A.pb[b * 4 + 1], A.pb[b * 4 + 2], A.pb[b * 4 + 3],
+                             lane, wave);
+  if (tid < ldx - nx) {
+    VV[pidx<P>(nx + tid)] = 0.0;
+    GV[pidx<P>(nx + tid)] = 0.0;
+  }
+  wg_sync<2>();
+  const __amdgpu_buffer_rsrc_t rv = row_rsrc(v + b * (int64_t)ldx, ldx), rg = row_rsrc(gradv + b * (int64_t)ldx, ldx);
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int sl = min(pair_slot<P>(ls2, WY * it), RB - 4);
+    d2 t;
+    t.x = VV[sl];
+    t.y = VV[sl + PAIR_STEP<P>];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), rv, tid * 16 + it * (1024 * WY), 0, 0);
+    t.x = GV[sl];
+    t.y = GV[sl + PAIR_STEP<P>];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), rg, tid * 16 + it * (1024 * WY), 0, 0);
+  }
+}
+
 // stand-alone Poisson (read-back of tp.potential / tp.efield): one wave per lane of the batch
 template <int P>
 __global__ __launch_bounds__(64) void poisson_kernel(const DevArgs A, const double* __restrict__ lapl,
@@ -1305,7 +1764,44 @@ int points_per_lane(int nx) {
   for (int P : {1, 2, 4, 8, 16}) {
     if (m <= 64 * P) return P;
   }
+  if (m <= 64 * 16 * 4) return 16;   // several waves per system (waves_per_system)
   return 0;
+}
+
+int waves_per_system(int nx) {
+  const int m = nx - 2;
+  if (m <= 64 * 16) return 1;
+  return m <= 64 * 16 * 2 ? 2 : 4;
+}
+
+template <int WY>
+static size_t mw_lds_bytes() {
+  return (size_t)(3 * rowbuf_mw_doubles<16, WY>() + xch_doubles<WY>() + WY * 256 + WY + 2) * sizeof(double);
+}
+
+hipError_t launch_step_mw(const DevArgs& a, hipStream_t stream) {
+  const dim3 grid((unsigned)a.B);
+  static bool attr_set = false;
+  if (!attr_set) {   // more than the default 64 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)step_kernel_mw<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mw_lds_bytes<2>());
+    (void)hipFuncSetAttribute((const void*)step_kernel_mw<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mw_lds_bytes<4>());
+    (void)hipFuncSetAttribute((const void*)poisson_kernel_mw<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mw_lds_bytes<2>());
+    (void)hipFuncSetAttribute((const void*)poisson_kernel_mw<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mw_lds_bytes<4>());
+    attr_set = true;
+  }
+  if (waves_per_system(a.nx) == 2) hipLaunchKernelGGL((step_kernel_mw<16, 2>), grid, dim3(128), mw_lds_bytes<2>(), stream, a);
+  else hipLaunchKernelGGL((step_kernel_mw<16, 4>), grid, dim3(256), mw_lds_bytes<4>(), stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_poisson_mw(const DevArgs& a, const double* lapl, double* v, double* gradv, hipStream_t stream) {
+  const dim3 grid((unsigned)a.B);
+  (void)launch_step_mw;   // attributes are set by the first step launch; set them here too for read-back-first use
+  (void)hipFuncSetAttribute((const void*)poisson_kernel_mw<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mw_lds_bytes<2>());
+  (void)hipFuncSetAttribute((const void*)poisson_kernel_mw<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mw_lds_bytes<4>());
+  if (waves_per_system(a.nx) == 2) hipLaunchKernelGGL((poisson_kernel_mw<16, 2>), grid, dim3(128), mw_lds_bytes<2>(), stream, a, lapl, v, gradv);
+  else hipLaunchKernelGGL((poisson_kernel_mw<16, 4>), grid, dim3(256), mw_lds_bytes<4>(), stream, a, lapl, v, gradv);
+  return hipGetLastError();
 }
 
 void choose_step_config(int N, int64_t B, int P, int* W, int* G) {
@@ -1406,6 +1902,7 @@ hipError_t launch_step(const DevArgs& a, int W, int G, hipStream_t stream) {
 }
 
 hipError_t launch_poisson(const DevArgs& a, const double* lapl, double* v, double* gradv, hipStream_t stream) {
+  if (waves_per_system(a.nx) > 1) return launch_poisson_mw(a, lapl, v, gradv, stream);
   const int P = points_per_lane(a.nx);
   const dim3 grid((unsigned)a.B), block(64);
   switch (P) {

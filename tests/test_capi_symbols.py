@@ -46,7 +46,7 @@ def test_create_rejects_bad_config_without_gpu(lib):
     from catint_amd import _capi
     L = _capi.load_library()
     h = ctypes.c_void_p()
-    cfg = _capi.PnpConfig(ctypes.sizeof(_capi.PnpConfig), 0, 3, 2000, 0, 0, 0, 1, 4, 1e-10, 1e-12, 4e-4, 7e-10)
+    cfg = _capi.PnpConfig(ctypes.sizeof(_capi.PnpConfig), 0, 3, 5000, 0, 0, 0, 1, 4, 1e-10, 1e-12, 4e-4, 7e-10)
     assert L.pnp_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b'nx' in L.pnp_last_error(None)
     cfg = _capi.PnpConfig(ctypes.sizeof(_capi.PnpConfig), 0, 3, 100, 7, 0, 0, 1, 4, 1e-10, 1e-12, 4e-4, 7e-10)

@@ -66,9 +66,10 @@ def test_config4_shape_lanes():
     assert relerr(c, ref) < RTOL and relerr(v, rv) < RTOL and relerr(g, rg) < RTOL
 
 
-@pytest.mark.parametrize('nx', [5, 6, 66, 67, 130, 131, 258, 259, 513, 514, 515, 1025, 1026])
+@pytest.mark.parametrize('nx', [5, 6, 66, 67, 130, 131, 258, 259, 513, 514, 515, 1025, 1026, 1027, 2050, 2051, 4096, 4098])
 def test_ragged_grid_sizes(nx):
-    """every points-per-lane instantiation at its edges, incl. the reference's odd mesh sizes (513, 1025)"""
+    """every points-per-lane instantiation at its edges, incl. the reference's odd mesh sizes (513, 1025) and the
+    grids that span 2 and 4 waves per system (up to BASELINE configs[4]'s 4096 points)"""
     B, N = 5, 2
     p, c0, pb, vz, fl = make_batch(B, N, nx, seed=nx, phi_max=0.02, dt_factor=1e-4)
     rng = np.random.default_rng(nx)
@@ -87,7 +88,7 @@ def test_ragged_grid_sizes(nx):
 
 def test_limits_and_errors():
     p, c0, pb, vz, fl = make_batch(2, 2, 64)
-    for bad_nx in (4, 1027, 4096):
+    for bad_nx in (4, 4099, 100000):
         with pytest.raises(PnpError):
             PnpSolver(2, bad_nx, p.dx, p.dt, p.beta, p.eps, p.D, p.charges)
     with pytest.raises(PnpError):
@@ -114,3 +115,27 @@ def test_status_flags_nan_and_negative():
         c = s.get_state(potential=False)
     assert st[0] == 0 and st[3] == 0 and st[1] == 2 and st[2] == 3
     assert np.isfinite(c[0]).all() and np.isfinite(c[3]).all()   # no cross-lane contamination
+
+
+def test_config5_shape_lanes_all_poisson_branches():
+    """8 species, 4096 grid points (BASELINE configs[4] per-lane shape; 4 waves per system), every Poisson
+    boundary combination of the reference (calculator_old.py:776-803)."""
+    B, N, nx = 6, 8, 4096
+    p, c0, pb, vz, fl = make_batch(B, N, nx, seed=11, phi_max=0.02, dt_factor=1e-4)
+    rng = np.random.default_rng(3)
+    c0 = c0 * (1 + 0.02 * rng.uniform(-1, 1, c0.shape))     # non-neutral start so the prefix branches are not trivial
+    combos = {
+        'dd': [0.01, 0.0, np.nan, np.nan], 'vwall_gbulk': [0.01, np.nan, np.nan, 0.0],
+        'gwall_vbulk': [np.nan, 0.0, 1e5, np.nan], 'vwall_gwall': [0.01, np.nan, 1e5, np.nan],
+        'vbulk_gbulk': [np.nan, 0.0, np.nan, -1e5],
+    }
+    for name, row in combos.items():
+        pbm = np.repeat(np.array([row]), B, axis=0)
+        p.pb = pbm[0].copy()
+        with solver_from_problem(p, 'Crank-Nicolson', batch_capacity=B) as s:
+            s.set_batch(c0, pbm, vz, fl)
+            s.step(5)
+            c, v, g, l = s.get_state()
+        ref, (rv, rg, rl) = oracle_steps(p, 'Crank-Nicolson', c0, pbm, vz, fl, 5)
+        assert relerr(c, ref) < RTOL, name
+        assert relerr(v, rv) < RTOL and relerr(g, rg) < RTOL and relerr(l, rl) < RTOL, name
