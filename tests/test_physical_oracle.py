@@ -1,0 +1,189 @@
+"""Known-answer tests that pin the physical-mode CPU oracle (oracle/pnp_physical.py).
+
+The reference delegates this solve to COMSOL (catint/comsol_wrapper.py:145,158) and holds no fixtures for it, so parity
+with the reference is UNPINNED; what the reference does carry are analytic answers, used here:
+Gouy-Chapman (catint/transport.py:1373-1383), Boltzmann profiles (:1325-1346), the Debye length (:439-443).
+"""
+import numpy as np
+import pytest
+
+from oracle import pnp_physical as PH
+
+F = 96485.33289
+RGAS = 8.3144598
+T = 298.14
+EPS = 78.36 * 8.854187817e-12
+BETA = 1.0 / (RGAS * T)
+
+
+def debye(cb, q):
+    return np.sqrt(EPS / BETA / (q ** 2 * cb).sum())
+
+
+def binary(phiM, ppl=8, ncell=30, cb=10.0, **kw):
+    cbv = np.array([cb, cb])
+    q = np.array([F, -F])
+    lam = debye(cbv, q)
+    nx = ncell * ppl + 1
+    dx = ncell * lam / (nx - 1)
+    p = PH.PhysicalProblem(D=[1.957e-9, 1.185e-9], charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=cbv, phiM=phiM, **kw)
+    c0 = np.repeat(cbv[:, None], nx, axis=1)
+    return p, c0, np.zeros(nx), lam
+
+
+def test_bernoulli_series_matches_closed_form():
+    u = np.array([-0.0499999, -1e-3, 0.0, 1e-9, 0.04999, 0.0500001, -0.0500001, 3.0, -40.0, 800.0])
+    B, dB = PH.bernoulli(u)
+    import mpmath as mp
+    mp.mp.dps = 60
+    for ui, Bi, dBi in zip(u, B, dB):
+        x = mp.mpf(float(ui))
+        Bx = mp.mpf(1) if x == 0 else x / mp.expm1(x)
+        dBx = mp.mpf(-0.5) if x == 0 else (mp.expm1(x) - x * mp.exp(x)) / mp.expm1(x) ** 2
+        assert abs(Bi - float(Bx)) <= 4e-16 * max(1.0, abs(float(Bx)))
+        assert abs(dBi - float(dBx)) <= 2e-14 * max(1.0, abs(float(dBx)))
+
+
+def test_jacobian_matches_finite_differences():
+    rng = np.random.default_rng(0)
+    nx, nb = 12, 4
+    p = PH.PhysicalProblem(D=[1.957e-9, 1.185e-9, 1e-9], charges=[F, -F, 0.0], beta=BETA, eps=EPS, dx=3e-10, nx=nx,
+                           c_bulk=[10, 10, 5], phiM=0.1, flux=[1e-4, 0, -1e-4], stern_capacitance=0.2,
+                           mpb_radius=[4e-10, 3e-10, 0],
+                           reactions=[{'lhs': [0, 1], 'rhs': [2], 'kf': 3e3, 'kr': 2e4},
+                                      {'lhs': [2, 2], 'rhs': [0], 'kf': 1e2, 'kr': 5e2}])
+    c = rng.uniform(1, 20, (3, nx)); phi = rng.uniform(-0.05, 0.1, nx); co = rng.uniform(1, 20, (3, nx))
+    dt = 1e-9
+    _, L, M, U = PH.residual_and_jacobian(p, c, phi, co, dt)
+    J = np.zeros((nx * nb, nx * nb))
+    for i in range(nx):
+        for blk, o in ((L, -1), (M, 0), (U, 1)):
+            if 0 <= i + o < nx:
+                J[i * nb:(i + 1) * nb, (i + o) * nb:(i + o + 1) * nb] = blk[i]
+    x0 = np.concatenate([c, phi[None]], 0)
+    Jfd = np.zeros_like(J)
+    for j in range(nx):
+        for s in range(nb):
+            h = 1e-5 * max(abs(x0[s, j]), 1e-3)
+            xp = x0.copy(); xp[s, j] += h
+            xm = x0.copy(); xm[s, j] -= h
+            Jfd[:, j * nb + s] = ((PH.residual(p, xp[:3], xp[3], co, dt) - PH.residual(p, xm[:3], xm[3], co, dt)) / (2 * h)).T.reshape(-1)
+    assert np.abs(J - Jfd).max() <= 2e-6 * np.abs(Jfd).max()
+    col = np.abs(Jfd).max(axis=0)
+    assert (np.abs(J - Jfd) / col[None, :]).max() < 1e-5
+
+
+def test_block_pcr_mirror_equals_banded_lu():
+    rng = np.random.default_rng(1)
+    p, c0, phi0, lam = binary(0.1, ppl=4, ncell=16)
+    c = c0 * rng.uniform(0.5, 2.0, c0.shape); phi = rng.uniform(-0.1, 0.1, p.nx)
+    F_, L, M, U = PH.residual_and_jacobian(p, c, phi, c0, 1e-8)
+    x1 = PH.solve_block_tridiagonal(L, M, U, -F_)
+    x2 = PH.solve_block_pcr(L, M, U, -F_)
+    assert np.abs(x1 - x2).max() <= 1e-11 * np.abs(x1).max()
+
+
+@pytest.mark.parametrize("phiM", [0.025, -0.1, 0.2])
+def test_stationary_is_boltzmann_and_gouy_chapman(phiM):
+    p, c0, phi0, lam = binary(phiM, ppl=16 if abs(phiM) > 0.1 else 8)
+    c, phi, it, hist = PH.newton_step(p, c0, np.linspace(phiM, 0, p.nx), c0, np.inf, tol=1e-11, maxit=60)
+    assert it <= 12
+    # exponentially fitted fluxes: Boltzmann to rounding on any grid (transport.py:1325-1346)
+    for k in range(2):
+        cb = p.c_bulk[k] * np.exp(-BETA * p.q[k] * phi)
+        assert (np.abs(c[k] - cb) / cb).max() < 1e-11
+    gc = PH.gouy_chapman(np.arange(p.nx) * p.dx, phiM, BETA, F, lam)
+    tol = {0.025: 5e-4, -0.1: 4e-3, 0.2: 2e-2}[phiM]
+    assert np.abs(phi - gc).max() / abs(phiM) < tol
+
+
+def test_second_order_convergence_to_gouy_chapman():
+    errs = []
+    for ppl in (4, 8, 16):
+        p, c0, phi0, lam = binary(0.05, ppl=ppl)
+        c, phi, it, _ = PH.newton_step(p, c0, phi0, c0, np.inf, tol=1e-12)
+        errs.append(np.abs(phi - PH.gouy_chapman(np.arange(p.nx) * p.dx, 0.05, BETA, F, lam)).max())
+    assert errs[0] / errs[1] > 3.5 and errs[1] / errs[2] > 3.5
+
+
+def test_newton_converges_quadratically():
+    p, c0, phi0, lam = binary(0.03)
+    _, _, it, hist = PH.newton_step(p, c0, phi0, c0, np.inf, tol=1e-13, dphi_max=None)
+    h = [x for x in hist if x < 1e-1]
+    assert it <= 7 and any(h[i + 1] < 50 * h[i] ** 2 for i in range(len(h) - 1)) and hist[-1] < 1e-13
+
+
+def test_transient_conserves_mass_and_reaches_the_stationary_state():
+    p, c0, phi0, lam = binary(0.05, ppl=4, ncell=12)
+    dt = 0.2 * lam * (p.nx - 1) * p.dx / p.D.max()
+    c, phi = c0.copy(), phi0.copy()
+    its = []
+    for n in range(120):
+        step = dt if n < 60 else 50 * dt
+        cn, phi, it, _ = PH.newton_step(p, c, phi, c, step, tol=1e-12)
+        # conservative form: the half-cell-weighted mass changes only by what crosses the last edge
+        for k in range(2):
+            mass = lambda a: p.dx * (0.5 * a[k, 0] + a[k, 1:-1].sum())
+            u = p.q[k] * p.beta * (phi[-1] - phi[-2])
+            B, _ = PH.bernoulli(np.array([u]))
+            jhat = -((B[0] + u) * cn[k, -1] - B[0] * cn[k, -2])
+            assert abs((mass(cn) - mass(c)) + jhat * p.D[k] * step / p.dx) < 1e-9 * mass(c)
+        c = cn
+        its.append(it)
+    cs, phis, _, _ = PH.newton_step(p, c0, phi0, c0, np.inf, tol=1e-12)
+    assert max(its) <= 8 and its[-1] <= 3
+    assert np.abs(phi - phis).max() < 1e-6 * abs(p.phiM)
+    assert (np.abs(c - cs) / cs).max() < 1e-5
+
+
+def test_wall_flux_balance_at_steady_state():
+    # neutral species with a wall flux: stationary profile is linear with slope -j/D (flux closure, transport.py:1034-1095)
+    nx = 41
+    p = PH.PhysicalProblem(D=[2e-9, 1e-9], charges=[0.0, 0.0], beta=BETA, eps=EPS, dx=1e-6, nx=nx, c_bulk=[5.0, 1.0],
+                           phiM=0.0, flux=[-1e-4, 1e-4])
+    c0 = np.repeat(p.c_bulk[:, None], nx, axis=1)
+    c, phi, it, _ = PH.newton_step(p, c0, np.zeros(nx), c0, np.inf)
+    x = np.arange(nx) * p.dx
+    for k in range(2):
+        expect = p.c_bulk[k] + p.flux[k] / p.D[k] * (x[-1] - x)
+        assert np.abs(c[k] - expect).max() < 1e-10 * expect.max()
+    assert np.abs(phi).max() < 1e-12
+
+
+def test_stern_layer_and_steric_saturation():
+    a = 4.1e-10
+    cmax = 1.0 / (PH.N_AVOGADRO * a ** 3)
+    p, c0, phi0, lam = binary(-2.0, cb=100.0, stern_capacitance=0.2, mpb_radius=[a, 3.1e-10])
+    c, phi, it, _ = PH.newton_step(p, c0, phi0, c0, np.inf, tol=1e-10, maxit=60)
+    assert it <= 15
+    assert 0.8 * cmax < c[0, 0] < cmax                     # cations crowd at the wall but never exceed 1/(N_A a^3)
+    # Stern Robin condition: eps*E(0) = C_S (phiM - phi(0)) with E from the one-sided difference used in the residual
+    lhs = p.eps * (phi[1] - phi[0]) / p.dx
+    assert abs(lhs + p.CS * (p.phiM - phi[0])) < 1e-9 * abs(lhs)
+    # MPB equilibrium: c_k (1-phi0)^-1 exp(q beta phi) is constant (Bikerman), transport.py:1325-1346 generalised
+    free = 1.0 - (p.vol[:, None] * c).sum(axis=0)
+    for k in range(2):
+        inv = c[k] / free * np.exp(BETA * p.q[k] * phi)
+        assert (np.abs(inv - inv[-1]) / inv[-1]).max() < 1e-9
+
+
+def test_homogeneous_reaction_reaches_mass_action_equilibrium():
+    # A + B <-> C, neutral, no fluxes, bulk not in equilibrium -> interior relaxes towards kf a b = kr c near the wall
+    nx = 201
+    kf, kr = 1e3, 1e2
+    p = PH.PhysicalProblem(D=[1e-9, 1e-9, 1e-9], charges=[0.0, 0.0, 0.0], beta=BETA, eps=EPS, dx=1e-6, nx=nx,
+                           c_bulk=[1.0, 2.0, 0.5], phiM=0.0, reactions=[{'lhs': [0, 1], 'rhs': [2], 'kf': kf, 'kr': kr}])
+    c0 = np.repeat(p.c_bulk[:, None], nx, axis=1)
+    c, phi, it, _ = PH.newton_step(p, c0, np.zeros(nx), c0, np.inf, tol=1e-12)
+    assert it <= 10
+    q = kf * c[0, 0] * c[1, 0] / (kr * c[2, 0])
+    assert abs(q - 1.0) < 1e-6
+    # element conservation with equal D and zero wall flux: a + c and b + c are harmonic -> constant
+    assert np.abs((c[0] + c[2]) - 1.5).max() < 1e-9 and np.abs((c[1] + c[2]) - 2.5).max() < 1e-9
+
+
+def test_unrepresentable_crowding_is_reported_not_nan():
+    a = 4.1e-10
+    p, c0, phi0, lam = binary(-1.0, cb=100.0, mpb_radius=[a, a])       # Dirichlet -1 V at the plane of closest approach
+    c, phi, it, _ = PH.newton_step(p, c0, phi0, c0, np.inf, maxit=40)
+    assert it == 41 and np.all(np.isfinite(c)) and np.all(np.isfinite(phi))
