@@ -19,18 +19,21 @@ PNP_MAX_REACTANTS = 4
 
 METHOD_CRANK_NICOLSON = 0
 METHOD_FTCS = 1
-METHODS = {'Crank-Nicolson': METHOD_CRANK_NICOLSON, 'FTCS': METHOD_FTCS}
+METHOD_NEWTON = 2      # physical mode: fully implicit coupled Newton (what the reference asks COMSOL for)
+METHODS = {'Crank-Nicolson': METHOD_CRANK_NICOLSON, 'FTCS': METHOD_FTCS, 'Newton': METHOD_NEWTON}
+PNP_NEWTON_MAX_SPECIES = 8
 
 PB_DD, PB_VWALL_GBULK, PB_GWALL_VBULK, PB_VWALL_GWALL, PB_VBULK_GBULK = range(5)
 
-STATUS_OK, STATUS_NAN, STATUS_NEGATIVE = 0, 2, 3
+STATUS_OK, STATUS_MAXIT, STATUS_NAN, STATUS_NEGATIVE = 0, 1, 2, 3
 
 # every symbol include/catint_pnp.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     'pnp_create', 'pnp_destroy', 'pnp_last_error', 'pnp_version', 'pnp_set_species', 'pnp_set_reactions',
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
-    'pnp_device_bytes', 'pnp_row_pitch',
+    'pnp_device_bytes', 'pnp_row_pitch', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
+    'pnp_set_potential',
 ]
 
 
@@ -50,6 +53,13 @@ class PnpConfig(C.Structure):
         ('method', C.c_int32), ('pb_mode', C.c_int32), ('lax_friedrich', C.c_int32), ('use_migration', C.c_int32),
         ('batch_capacity', C.c_int64), ('dx', C.c_double), ('dt', C.c_double), ('beta', C.c_double),
         ('eps', C.c_double),
+    ]
+
+
+class PnpNewtonParams(C.Structure):
+    _fields_ = [
+        ('struct_size', C.c_int32), ('wall_bc', C.c_int32), ('maxit', C.c_int32), ('reserved', C.c_int32),
+        ('stern_capacitance', C.c_double), ('phi_pzc', C.c_double), ('tol', C.c_double), ('dphi_max', C.c_double),
     ]
 
 
@@ -91,6 +101,12 @@ def load_library():
     lib.pnp_synchronize.argtypes = [vp]
     lib.pnp_timer_start.argtypes = [vp]
     lib.pnp_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pnp_set_newton.argtypes = [vp, C.POINTER(PnpNewtonParams), dp]
+    lib.pnp_solve_stationary.argtypes = [vp, C.c_double, C.c_int32, ip]
+    lib.pnp_get_newton_iterations.argtypes = [vp, ip]
+    lib.pnp_set_potential.argtypes = [vp, dp]
+    for name in ('pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations', 'pnp_set_potential'):
+        getattr(lib, name).restype = C.c_int
     for name in ('pnp_set_species', 'pnp_set_reactions', 'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step',
                  'pnp_integrate', 'pnp_mol_rhs', 'pnp_get_state', 'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize',
                  'pnp_timer_start', 'pnp_timer_stop'):
@@ -195,6 +211,29 @@ class PnpSolver(object):
     def set_pb(self, pb, vzeta):
         pb = np.nan_to_num(_f64(pb, (self.B, 4)), nan=0.0)
         self._check(self._lib.pnp_set_pb(self._h, _dptr(pb), _dptr(_f64(vzeta, (self.B,)))))
+
+    # -- physical mode ---------------------------------------------------------------------
+    def set_newton(self, wall_bc='dirichlet', stern_capacitance=0.0, phi_pzc=0.0, tol=1e-10, maxit=50, dphi_max=0.05,
+                   mpb_radius=None):
+        """Boundary model and Newton controls of the physical mode (tp.system['Stern capacitance'], ['phiPZC'],
+        tp.species[sp]['MPB_radius']; comsol_model.py:613,:982,:1041-1063)."""
+        p = PnpNewtonParams(C.sizeof(PnpNewtonParams), {'dirichlet': 0, 'stern': 1}[wall_bc], int(maxit), 0,
+                            float(stern_capacitance), float(phi_pzc), float(tol), float(dphi_max))
+        r = None if mpb_radius is None else _f64(mpb_radius, (self.N,))
+        self._check(self._lib.pnp_set_newton(self._h, C.byref(p), _dptr(r)))
+
+    def solve_stationary(self, tol=0.0, maxit=0):
+        st = np.zeros(self.B, np.int32)
+        self._check(self._lib.pnp_solve_stationary(self._h, float(tol), int(maxit), _iptr(st)))
+        return st
+
+    def newton_iterations(self):
+        it = np.zeros(self.B, np.int32)
+        self._check(self._lib.pnp_get_newton_iterations(self._h, _iptr(it)))
+        return it
+
+    def set_potential(self, phi):
+        self._check(self._lib.pnp_set_potential(self._h, _dptr(_f64(phi, (self.B, self.nx)))))
 
     # -- hot path --------------------------------------------------------------------------
     def step(self, nsteps=1, steps_per_launch=0):

@@ -32,6 +32,15 @@ struct pnp_handle {
   int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
   int kernel_override = 0;   // CATINT_PNP_KERNEL = 2 (LDS-staged step_kernel) | 4 (register-resident step_kernel_rr)
   int32_t* status = nullptr;
+  // physical mode (PNP_METHOD_NEWTON)
+  bool newton = false;
+  pnp_newton_params np;
+  double Dk[PNP_NEWTON_MAX_SPECIES] = {0}, qk[PNP_NEWTON_MAX_SPECIES] = {0}, volk[PNP_NEWTON_MAX_SPECIES] = {0};
+  bool mpb = false;
+  double* c_old = nullptr;
+  double* work = nullptr;
+  int32_t* iters = nullptr;
+  int nw_blocks = 0;
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
   int64_t dev_bytes = 0;
   std::string err;
@@ -72,7 +81,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -87,10 +96,16 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
     return fail(nullptr, PNP_EINVAL, "pnp_create: pnp_config.struct_size mismatch (ABI)");
   if (cfg->nspecies < 1 || cfg->nspecies > PNP_MAX_SPECIES)
     return fail(nullptr, PNP_EINVAL, "pnp_create: nspecies out of range [1,16]");
-  const int P = points_per_lane(cfg->nx);
+  const bool newton = cfg->method == PNP_METHOD_NEWTON;
+  const int P = newton ? 1 : points_per_lane(cfg->nx);
   if (P == 0)
     return fail(nullptr, PNP_EINVAL, "pnp_create: nx must be in [5, 4098] (<=16 points per lane, <=4 waves per system)");
-  if (cfg->method != PNP_METHOD_CRANK_NICOLSON && cfg->method != PNP_METHOD_FTCS)
+  if (newton && (cfg->nx < 3 || cfg->nx > 8192)) return fail(nullptr, PNP_EINVAL, "pnp_create: physical mode needs nx in [3, 8192]");
+  if (newton && cfg->nspecies > PNP_NEWTON_MAX_SPECIES)
+    return fail(nullptr, PNP_EINVAL, "pnp_create: physical mode supports at most 8 species");
+  if (newton && cfg->pb_mode != PNP_PB_DD)
+    return fail(nullptr, PNP_EINVAL, "pnp_create: physical mode takes the wall and bulk potentials (PNP_PB_DD)");
+  if (cfg->method != PNP_METHOD_CRANK_NICOLSON && cfg->method != PNP_METHOD_FTCS && !newton)
     return fail(nullptr, PNP_EINVAL, "pnp_create: no calculator found with this method");  // calculator_old.py:109-111
   if (cfg->pb_mode < PNP_PB_DD || cfg->pb_mode > PNP_PB_VBULK_GBULK)
     return fail(nullptr, PNP_EINVAL, "pnp_create: unsupported pb_bound combination");
@@ -109,6 +124,12 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   pnp_handle* h = new pnp_handle();
   h->cfg = *cfg;
   h->P = P;
+  h->newton = newton;
+  memset(&h->np, 0, sizeof(h->np));
+  h->np.struct_size = (int32_t)sizeof(pnp_newton_params);
+  h->np.maxit = 50;       // COMSOL maxiter, comsol_model.py:465-516
+  h->np.tol = 1e-10;
+  h->np.dphi_max = 0.05;
   memset(&h->a, 0, sizeof(DevArgs));
   memset(&h->rt, 0, sizeof(ReactionTable));
   auto bail = [&](int code) {
@@ -132,8 +153,25 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   const int N = cfg->nspecies;
   const int ldx = (cfg->nx + 15) / 16 * 16;
   HIP_TRYC(dev_alloc(h, &h->c, (size_t)Bc * N * ldx));
-  HIP_TRYC(dev_alloc(h, &h->lapl[0], (size_t)Bc * ldx));
-  HIP_TRYC(dev_alloc(h, &h->lapl[1], (size_t)Bc * ldx));
+  if (!newton) {
+    HIP_TRYC(dev_alloc(h, &h->lapl[0], (size_t)Bc * ldx));
+    HIP_TRYC(dev_alloc(h, &h->lapl[1], (size_t)Bc * ldx));
+  } else {
+    HIP_TRYC(dev_alloc(h, &h->c_old, (size_t)Bc * N * ldx));
+    HIP_TRYC(dev_alloc(h, &h->v, (size_t)Bc * ldx));
+    HIP_TRYC(dev_alloc(h, &h->iters, (size_t)Bc));
+    const int nb = N + 1;
+    if (!newton_exchange_in_lds(nb, cfg->nx)) {
+      const size_t slice = newton_exchange_doubles(nb, cfg->nx);
+      int64_t blocks = Bc < 1024 ? Bc : 1024;
+      const int64_t cap = (int64_t)((size_t)4 << 30) / (int64_t)(slice * sizeof(double));
+      if (blocks > cap) blocks = cap < 1 ? 1 : cap;
+      h->nw_blocks = (int)blocks;
+      HIP_TRYC(dev_alloc(h, &h->work, slice * (size_t)blocks));
+    } else {
+      h->nw_blocks = (int)(Bc < 4096 ? Bc : 4096);
+    }
+  }
   HIP_TRYC(dev_alloc(h, &h->pb, (size_t)Bc * 4));
   HIP_TRYC(dev_alloc(h, &h->vzeta, (size_t)Bc));
   HIP_TRYC(dev_alloc(h, &h->flux, (size_t)Bc * N));
@@ -180,6 +218,11 @@ int pnp_set_species(pnp_handle* h, const double* D, const double* charges) {
   const double dx = h->a.dx, dt = h->a.dt, beta = h->a.beta, eps = h->a.eps;
   for (int k = 0; k < h->a.N; ++k) {
     if (!(D[k] >= 0) || !std::isfinite(charges[k])) return fail(h, PNP_EINVAL, "pnp_set_species: bad D or charge");
+    if (h->newton) {
+      if (!(D[k] > 0)) return fail(h, PNP_EINVAL, "pnp_set_species: physical mode needs D > 0");
+      h->Dk[k] = D[k];
+      h->qk[k] = charges[k];
+    }
     SpecConst& S = sc[k];
     S.D = D[k];
     S.q = charges[k];
@@ -213,6 +256,8 @@ int pnp_set_reactions(pnp_handle* h, int32_t nreactions, const int32_t* n_lhs, c
                       const int32_t* rhs, const double* kf, const double* kr) {
   if (!h) return PNP_EINVAL;
   if (nreactions < 0 || nreactions > PNP_MAX_REACTIONS) return fail(h, PNP_EINVAL, "pnp_set_reactions: too many reactions");
+  if (nreactions > 0 && h->newton)
+    return fail(h, PNP_EINVAL, "pnp_set_reactions: homogeneous reactions are not implemented in the physical mode yet");
   if (nreactions > 0 && h->cfg.method != PNP_METHOD_FTCS)
     return fail(h, PNP_EINVAL, "pnp_set_reactions: only FTCS has a rate term (calculator_old.py:1022; CN has none)");
   ReactionTable& rt = h->rt;
@@ -284,6 +329,18 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   HIP_TRY(h, hipMemcpy2DAsync(h->cbulk, sizeof(double), c0 + (nx - 1), (size_t)nx * sizeof(double), sizeof(double), (size_t)B * N,
                               hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->status, 0, (size_t)B * sizeof(int32_t), h->stream));
+  if (h->newton) {
+    // initial guess of the potential: the bulk value everywhere (field-free electrolyte, c = c_bulk; comsol_model.py:744)
+    std::vector<double> phi0((size_t)B * ldx, 0.0);
+    for (int64_t b = 0; b < B; ++b)
+      for (int i = 0; i < nx; ++i) phi0[(size_t)b * ldx + i] = pb[b * 4 + 1];
+    HIP_TRY(h, hipMemcpyAsync(h->v, phi0.data(), phi0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->iters, 0, (size_t)B * sizeof(int32_t), h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_batch = true;
+    h->steps_done = 0;
+    return PNP_OK;
+  }
   HIP_TRY(h, hipMemsetAsync(h->lapl[1], 0, (size_t)B * ldx * sizeof(double), h->stream));
   h->cur = 0;
   HIP_TRY(h, launch_charge_row(h->a, h->lapl[0], h->stream));
@@ -338,11 +395,111 @@ static int run_steps(pnp_handle* h, int nsteps) {
   return PNP_OK;
 }
 
+// physical mode: nsteps backward-Euler steps (stationary: one solve with 1/dt = 0) in one launch
+static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, int maxit) {
+  NewtonArgs a;
+  memset(&a, 0, sizeof(a));
+  const int N = h->a.N, nx = h->a.nx;
+  const double dx = h->a.dx, dt = h->a.dt, beta = h->a.beta, eps = h->a.eps;
+  a.N = N;
+  a.nx = nx;
+  a.ldx = h->a.ldx;
+  a.nsteps = nsteps;
+  a.maxit = maxit > 0 ? maxit : h->np.maxit;
+  a.wall_bc = h->np.wall_bc;
+  a.mpb = h->mpb ? 1 : 0;
+  a.RS = (nx + 15) / 16 * 16;
+  a.B = h->B;
+  a.work = h->work;
+  a.work_stride = (int64_t)newton_exchange_doubles(N + 1, nx);
+  a.tol = tol > 0 ? tol : h->np.tol;
+  a.dphi_max = h->np.dphi_max;
+  a.stern = dx * h->np.stern_capacitance / eps;
+  a.phi_pzc = h->np.phi_pzc;
+  double qmax = 1.0;
+  for (int k = 0; k < N; ++k) {
+    a.qb[k] = h->qk[k] * beta;
+    a.sig[k] = stationary ? 0.0 : dx * dx / (h->Dk[k] * dt);
+    a.fl[k] = dx / h->Dk[k];
+    a.peq[k] = dx * dx / eps * h->qk[k];
+    a.vol[k] = h->volk[k];
+    if (fabs(h->qk[k]) > qmax) qmax = fabs(h->qk[k]);
+  }
+  a.vt_inv = beta * qmax;
+  a.c = h->c;
+  a.c_old = h->c_old;
+  a.phi = h->v;
+  a.pb = h->pb;
+  a.flux = h->flux;
+  a.cbulk = h->cbulk;
+  a.status = h->status;
+  a.iters = h->iters;
+  int blocks = h->nw_blocks;
+  if ((int64_t)blocks > h->B) blocks = (int)h->B;
+  HIP_TRY(h, launch_newton(a, blocks, h->stream));
+  h->steps_done += nsteps;
+  return PNP_OK;
+}
+
+int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_radius) {
+  if (!h || !p) return fail(h, PNP_EINVAL, "pnp_set_newton: null argument");
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_set_newton: the handle was not created with PNP_METHOD_NEWTON");
+  if (p->struct_size != (int32_t)sizeof(pnp_newton_params)) return fail(h, PNP_EINVAL, "pnp_set_newton: struct_size mismatch (ABI)");
+  if (p->wall_bc != 0 && p->wall_bc != 1) return fail(h, PNP_EINVAL, "pnp_set_newton: wall_bc must be 0 (Dirichlet) or 1 (Stern)");
+  if (p->wall_bc == 1 && !(p->stern_capacitance > 0)) return fail(h, PNP_EINVAL, "pnp_set_newton: Stern capacitance must be positive");
+  if (p->maxit < 1 || !(p->tol > 0)) return fail(h, PNP_EINVAL, "pnp_set_newton: maxit >= 1 and tol > 0 required");
+  h->np = *p;
+  h->mpb = false;
+  for (int k = 0; k < h->a.N; ++k) {
+    const double a = mpb_radius ? mpb_radius[k] : 0.0;
+    if (!(a >= 0)) return fail(h, PNP_EINVAL, "pnp_set_newton: negative MPB radius");
+    h->volk[k] = 6.022140857e23 * a * a * a;       // unit_NA, catint/units.py
+    if (h->volk[k] != 0.0) h->mpb = true;
+  }
+  return PNP_OK;
+}
+
+int pnp_solve_stationary(pnp_handle* h, double tol, int32_t maxit, int32_t* status) {
+  if (!h) return PNP_EINVAL;
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_solve_stationary: the handle was not created with PNP_METHOD_NEWTON");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_solve_stationary: call pnp_set_batch first");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int rc = run_newton(h, 1, true, tol, maxit);
+  if (rc != PNP_OK) return rc;
+  if (status) return pnp_get_status(h, status);
+  return PNP_OK;
+}
+
+int pnp_get_newton_iterations(pnp_handle* h, int32_t* iters) {
+  if (!h || !iters) return fail(h, PNP_EINVAL, "pnp_get_newton_iterations: null argument");
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_get_newton_iterations: the handle was not created with PNP_METHOD_NEWTON");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_get_newton_iterations: call pnp_set_batch first");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(iters, h->iters, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
+int pnp_set_potential(pnp_handle* h, const double* phi) {
+  if (!h || !phi) return fail(h, PNP_EINVAL, "pnp_set_potential: null argument");
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_set_potential: the handle was not created with PNP_METHOD_NEWTON");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_set_potential: call pnp_set_batch first");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const size_t w = (size_t)h->a.nx * sizeof(double), dp = (size_t)h->a.ldx * sizeof(double);
+  HIP_TRY(h, hipMemcpy2DAsync(h->v, dp, phi, w, w, (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
 int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch) {
   if (!h) return PNP_EINVAL;
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_step: call pnp_set_batch first");
   if (nsteps < 0) return fail(h, PNP_EINVAL, "pnp_step: nsteps < 0");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (h->newton) {
+    if (nsteps == 0) return PNP_OK;
+    return run_newton(h, nsteps, false, 0.0, 0);
+  }
   int spl = steps_per_launch <= 0 ? 64 : steps_per_launch;
   if (h->a.has_rates) spl = 1;
   int left = nsteps;
@@ -363,7 +520,8 @@ int pnp_integrate(pnp_handle* h, int32_t nt, const int32_t* itout, int32_t n_out
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
   const int64_t B = h->B;
   // CN: for n in range(1,nt) (calculator_old.py:512);  FTCS: for n in range(0,nt) (:990)
-  const int n_first = (h->cfg.method == PNP_METHOD_CRANK_NICOLSON) ? 1 : 0;
+  // physical mode: the state after n backward-Euler steps is t_n, like CN
+  const int n_first = (h->cfg.method == PNP_METHOD_FTCS) ? 0 : 1;
   int n = n_first;  // index of the next loop pass to run
   for (int io = 0; io <= n_out; ++io) {
     int target;  // run passes n .. target (inclusive)
@@ -404,6 +562,7 @@ static int ensure_potential_buffers(pnp_handle* h) {
 
 int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
   if (!h || !c || !dcdt) return fail(h, PNP_EINVAL, "pnp_mol_rhs: null argument");
+  if (h->newton) return fail(h, PNP_EINVAL, "pnp_mol_rhs: not part of the physical mode");
   if (waves_per_system(h->a.nx) > 1) return fail(h, PNP_EINVAL, "pnp_mol_rhs: nx > 1026 is not supported by the method-of-lines RHS");
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_mol_rhs: call pnp_set_batch first");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -436,6 +595,37 @@ int pnp_get_state(pnp_handle* h, double* c, double* v, double* grad_v, double* l
   const int64_t B = h->B;
   const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
   if (c) HIP_TRY(h, hipMemcpy2DAsync(c, w, h->c, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, h->stream));
+  if (h->newton) {
+    // the potential is part of the state; its gradient (centred, one-sided at the ends) and -rho/eps are derived here
+    std::vector<double> ph, cc;
+    if (v || grad_v) {
+      ph.resize((size_t)B * nx);
+      HIP_TRY(h, hipMemcpy2DAsync(ph.data(), w, h->v, dp, w, (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (lapl_v) {
+      cc.resize((size_t)B * N * nx);
+      HIP_TRY(h, hipMemcpy2DAsync(cc.data(), w, h->c, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const double dx = h->a.dx;
+    for (int64_t b = 0; b < B; ++b) {
+      if (v) memcpy(v + (size_t)b * nx, ph.data() + (size_t)b * nx, w);
+      if (grad_v) {
+        const double* p = ph.data() + (size_t)b * nx;
+        double* g = grad_v + (size_t)b * nx;
+        for (int i = 1; i < nx - 1; ++i) g[i] = (p[i + 1] - p[i - 1]) / (2 * dx);
+        g[0] = (p[1] - p[0]) / dx;
+        g[nx - 1] = (p[nx - 1] - p[nx - 2]) / dx;
+      }
+      if (lapl_v)
+        for (int i = 0; i < nx; ++i) {
+          double rho = 0;
+          for (int k = 0; k < N; ++k) rho += h->qk[k] * cc[((size_t)b * N + k) * nx + i];
+          lapl_v[(size_t)b * nx + i] = -rho / h->a.eps;
+        }
+    }
+    return PNP_OK;
+  }
   // Poisson solve of the most recent step used the lagged row; before any step it is the initial row
   const double* lagged = (h->steps_done > 0) ? h->lapl[1 - h->cur] : h->lapl[h->cur];
   if (v || grad_v) {
@@ -459,6 +649,17 @@ int pnp_get_surface(pnp_handle* h, double* csurf, double* vsurf, double* esurf) 
   if (csurf) {
     HIP_TRY(h, launch_surface(h->a, h->csurf, h->stream));
     HIP_TRY(h, hipMemcpyAsync(csurf, h->csurf, (size_t)B * h->a.N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  if (h->newton && (vsurf || esurf)) {
+    std::vector<double> p01((size_t)B * 2);
+    HIP_TRY(h, hipMemcpy2DAsync(p01.data(), 2 * sizeof(double), h->v, (size_t)ldx * sizeof(double), 2 * sizeof(double), (size_t)B,
+                                hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int64_t b = 0; b < B; ++b) {
+      if (vsurf) vsurf[b] = p01[2 * b];
+      if (esurf) esurf[b] = -(p01[2 * b + 1] - p01[2 * b]) / h->a.dx;   // the one-sided field of the Stern condition
+    }
+    return PNP_OK;
   }
   if (vsurf || esurf) {
     const int rc = ensure_potential_buffers(h);

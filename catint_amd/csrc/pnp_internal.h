@@ -95,4 +95,34 @@ hipError_t launch_mol_rhs(const DevArgs& a, const double* y, double* dydt, hipSt
 // surface gather: csurf[B][N] = c[b][k][0]
 hipError_t launch_surface(const DevArgs& a, double* csurf, hipStream_t stream);
 
+// ---- physical mode (pnp_newton.hip): fully implicit coupled Newton, block-tridiagonal PCR ------------------------
+struct NewtonArgs {
+  int32_t N, nx, ldx, nsteps;
+  int32_t maxit, wall_bc, mpb, RS;       // RS: row stride of the element-major PCR buffers
+  int64_t B;
+  int64_t work_stride;                   // doubles per workgroup in `work`
+  double tol, dphi_max;
+  double stern;                          // dx*C_S/eps              (Stern Robin wall, comsol_model.py:613,:982)
+  double phi_pzc;
+  double vt_inv;                         // beta*max(|q|max, 1): 1/thermal voltage of the highest valence
+  double qb[PNP_NEWTON_MAX_SPECIES];     // q_k*beta
+  double sig[PNP_NEWTON_MAX_SPECIES];    // dx^2/(D_k dt), 0 for the stationary problem
+  double fl[PNP_NEWTON_MAX_SPECIES];     // dx/D_k      (scales the wall flux)
+  double peq[PNP_NEWTON_MAX_SPECIES];    // dx^2/eps*q_k
+  double vol[PNP_NEWTON_MAX_SPECIES];    // N_A a_k^3   (MPB, comsol_model.py:1041-1063)
+  double* c;                             // [B][N][ldx] state = Newton iterate, in place
+  double* c_old;                         // [B][N][ldx] previous time level
+  double* phi;                           // [B][ldx]
+  const double* pb;                      // [B][4]: wall potential phiM, bulk potential
+  const double* flux;                    // [B][N] wall flux INTO the domain
+  const double* cbulk;                   // [B][N]
+  double* work;                          // PCR exchange buffers in device memory, or null -> dynamic LDS
+  int32_t* status;                       // [B]
+  int32_t* iters;                        // [B] Newton iterations spent by this call (maxit+1 for a failed solve)
+};
+int newton_threads(int nb, int nx);
+size_t newton_exchange_doubles(int nb, int nx);
+bool newton_exchange_in_lds(int nb, int nx);
+hipError_t launch_newton(const NewtonArgs& a, int blocks, hipStream_t stream);
+
 }  // namespace pnp

@@ -19,7 +19,7 @@
  *   - the library owns the device buffers and one HIP stream behind the opaque handle; one
  *     handle per GPU; calls on one handle are not thread-safe, distinct handles are independent;
  *   - per-lane `status` replaces Comsol.check_error / the NaN test of calculator.py:409-414:
- *     0 ok, 2 NaN/Inf in the state, 3 negative concentration.
+ *     0 ok, 1 Newton not converged (physical mode), 2 NaN/Inf in the state, 3 negative concentration.
  */
 #ifndef CATINT_PNP_H
 #define CATINT_PNP_H
@@ -44,6 +44,12 @@ extern "C" {
 /* integrator, mirrors the reference's calculator names (calculator_old.py:107, :1121-1140) */
 #define PNP_METHOD_CRANK_NICOLSON 0   /* integrate_Crank_Nicolson, calculator_old.py:457-564 */
 #define PNP_METHOD_FTCS 1             /* integrate_FTCS,           calculator_old.py:976-1029 */
+/* physical mode: what the reference's production path asks COMSOL for (comsol_wrapper.py:145,158; model stated by
+ * comsol_model.py) -- fully implicit coupled Poisson + Nernst-Planck, damped Newton per timestep
+ * (or stationary), block-tridiagonal Jacobian solved by block cyclic reduction.  cfg.pb_mode must be PNP_PB_DD:
+ * pb[b][0] = phiM of lane b, pb[b][1] = bulk potential; cfg.use_migration/lax_friedrich are ignored. */
+#define PNP_METHOD_NEWTON 2
+#define PNP_NEWTON_MAX_SPECIES 8
 
 /* Poisson boundary combination = which two slots of tp.pb_bound are set
  * (transport.py:1296-1311; branches of get_potential_and_gradient calculator_old.py:776-803) */
@@ -55,6 +61,7 @@ extern "C" {
 
 /* lane status */
 #define PNP_STATUS_OK 0
+#define PNP_STATUS_MAXIT 1      /* physical mode: Newton did not reach tol within maxit iterations */
 #define PNP_STATUS_NAN 2
 #define PNP_STATUS_NEGATIVE 3
 
@@ -126,6 +133,30 @@ int pnp_integrate(pnp_handle* h, int32_t nt, const int32_t* itout, int32_t n_out
  * to scipy.integrate.odeint / ode ('odeint','lsoda','dopri5','dop853', calculator_old.py:946-963); the host side
  * (catint_amd/calculator.py) does the same with this entry point.  The state on the device is not touched. */
 int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt);
+
+/* ---- physical mode (PNP_METHOD_NEWTON) -------------------------------------------------------------- */
+typedef struct pnp_newton_params {
+  int32_t struct_size;       /* = sizeof(pnp_newton_params) */
+  int32_t wall_bc;           /* 0: phi(0) = phiM (Dirichlet);  1: Stern layer, eps dphi/dx = -C_S (phiM - phiPZC - phi(0))
+                              *    (comsol_model.py:613, :982; tp.system['Stern capacitance'], ['phiPZC']) */
+  int32_t maxit;             /* Newton iterations per solve (COMSOL maxiter 50, comsol_model.py:465-516) */
+  int32_t reserved;
+  double stern_capacitance;  /* F/m^2 */
+  double phi_pzc;            /* V */
+  double tol;                /* scaled update max(|dc|/(c + c_bulk), |dphi| beta max|q|) < tol on an undamped step */
+  double dphi_max;           /* potential limiting per iteration (V); <= 0 disables */
+} pnp_newton_params;
+/* mpb_radius[N] (m, nullable = point ions): size-modified drift with phi0 = N_A sum a_k^3 c_k
+ * (tp.species[sp]['MPB_radius'], comsol_model.py:1041-1063). */
+int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_radius);
+/* Stationary solve of every lane from the current state as the initial guess (studies=['stat'], transport.py:811-812).
+ * tol/maxit <= 0 keep the values of pnp_set_newton.  status[B] nullable. */
+int pnp_solve_stationary(pnp_handle* h, double tol, int32_t maxit, int32_t* status);
+/* Newton iterations each lane spent in the most recent pnp_step / pnp_solve_stationary call, summed over its
+ * timesteps; a solve that hit maxit counts maxit+1. */
+int pnp_get_newton_iterations(pnp_handle* h, int32_t* iters /* [B] */);
+/* Overwrite the potential rows (initial guess of the physical mode), phi[B][nx]. */
+int pnp_set_potential(pnp_handle* h, const double* phi);
 
 /* ---- read-back ------------------------------------------------------------------------------ */
 /* Any pointer may be NULL. c[B][N][nx]; v, grad_v, lapl_v [B][nx] are the Poisson solve of the

@@ -1,0 +1,151 @@
+"""GPU parity of the physical mode (PNP_METHOD_NEWTON, catint_amd/csrc/pnp_newton.hip) against the CPU oracle
+oracle/pnp_physical.py, through the C-ABI.  The oracle is pinned by analytic known answers (tests/test_physical_oracle.py);
+parity with the reference's COMSOL path itself is unpinned (no fixtures exist).
+
+Tolerance: both sides iterate Newton to a scaled update < 1e-10 with the same damping rules, so the converged states agree
+to ~1e-9 relative whatever the linear solver (LAPACK banded LU on the CPU, block cyclic reduction on the GPU).
+"""
+import numpy as np
+import pytest
+
+from catint_amd import _capi
+from oracle import pnp_physical as PH
+
+pytestmark = pytest.mark.gpu
+
+F = 96485.33289
+BETA = 1.0 / (8.3144598 * 298.14)
+EPS = 78.36 * 8.854187817e-12
+
+SPECIES = [  # (D, z)
+    (1.957e-9, 1), (1.185e-9, -1), (2.032e-9, -1), (1.334e-9, 1), (0.923e-9, -2), (5.273e-9, -1), (2.06e-9, 1), (1.792e-9, -1),
+]
+
+
+def make_lanes(N, nx, B, seed, phi_lo=-0.15, phi_hi=0.15, points_per_debye=6.0, cref=10.0):
+    rng = np.random.default_rng(seed)
+    D = np.array([SPECIES[k][0] for k in range(N)])
+    q = np.array([SPECIES[k][1] * F for k in range(N)])
+    cb = np.exp(rng.uniform(np.log(0.3 * cref), np.log(3 * cref), (B, N)))
+    if N >= 2:  # first species closes charge neutrality (transport.py:757-765); keep it positive by flipping signs if needed
+        rest = (cb[:, 1:] * q[None, 1:]).sum(axis=1)
+        need = -rest / q[0]
+        bad = need <= 0
+        cb[:, 0] = np.where(bad, cb[:, 0], need)
+        # lanes that cannot be neutralised by species 0 get a compensating amount of the first opposite species
+        if np.any(bad):
+            opp = [k for k in range(1, N) if q[k] * q[0] < 0][0]
+            excess = (cb[bad] * q[None, :]).sum(axis=1)
+            cb[bad, opp] += -excess / q[opp]
+            assert np.all(cb[bad, opp] > 0)
+    lam = np.sqrt(EPS / BETA / max((q ** 2 * cref).sum(), 1.0))
+    dx = lam / points_per_debye
+    phiM = rng.uniform(phi_lo, phi_hi, B)
+    return D, q, cb, dx, phiM
+
+
+def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None, flux=None, **lane_kw):
+    newton_kw = dict(newton_kw or {})
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, seed, **lane_kw)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    fl = np.zeros((B, N)) if flux is None else flux
+    s = _capi.PnpSolver(N, nx, dx, dt if dt else 1.0, BETA, EPS, D, q, method='Newton', pb_mode=_capi.PB_DD, batch_capacity=B)
+    s.set_newton(**newton_kw)
+    s.set_batch(c0, pb, np.zeros(B), fl)
+    if stationary:
+        st = s.solve_stationary()
+    else:
+        s.step(nsteps)
+        st = s.get_status()
+    c, phi, _, _ = s.get_state()
+    its = s.newton_iterations()
+    s.close()
+    okw = dict(tol=newton_kw.get('tol', 1e-10), maxit=newton_kw.get('maxit', 50), dphi_max=newton_kw.get('dphi_max', 0.05))
+    if okw['dphi_max'] <= 0:
+        okw['dphi_max'] = None
+    ref_c = np.zeros_like(c); ref_phi = np.zeros_like(phi); ref_it = np.zeros(B, int)
+    for b in range(B):
+        p = PH.PhysicalProblem(D=D, charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=cb[b], phiM=phiM[b], flux=fl[b],
+                               stern_capacitance=newton_kw.get('stern_capacitance') if newton_kw.get('wall_bc') == 'stern' else None,
+                               phi_pzc=newton_kw.get('phi_pzc', 0.0), mpb_radius=newton_kw.get('mpb_radius'))
+        cc, ph = c0[b].copy(), np.zeros(nx)
+        if stationary:
+            cc, ph, it, _ = PH.newton_step(p, cc, ph, cc, np.inf, **okw)
+            ref_it[b] = it
+        else:
+            for _ in range(nsteps):
+                cc, ph, it, _ = PH.newton_step(p, cc, ph, cc, dt, **okw)
+                ref_it[b] += it
+        ref_c[b], ref_phi[b] = cc, ph
+    return (c, phi, its, st), (ref_c, ref_phi, ref_it)
+
+
+def assert_close(got, ref, rtol=2e-9):
+    c, phi, its, st = got
+    rc, rphi, rit = ref
+    assert np.all(st == 0), st
+    cscale = np.abs(rc).max(axis=2, keepdims=True)
+    assert np.abs(c - rc).max() <= rtol * cscale.max() and (np.abs(c - rc) / (np.abs(rc) + 1e-3 * cscale)).max() < 1e-6
+    assert np.abs(phi - rphi).max() <= rtol * max(np.abs(rphi).max(), 0.025)
+    assert np.array_equal(its, rit), (its, rit)
+
+
+@pytest.mark.parametrize("N,nx", [(2, 64), (2, 201), (3, 128), (3, 512), (1, 33), (4, 100), (5, 70), (6, 96), (7, 50), (8, 40)])
+def test_stationary_matches_oracle(N, nx):
+    got, ref = run_both(N, nx, B=5, seed=N * 1000 + nx)
+    assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx", [(3, 513), (2, 1030), (3, 1200)])
+def test_more_rows_than_threads(N, nx):
+    got, ref = run_both(N, nx, B=3, seed=nx, points_per_debye=20.0)
+    assert_close(got, ref)
+
+
+def test_transient_steps_match_oracle():
+    N, nx = 3, 160
+    D, q, cb, dx, phiM = make_lanes(N, nx, 4, 7)
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    got, ref = run_both(N, nx, B=4, seed=7, dt=dt, nsteps=6, stationary=False)
+    assert_close(got, ref)
+    assert got[2].min() >= 6 * 2          # at least two Newton iterations per step
+
+
+def test_stern_layer_and_steric_ions():
+    a = [4.1e-10, 3.1e-10, 3.5e-10]
+    got, ref = run_both(3, 240, B=6, seed=11, phi_lo=-1.5, phi_hi=1.0, cref=100.0,
+                        newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, phi_pzc=0.05, mpb_radius=a, maxit=60))
+    assert_close(got, ref)
+    c = got[0]
+    assert (c[:, 0, 0] * PH.N_AVOGADRO * a[0] ** 3).max() < 1.0
+
+
+def test_wall_fluxes():
+    rng = np.random.default_rng(5)
+    B, N = 4, 3
+    flux = rng.uniform(-2e-4, 2e-4, (B, N))
+    got, ref = run_both(N, 96, B=B, seed=13, flux=flux)
+    assert_close(got, ref)
+
+
+def test_not_converged_is_reported():
+    got, ref = run_both(2, 64, B=3, seed=3, newton_kw=dict(maxit=2))
+    assert np.all(got[3] == _capi.STATUS_MAXIT)
+    assert np.array_equal(got[2], ref[2]) and np.all(got[2] == 3)
+
+
+def test_surface_observables():
+    N, nx, B = 2, 128, 3
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 21)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4)); pb[:, 0] = phiM
+    with _capi.PnpSolver(N, nx, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+        s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+        assert np.all(s.solve_stationary() == 0)
+        c, phi, g, l = s.get_state()
+        cs, vs, es = s.get_surface()
+    assert np.allclose(cs, c[:, :, 0]) and np.allclose(vs, phiM) and np.allclose(es, -(phi[:, 1] - phi[:, 0]) / dx)
+    assert np.allclose(l, -(q[None, :, None] * c).sum(axis=1) / EPS)
+    assert np.allclose(g[:, 1:-1], (phi[:, 2:] - phi[:, :-2]) / (2 * dx))
