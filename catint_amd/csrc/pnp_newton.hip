@@ -16,6 +16,8 @@
 // stays L2/MALL resident.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pnp_internal.h"
 
 namespace pnp {
@@ -449,6 +451,307 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast path: every thread owns the two adjacent block rows a = 2t, b = 2t+1 (nx <= 2*blockDim.x).
+//   1. row a is normalised and eliminated against its neighbours in registers (first level of cyclic reduction):
+//      the T reduced b-rows form a block-tridiagonal system of half the size;
+//   2. parallel cyclic reduction over the T b-rows, the thread's own row resident in registers, neighbour rows
+//      exchanged through ONE element-major LDS buffer (write own / barrier / read i-s, i+s / barrier);
+//   3. x_a = rt_a - Lt_a x_b[t-1] - Ut_a x_b[t].
+// LDS: (2 NB^2 + NB) * T doubles (72 KiB for N = 3, nx = 512 -> two workgroups per CU).
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void lds_store_row(double* buf, int T, int t, const double (&X)[NB][2 * NB + 1]) {
+  double* p = buf + t;
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 2 * NB + 1; ++cc) p[(r * (2 * NB + 1) + cc) * T] = X[r][cc];
+}
+
+// Q <- columns [c0, c0+NB) of row t's stored [NB][2NB+1] matrix
+template <int NB>
+__device__ __forceinline__ void lds_load_block(const double* buf, int T, int t, int c0, double (&Q)[NB][NB]) {
+  const double* p = buf + t;
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int cc = 0; cc < NB; ++cc) Q[r][cc] = p[(r * (2 * NB + 1) + c0 + cc) * T];
+}
+
+template <int NB>
+__device__ __forceinline__ void lds_load_rhs(const double* buf, int T, int t, double (&v)[NB]) {
+  const double* p = buf + t;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) v[r] = p[(r * (2 * NB + 1) + 2 * NB) * T];
+}
+
+// acc[:, c0:c0+NB] -= A * Q
+template <int NB, int NC>
+__device__ __forceinline__ void mm_sub(double (&acc)[NB][NC], int c0, const double (&A)[NB][NB], const double (&Q)[NB][NB]) {
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int cc = 0; cc < NB; ++cc)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[r][c0 + cc] = __builtin_fma(-A[r][j], Q[j][cc], acc[r][c0 + cc]);
+}
+
+template <int NB, int TMAX, bool MPB>
+__global__ __launch_bounds__(TMAX) void newton_pair_kernel(const NewtonArgs A) {
+  constexpr int N = NB - 1;
+  constexpr int NC = 2 * NB + 1;
+  extern __shared__ double newton_lds[];
+  __shared__ double red[2][16];
+  double* xch = newton_lds;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int nx = A.nx, ldx = A.ldx;
+  const int ra = 2 * tid, rb = 2 * tid + 1;
+  for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+    double* c = A.c + (size_t)b * N * ldx;
+    double* co = A.c_old + (size_t)b * N * ldx;
+    double* phi = A.phi + (size_t)b * ldx;
+    const double* flux = A.flux + (size_t)b * N;
+    const double* cb = A.cbulk + (size_t)b * N;
+    const double phiM = A.pb[b * 4 + 0], phiB = A.pb[b * 4 + 1];
+    int total_it = 0, st = PNP_STATUS_OK;
+    for (int step = 0; step < A.nsteps; ++step) {
+      for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
+      __syncthreads();
+      bool conv = false;
+      int it = 1;
+      for (; it <= A.maxit; ++it) {
+        // ---- rows a and b; a normalised
+        double Ma[NB][NB], Xa[NB][NC];     // Xa = [Lt_a | Ut_a | rt_a] after the solve
+        if (ra < nx) {
+          assemble_row<NB, MPB>(A, c, co, phi, flux, cb, phiM, phiB, ra, Ma, Xa);
+          block_solve<NB, NC, true>(Ma, Xa);
+        } else {
+#pragma unroll
+          for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) Xa[r][cc] = 0.0;
+        }
+        lds_store_row<NB>(xch, T, tid, Xa);
+        double Mb[NB][NB], Xb[NB][NC];
+        if (rb < nx) {
+          assemble_row<NB, MPB>(A, c, co, phi, flux, cb, phiM, phiB, rb, Mb, Xb);
+        } else {
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc) Mb[r][cc] = (r == cc) ? 1.0 : 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) Xb[r][cc] = 0.0;
+          }
+        }
+        __syncthreads();
+        {
+          // eliminate x_a (own) and x_a' (thread t+1) from row b:  L_b x_a + M_b x_b + U_b x_a' = r_b
+          double Lb[NB][NB], Ub[NB][NB], Q[NB][NB], qv[NB];
+#pragma unroll
+          for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc) {
+              Lb[r][cc] = Xb[r][cc];
+              Ub[r][cc] = Xb[r][NB + cc];
+              Xb[r][cc] = 0.0;
+              Xb[r][NB + cc] = 0.0;
+            }
+          // own a-row: M_b -= L_b Ut_a ; L' = -L_b Lt_a ; r' -= L_b rt_a
+#pragma unroll
+          for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc)
+#pragma unroll
+              for (int j = 0; j < NB; ++j) {
+                Mb[r][cc] = __builtin_fma(-Lb[r][j], Xa[j][NB + cc], Mb[r][cc]);
+                Xb[r][cc] = __builtin_fma(-Lb[r][j], Xa[j][cc], Xb[r][cc]);
+              }
+#pragma unroll
+          for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) Xb[r][2 * NB] = __builtin_fma(-Lb[r][j], Xa[j][2 * NB], Xb[r][2 * NB]);
+          if (tid + 1 < T) {   // a-row of the next thread: M_b -= U_b Lt_a' ; U' = -U_b Ut_a' ; r' -= U_b rt_a'
+            lds_load_block<NB>(xch, T, tid + 1, 0, Q);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+              for (int cc = 0; cc < NB; ++cc)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) Mb[r][cc] = __builtin_fma(-Ub[r][j], Q[j][cc], Mb[r][cc]);
+            lds_load_block<NB>(xch, T, tid + 1, NB, Q);
+            mm_sub<NB, NC>(Xb, NB, Ub, Q);
+            lds_load_rhs<NB>(xch, T, tid + 1, qv);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+              for (int j = 0; j < NB; ++j) Xb[r][2 * NB] = __builtin_fma(-Ub[r][j], qv[j], Xb[r][2 * NB]);
+          }
+          block_solve<NB, NC, true>(Mb, Xb);
+        }
+        // ---- PCR over the T reduced rows, own row in registers
+        for (int s = 1; s < T; s <<= 1) {
+          __syncthreads();                       // everyone has finished reading the previous contents of xch
+          lds_store_row<NB>(xch, T, tid, Xb);
+          __syncthreads();
+          double D[NB][NB], Y[NB][NC], Lt[NB][NB], Ut[NB][NB], Q[NB][NB], qv[NB];
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc) {
+              D[r][cc] = (r == cc) ? 1.0 : 0.0;
+              Lt[r][cc] = Xb[r][cc];
+              Ut[r][cc] = Xb[r][NB + cc];
+              Y[r][cc] = 0.0;
+              Y[r][NB + cc] = 0.0;
+            }
+            Y[r][2 * NB] = Xb[r][2 * NB];
+          }
+          if (tid - s >= 0) {
+            lds_load_block<NB>(xch, T, tid - s, NB, Q);     // Ut[-s]
+            mm_sub<NB, NB>(D, 0, Lt, Q);
+            lds_load_block<NB>(xch, T, tid - s, 0, Q);      // Lt[-s]
+            mm_sub<NB, NC>(Y, 0, Lt, Q);
+            lds_load_rhs<NB>(xch, T, tid - s, qv);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+              for (int j = 0; j < NB; ++j) Y[r][2 * NB] = __builtin_fma(-Lt[r][j], qv[j], Y[r][2 * NB]);
+          }
+          if (tid + s < T) {
+            lds_load_block<NB>(xch, T, tid + s, 0, Q);      // Lt[+s]
+            mm_sub<NB, NB>(D, 0, Ut, Q);
+            lds_load_block<NB>(xch, T, tid + s, NB, Q);     // Ut[+s]
+            mm_sub<NB, NC>(Y, NB, Ut, Q);
+            lds_load_rhs<NB>(xch, T, tid + s, qv);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+              for (int j = 0; j < NB; ++j) Y[r][2 * NB] = __builtin_fma(-Ut[r][j], qv[j], Y[r][2 * NB]);
+          }
+          block_solve<NB, NC, false>(D, Y);
+#pragma unroll
+          for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) Xb[r][cc] = Y[r][cc];
+        }
+        // ---- x_b = rt_b; x_a = rt_a - Lt_a x_b[t-1] - Ut_a x_b[t]
+        double dub[NB], dua[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) dub[r] = Xb[r][2 * NB];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NB; ++r) xch[r * T + tid] = dub[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+          double acc = Xa[r][2 * NB];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc = __builtin_fma(-Xa[r][NB + j], dub[j], acc);
+          dua[r] = acc;
+        }
+        if (tid > 0) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const double xl = xch[j * T + tid - 1];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) dua[r] = __builtin_fma(-Xa[r][j], xl, dua[r]);
+          }
+        }
+        // ---- damping, update, convergence (oracle/pnp_physical.py: newton_step)
+        double mphi = 0.0, upd = 0.0;
+        double ca[N], cbv[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          ca[k] = ra < nx ? c[k * ldx + ra] : 1.0;
+          cbv[k] = rb < nx ? c[k * ldx + rb] : 1.0;
+          upd = fmax(upd, fabs(dua[k]) / (fabs(ca[k]) + fabs(cb[k]) + 1e-300));
+          upd = fmax(upd, fabs(dub[k]) / (fabs(cbv[k]) + fabs(cb[k]) + 1e-300));
+          if (!(dua[k] == dua[k]) || !(dub[k] == dub[k])) upd = INFINITY;
+        }
+        mphi = fmax(fabs(dua[N]), fabs(dub[N]));
+        if (!(mphi == mphi)) mphi = INFINITY;
+        upd = fmax(upd, mphi * A.vt_inv);
+        mphi = wave_max(mphi);
+        upd = wave_max(upd);
+        if ((tid & 63) == 0) {
+          red[0][tid >> 6] = mphi;
+          red[1][tid >> 6] = upd;
+        }
+        __syncthreads();
+        mphi = 0.0;
+        upd = 0.0;
+        for (int w = 0; w < (T >> 6); ++w) {
+          mphi = fmax(mphi, red[0][w]);
+          upd = fmax(upd, red[1][w]);
+        }
+        double lam = 1.0;
+        if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int row = half == 0 ? ra : rb;
+          if (row < nx) {
+            double cn[N];
+            double f_old = 0.0, f_new = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              const double cc_ = half == 0 ? ca[k] : cbv[k];
+              const double du = half == 0 ? dua[k] : dub[k];
+              const double t_ = __builtin_fma(lam, du, cc_);
+              const double lo = 0.1 * cc_;
+              cn[k] = t_ < lo ? lo : t_;
+              if constexpr (MPB) {
+                f_old = __builtin_fma(A.vol[k], cc_, f_old);
+                f_new = __builtin_fma(A.vol[k], cn[k], f_new);
+              }
+            }
+            if constexpr (MPB) {
+              const double free_ = 1.0 - f_old;
+              const double target = fmax(0.1 * free_, 1e-12);
+              if ((1.0 - f_new) < target) {
+                const double theta = (free_ - target) / (f_new - f_old);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                  const double cc_ = half == 0 ? ca[k] : cbv[k];
+                  cn[k] = __builtin_fma(theta, cn[k] - cc_, cc_);
+                }
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) c[k * ldx + row] = cn[k];
+            phi[row] = __builtin_fma(lam, half == 0 ? dua[N] : dub[N], phi[row]);
+          }
+        }
+        __syncthreads();
+        if (upd < A.tol && lam == 1.0) {
+          conv = true;
+          break;
+        }
+      }
+      total_it += conv ? it : A.maxit + 1;
+      if (!conv) st = PNP_STATUS_MAXIT;
+    }
+    double bad = 0.0;
+    for (int e = tid; e < nx; e += T) {
+      double sacc = phi[e];
+#pragma unroll
+      for (int k = 0; k < N; ++k) sacc += c[k * ldx + e];
+      if (!(fabs(sacc) < INFINITY)) bad = 1.0;
+    }
+    bad = wave_max(bad);
+    if ((tid & 63) == 0) red[0][tid >> 6] = bad;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 0; w < (T >> 6); ++w) bad = fmax(bad, red[0][w]);
+      A.status[b] = bad > 0.0 ? PNP_STATUS_NAN : st;
+      A.iters[b] = total_it;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -467,8 +770,34 @@ size_t newton_exchange_doubles(int nb, int nx) {   // both ping-pong buffers of 
 
 bool newton_exchange_in_lds(int nb, int nx) { return newton_exchange_doubles(nb, nx) * sizeof(double) <= kLdsBudget; }
 
+// pair kernel: nx <= 2*T with T <= TMAX threads and the exchange buffer in LDS
+template <int NB>
+static constexpr int pair_tmax() { return NB <= 4 ? 512 : 256; }
+
+int newton_pair_threads(int nb, int nx) {
+  const int tmax = nb <= 4 ? 512 : 256;
+  const int t = ((nx + 1) / 2 + 63) / 64 * 64;
+  if (t > tmax) return 0;
+  if ((size_t)(2 * nb * nb + nb) * t * sizeof(double) > kLdsBudget) return 0;
+  return t;
+}
+
 template <int NB, int TMAX>
 static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t stream) {
+  const char* force = getenv("CATINT_NEWTON_KERNEL");     // "generic" forces the row-per-thread kernel (tests)
+  const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
+  if (tp > 0) {
+    const size_t lds = (size_t)(2 * NB * NB + NB) * tp * sizeof(double);
+    constexpr int TP = pair_tmax<NB>();
+    if (a.mpb) {
+      (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((newton_pair_kernel<NB, TP, true>), dim3(blocks), dim3(tp), lds, stream, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((newton_pair_kernel<NB, TP, false>), dim3(blocks), dim3(tp), lds, stream, a);
+    }
+    return hipGetLastError();
+  }
   const int T = newton_threads(NB, a.nx);
   const size_t lds = a.work ? 0 : newton_exchange_doubles(NB, a.nx) * sizeof(double);
   if (a.mpb) {

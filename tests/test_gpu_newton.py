@@ -98,6 +98,15 @@ def test_stationary_matches_oracle(N, nx):
     assert_close(got, ref)
 
 
+@pytest.mark.parametrize("N,nx", [(2, 64), (3, 130), (4, 77), (6, 40)])
+def test_row_per_thread_kernel(N, nx, monkeypatch):
+    # the general kernel (rows exchanged through device memory or LDS ping-pong buffers) on shapes the pair kernel
+    # would otherwise take
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'generic')
+    got, ref = run_both(N, nx, B=4, seed=N * 77 + nx)
+    assert_close(got, ref)
+
+
 @pytest.mark.parametrize("N,nx", [(3, 513), (2, 1030), (3, 1200)])
 def test_more_rows_than_threads(N, nx):
     got, ref = run_both(N, nx, B=3, seed=nx, points_per_debye=20.0)
