@@ -39,6 +39,8 @@ struct pnp_handle {
   bool mpb = false;
   double* c_old = nullptr;
   double* work = nullptr;
+  double* stash = nullptr;
+  int64_t stash_stride = 0;
   int32_t* iters = nullptr;
   int nw_blocks = 0;
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
@@ -81,7 +83,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -170,6 +172,10 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
       HIP_TRYC(dev_alloc(h, &h->work, slice * (size_t)blocks));
     } else {
       h->nw_blocks = (int)(Bc < 4096 ? Bc : 4096);
+    }
+    if (const int ts = newton_pair_stride(nb, cfg->nx)) {
+      h->stash_stride = (int64_t)(2 * nb * nb + nb) * ts;
+      HIP_TRYC(dev_alloc(h, &h->stash, (size_t)h->stash_stride * (size_t)h->nw_blocks));
     }
   }
   HIP_TRYC(dev_alloc(h, &h->pb, (size_t)Bc * 4));
@@ -412,6 +418,8 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.B = h->B;
   a.work = h->work;
   a.work_stride = (int64_t)newton_exchange_doubles(N + 1, nx);
+  a.stash = h->stash;
+  a.stash_stride = h->stash_stride;
   a.tol = tol > 0 ? tol : h->np.tol;
   a.dphi_max = h->np.dphi_max;
   a.stern = dx * h->np.stern_capacitance / eps;

@@ -117,12 +117,16 @@ struct NewtonArgs {
   const double* flux;                    // [B][N] wall flux INTO the domain
   const double* cbulk;                   // [B][N]
   double* work;                          // PCR exchange buffers in device memory, or null -> dynamic LDS
+  double* stash;                         // pair kernel: parked a-rows, stash_stride doubles per workgroup
+  int64_t stash_stride;
   int32_t* status;                       // [B]
   int32_t* iters;                        // [B] Newton iterations spent by this call (maxit+1 for a failed solve)
 };
 int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);
 bool newton_exchange_in_lds(int nb, int nx);
+int newton_pair_threads(int nb, int nx);   // threads of the pair kernel, 0 if the shape does not fit it
+int newton_pair_stride(int nb, int nx);    // its compile-time row stride (256 or 512)
 hipError_t launch_newton(const NewtonArgs& a, int blocks, hipStream_t stream);
 
 }  // namespace pnp

@@ -30,20 +30,6 @@ __device__ __forceinline__ double nrcp(double x) {   // v_rcp_f64 + two Newton s
   return __builtin_fma(r, e, r);
 }
 
-// Bernoulli function B(u) = u/(exp(u)-1) and its derivative; Taylor series below |u| = 0.05
-// (oracle/pnp_physical.py: bernoulli, SERIES_U).
-__device__ __forceinline__ void bernoulli(double u, double& B, double& dB) {
-  if (fabs(u) < 0.05) {
-    const double u2 = u * u;
-    B = 1.0 - 0.5 * u + u2 * (1.0 / 12.0 + u2 * (-1.0 / 720.0 + u2 * (1.0 / 30240.0)));
-    dB = -0.5 + u * (1.0 / 6.0 + u2 * (-1.0 / 180.0 + u2 * (1.0 / 5040.0)));
-  } else {
-    const double E = expm1(u);
-    B = u / E;
-    dB = (1.0 - B - u) / E;
-  }
-}
-
 // X <- M^-1 X for a dense NB x NB block M and NC right-hand-side columns, Gauss-Jordan in registers.
 // PIVOT: partial (row) pivoting, used for the raw Jacobian blocks; the PCR levels work on I - (small products)
 // and run without.
@@ -187,13 +173,75 @@ __device__ __forceinline__ void pcr_row(const double* __restrict__ src, double* 
   store_row<NB>(dst, RS, row, X);
 }
 
-// Residual F and Jacobian blocks (L, M, U) of block row i, returned as M and X = [L | U | -F]
+// Scharfetter-Gummel flux of one species across one edge (left point l, right point r), scaled by dx/D:
+//   J = -(B(-u) c_r - B(u) c_l),  u = psi_r - psi_l;   Ju = dJ/du;   dJ/dc_l = Bp, dJ/dc_r = -Bm
+struct Edge {
+  double Bp, Bm, J, Ju;
+};
+
+__device__ __forceinline__ Edge edge_flux(double u, double cl, double cr) {
+  double B, dB;
+  if (fabs(u) < 0.05) {   // oracle/pnp_physical.py: bernoulli, SERIES_U
+    const double u2 = u * u;
+    B = 1.0 - 0.5 * u + u2 * (1.0 / 12.0 + u2 * (-1.0 / 720.0 + u2 * (1.0 / 30240.0)));
+    dB = -0.5 + u * (1.0 / 6.0 + u2 * (-1.0 / 180.0 + u2 * (1.0 / 5040.0)));
+  } else {
+    const double rE = nrcp(expm1(u));
+    B = u * rE;
+    dB = (1.0 - B - u) * rE;
+  }
+  Edge e;
+  e.Bp = B;
+  e.Bm = B + u;
+  e.J = -(e.Bm * cr - B * cl);
+  e.Ju = -((dB + 1.0) * cr - dB * cl);
+  return e;
+}
+
+// State of one grid point as the assembly needs it: concentrations, potential and (MPB) w = -ln(1-phi0), dw/dc_j.
+template <int N, bool MPB>
+struct Point {
+  double c[N], phi, w, g[N];
+};
+
+template <int N, bool MPB>
+__device__ __forceinline__ Point<N, MPB> load_point(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ phi,
+                                                   int i) {
+  Point<N, MPB> P;
+  P.phi = phi[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) P.c[k] = c[k * A.ldx + i];
+  P.w = 0.0;
+  if constexpr (MPB) {
+    double f = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) f = __builtin_fma(A.vol[k], P.c[k], f);
+    P.w = -log1p(-f);
+    const double inv = 1.0 / (1.0 - f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) P.g[k] = A.vol[k] * inv;
+  }
+  return P;
+}
+
+template <int N, bool MPB>
+__device__ __forceinline__ void edge_fluxes(const NewtonArgs& A, const Point<N, MPB>& Pl, const Point<N, MPB>& Pr, Edge (&e)[N]) {
+  const double dphi = Pr.phi - Pl.phi, dw = Pr.w - Pl.w;
+#pragma unroll
+  for (int k = 0; k < N; ++k) e[k] = edge_flux(A.qb[k] * dphi + dw, Pl.c[k], Pr.c[k]);
+}
+
+// Residual F and Jacobian blocks (L, M, U) of block row i, returned as M and X = [L | U | -F], from the point states
+// Pm, P0, Pp (i-1, i, i+1) and the fluxes em (edge i-1/2) and ep (edge i+1/2)
 // (oracle/pnp_physical.py: residual_and_jacobian; same scaling: species rows dx^2/D_k, Poisson row dx^2/eps).
+// At the wall the left edge, at the bulk both edges are switched off by 0/1 weights (their values are finite: the
+// neighbour index is clamped).
 template <int NB, bool MPB>
-__device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ co,
-                                             const double* __restrict__ phi, const double* __restrict__ flux,
-                                             const double* __restrict__ cb, double phiM, double phiB, int i,
-                                             double (&M)[NB][NB], double (&X)[NB][2 * NB + 1]) {
+__device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __restrict__ co, const double* __restrict__ flux,
+                                         const double* __restrict__ cb, double phiM, double phiB, int i,
+                                         const Point<NB - 1, MPB>& Pm, const Point<NB - 1, MPB>& P0,
+                                         const Point<NB - 1, MPB>& Pp, const Edge (&em)[NB - 1], const Edge (&ep)[NB - 1],
+                                         double (&M)[NB][NB], double (&X)[NB][2 * NB + 1]) {
   constexpr int N = NB - 1;
   constexpr int NC = 2 * NB + 1;
   const int nx = A.nx, ldx = A.ldx;
@@ -204,93 +252,37 @@ __device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* 
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) X[r][cc] = 0.0;
   }
-  const int im = i > 0 ? i - 1 : 0;
-  const int ip = i < nx - 1 ? i + 1 : nx - 1;
-  const double pm = phi[im], p0 = phi[i], pp = phi[ip];
-  double cm[N], c0[N], cp[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    cm[k] = c[k * ldx + im];
-    c0[k] = c[k * ldx + i];
-    cp[k] = c[k * ldx + ip];
-  }
-  double dwm = 0.0, dwp = 0.0;                 // w_i - w_{i-1}, w_{i+1} - w_i with w = -ln(1-phi0)
-  double gm[N], g0[N], gp[N];                  // d w / d c_j at i-1, i, i+1
-  if constexpr (MPB) {
-    double fm = 0.0, f0 = 0.0, fp = 0.0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      fm = __builtin_fma(A.vol[k], cm[k], fm);
-      f0 = __builtin_fma(A.vol[k], c0[k], f0);
-      fp = __builtin_fma(A.vol[k], cp[k], fp);
-    }
-    const double wm = -log1p(-fm), w0 = -log1p(-f0), wp = -log1p(-fp);
-    dwm = w0 - wm;
-    dwp = wp - w0;
-    const double im_ = 1.0 / (1.0 - fm), i0_ = 1.0 / (1.0 - f0), ip_ = 1.0 / (1.0 - fp);
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      gm[k] = A.vol[k] * im_;
-      g0[k] = A.vol[k] * i0_;
-      gp[k] = A.vol[k] * ip_;
-    }
-  }
   const bool wall = (i == 0), bulk = (i == nx - 1);
+  const double wp = bulk ? 0.0 : 1.0;
+  const double wm = (wall || bulk) ? 0.0 : 1.0;
+  const double ws = bulk ? 0.0 : (wall ? 0.5 : 1.0);
+  const double wf = wall ? 1.0 : 0.0;
   double rho = 0.0;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const double qb = A.qb[k], sig = A.sig[k];
-    rho = __builtin_fma(A.peq[k], c0[k], rho);
-    if (bulk) {
-      X[k][2 * NB] = -(c0[k] - cb[k]);
-      M[k][k] = 1.0;
-      continue;
-    }
-    const double up = qb * (pp - p0) + dwp;
-    double Bp, dBp;
-    bernoulli(up, Bp, dBp);
-    const double Bmp = Bp + up;
-    const double Jp = -(Bmp * cp[k] - Bp * c0[k]);
-    const double Jup = -((dBp + 1.0) * cp[k] - dBp * c0[k]);
-    if (wall) {
-      const double F = 0.5 * sig * (c0[k] - co[k * ldx + i]) + Jp - flux[k] * A.fl[k];
-      X[k][2 * NB] = -F;
-      M[k][k] += 0.5 * sig + Bp;
-      X[k][NB + k] += -Bmp;
-      M[k][N] += -Jup * qb;
-      X[k][NB + N] += Jup * qb;
-      if constexpr (MPB) {
+    const double qb = A.qb[k], sg = ws * A.sig[k];
+    rho = __builtin_fma(A.peq[k], P0.c[k], rho);
+    const double Jp = wp * ep[k].J, Jup = wp * ep[k].Ju;
+    const double Jm = wm * em[k].J, Jum = wm * em[k].Ju;
+    double F = sg * (P0.c[k] - co[k * ldx + i]) + Jp - Jm - wf * (flux[k] * A.fl[k]);
+    if (bulk) F = P0.c[k] - cb[k];
+    X[k][2 * NB] = -F;
+    M[k][k] = sg + wp * ep[k].Bp + wm * em[k].Bm + (bulk ? 1.0 : 0.0);
+    X[k][NB + k] = -(wp * ep[k].Bm);
+    X[k][k] = -(wm * em[k].Bp);
+    M[k][N] = -qb * (Jup + Jum);
+    X[k][NB + N] = Jup * qb;
+    X[k][N] = Jum * qb;
+    if constexpr (MPB) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-          M[k][j] += -Jup * g0[j];
-          X[k][NB + j] += Jup * gp[j];
-        }
-      }
-    } else {
-      const double um = qb * (p0 - pm) + dwm;
-      double Bq, dBq;
-      bernoulli(um, Bq, dBq);
-      const double Bmq = Bq + um;
-      const double Jm = -(Bmq * c0[k] - Bq * cm[k]);
-      const double Jum = -((dBq + 1.0) * c0[k] - dBq * cm[k]);
-      const double F = sig * (c0[k] - co[k * ldx + i]) + Jp - Jm;
-      X[k][2 * NB] = -F;
-      M[k][k] += sig + Bp + Bmq;
-      X[k][NB + k] += -Bmp;
-      X[k][k] += -Bq;
-      M[k][N] += Jup * (-qb) - Jum * qb;
-      X[k][NB + N] += Jup * qb;
-      X[k][N] += Jum * qb;
-      if constexpr (MPB) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          M[k][j] += -Jup * g0[j] - Jum * g0[j];
-          X[k][NB + j] += Jup * gp[j];
-          X[k][j] += Jum * gm[j];
-        }
+      for (int j = 0; j < N; ++j) {
+        M[k][j] += -(Jup + Jum) * P0.g[j];
+        X[k][NB + j] += Jup * Pp.g[j];
+        X[k][j] += Jum * Pm.g[j];
       }
     }
   }
+  const double p0 = P0.phi, pp = Pp.phi, pm = Pm.phi;
   if (bulk) {
     X[N][2 * NB] = -(p0 - phiB);
     M[N][N] = 1.0;
@@ -313,6 +305,23 @@ __device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* 
   }
 }
 
+template <int NB, bool MPB>
+__device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ co,
+                                             const double* __restrict__ phi, const double* __restrict__ flux,
+                                             const double* __restrict__ cb, double phiM, double phiB, int i,
+                                             double (&M)[NB][NB], double (&X)[NB][2 * NB + 1]) {
+  constexpr int N = NB - 1;
+  const int im = i > 0 ? i - 1 : 0;
+  const int ip = i < A.nx - 1 ? i + 1 : A.nx - 1;
+  const Point<N, MPB> Pm = load_point<N, MPB>(A, c, phi, im);
+  const Point<N, MPB> P0 = load_point<N, MPB>(A, c, phi, i);
+  const Point<N, MPB> Pp = load_point<N, MPB>(A, c, phi, ip);
+  Edge em[N], ep[N];
+  edge_fluxes<N, MPB>(A, Pm, P0, em);
+  edge_fluxes<N, MPB>(A, P0, Pp, ep);
+  fill_row<NB, MPB>(A, co, flux, cb, phiM, phiB, i, Pm, P0, Pp, em, ep, M, X);
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -321,6 +330,10 @@ __device__ __forceinline__ double wave_max(double v) {
 
 // One workgroup per operating point (grid-stride over the batch).  blockDim.x = T threads, thread t owns block rows
 // t, t+T, ...  Dynamic LDS: the two PCR buffers when A.work == nullptr.
+// Launch bounds: every kernel of this file is compiled for at most 256 registers per thread (bound 512).  With the
+// 512-register budget (bound 256) the N >= 6 instances spilled into the accumulator half of the register file and
+// then produced run-to-run different, sometimes wrong, solutions on MI355X (tools/probe/repro_newton.py); with 256
+// they are bitwise reproducible.  The larger blocks pay with scratch traffic instead.
 template <int NB, int TMAX, bool MPB>
 __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
   constexpr int N = NB - 1;
@@ -461,30 +474,30 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
 //   3. x_a = rt_a - Lt_a x_b[t-1] - Ut_a x_b[t].
 // LDS: (2 NB^2 + NB) * T doubles (72 KiB for N = 3, nx = 512 -> two workgroups per CU).
 // ------------------------------------------------------------------------------------------------
-template <int NB>
-__device__ __forceinline__ void lds_store_row(double* buf, int T, int t, const double (&X)[NB][2 * NB + 1]) {
+template <int NB, int TS>
+__device__ __forceinline__ void lds_store_row(double* buf, int t, const double (&X)[NB][2 * NB + 1]) {
   double* p = buf + t;
 #pragma unroll
   for (int r = 0; r < NB; ++r)
 #pragma unroll
-    for (int cc = 0; cc < 2 * NB + 1; ++cc) p[(r * (2 * NB + 1) + cc) * T] = X[r][cc];
+    for (int cc = 0; cc < 2 * NB + 1; ++cc) p[(r * (2 * NB + 1) + cc) * TS] = X[r][cc];
 }
 
 // Q <- columns [c0, c0+NB) of row t's stored [NB][2NB+1] matrix
-template <int NB>
-__device__ __forceinline__ void lds_load_block(const double* buf, int T, int t, int c0, double (&Q)[NB][NB]) {
+template <int NB, int TS>
+__device__ __forceinline__ void lds_load_block(const double* buf, int t, int c0, double (&Q)[NB][NB]) {
   const double* p = buf + t;
 #pragma unroll
   for (int r = 0; r < NB; ++r)
 #pragma unroll
-    for (int cc = 0; cc < NB; ++cc) Q[r][cc] = p[(r * (2 * NB + 1) + c0 + cc) * T];
+    for (int cc = 0; cc < NB; ++cc) Q[r][cc] = p[(r * (2 * NB + 1) + c0 + cc) * TS];
 }
 
-template <int NB>
-__device__ __forceinline__ void lds_load_rhs(const double* buf, int T, int t, double (&v)[NB]) {
+template <int NB, int TS>
+__device__ __forceinline__ void lds_load_rhs(const double* buf, int t, double (&v)[NB]) {
   const double* p = buf + t;
 #pragma unroll
-  for (int r = 0; r < NB; ++r) v[r] = p[(r * (2 * NB + 1) + 2 * NB) * T];
+  for (int r = 0; r < NB; ++r) v[r] = p[(r * (2 * NB + 1) + 2 * NB) * TS];
 }
 
 // acc[:, c0:c0+NB] -= A * Q
@@ -498,8 +511,8 @@ __device__ __forceinline__ void mm_sub(double (&acc)[NB][NC], int c0, const doub
       for (int j = 0; j < NB; ++j) acc[r][c0 + cc] = __builtin_fma(-A[r][j], Q[j][cc], acc[r][c0 + cc]);
 }
 
-template <int NB, int TMAX, bool MPB>
-__global__ __launch_bounds__(TMAX) void newton_pair_kernel(const NewtonArgs A) {
+template <int NB, int TS, bool MPB>
+__global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
   constexpr int N = NB - 1;
   constexpr int NC = 2 * NB + 1;
   extern __shared__ double newton_lds[];
@@ -508,6 +521,7 @@ __global__ __launch_bounds__(TMAX) void newton_pair_kernel(const NewtonArgs A) {
   const int tid = threadIdx.x, T = blockDim.x;
   const int nx = A.nx, ldx = A.ldx;
   const int ra = 2 * tid, rb = 2 * tid + 1;
+  double* stash = A.stash + (size_t)blockIdx.x * A.stash_stride;
   for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
     double* c = A.c + (size_t)b * N * ldx;
     double* co = A.c_old + (size_t)b * N * ldx;
@@ -522,28 +536,41 @@ __global__ __launch_bounds__(TMAX) void newton_pair_kernel(const NewtonArgs A) {
       bool conv = false;
       int it = 1;
       for (; it <= A.maxit; ++it) {
-        // ---- rows a and b; a normalised
+        // ---- rows a and b (the edge between them is evaluated once); a normalised
         double Ma[NB][NB], Xa[NB][NC];     // Xa = [Lt_a | Ut_a | rt_a] after the solve
-        if (ra < nx) {
-          assemble_row<NB, MPB>(A, c, co, phi, flux, cb, phiM, phiB, ra, Ma, Xa);
-          block_solve<NB, NC, true>(Ma, Xa);
-        } else {
-#pragma unroll
-          for (int r = 0; r < NB; ++r)
-#pragma unroll
-            for (int cc = 0; cc < NC; ++cc) Xa[r][cc] = 0.0;
-        }
-        lds_store_row<NB>(xch, T, tid, Xa);
         double Mb[NB][NB], Xb[NB][NC];
-        if (rb < nx) {
-          assemble_row<NB, MPB>(A, c, co, phi, flux, cb, phiM, phiB, rb, Mb, Xb);
-        } else {
+        {
+          const int last = nx - 1;
+          const int i0 = ra > 0 ? (ra - 1 < last ? ra - 1 : last) : 0;
+          const int i1 = ra < last ? ra : last, i2 = rb < last ? rb : last, i3 = rb + 1 < last ? rb + 1 : last;
+          const Point<N, MPB> P0 = load_point<N, MPB>(A, c, phi, i0);
+          const Point<N, MPB> P1 = load_point<N, MPB>(A, c, phi, i1);
+          const Point<N, MPB> P2 = load_point<N, MPB>(A, c, phi, i2);
+          const Point<N, MPB> P3 = load_point<N, MPB>(A, c, phi, i3);
+          Edge e0[N], e1[N], e2[N];
+          edge_fluxes<N, MPB>(A, P0, P1, e0);
+          edge_fluxes<N, MPB>(A, P1, P2, e1);
+          edge_fluxes<N, MPB>(A, P2, P3, e2);
+          if (ra < nx) {
+            fill_row<NB, MPB>(A, co, flux, cb, phiM, phiB, ra, P0, P1, P2, e0, e1, Ma, Xa);
+            block_solve<NB, NC, true>(Ma, Xa);
+          } else {
 #pragma unroll
-          for (int r = 0; r < NB; ++r) {
+            for (int r = 0; r < NB; ++r)
 #pragma unroll
-            for (int cc = 0; cc < NB; ++cc) Mb[r][cc] = (r == cc) ? 1.0 : 0.0;
+              for (int cc = 0; cc < NC; ++cc) Xa[r][cc] = 0.0;
+          }
+          lds_store_row<NB, TS>(xch, tid, Xa);
+          if (rb < nx) {
+            fill_row<NB, MPB>(A, co, flux, cb, phiM, phiB, rb, P1, P2, P3, e1, e2, Mb, Xb);
+          } else {
 #pragma unroll
-            for (int cc = 0; cc < NC; ++cc) Xb[r][cc] = 0.0;
+            for (int r = 0; r < NB; ++r) {
+#pragma unroll
+              for (int cc = 0; cc < NB; ++cc) Mb[r][cc] = (r == cc) ? 1.0 : 0.0;
+#pragma unroll
+              for (int cc = 0; cc < NC; ++cc) Xb[r][cc] = 0.0;
+            }
           }
         }
         __syncthreads();
@@ -574,16 +601,16 @@ __global__ __launch_bounds__(TMAX) void newton_pair_kernel(const NewtonArgs A) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) Xb[r][2 * NB] = __builtin_fma(-Lb[r][j], Xa[j][2 * NB], Xb[r][2 * NB]);
           if (tid + 1 < T) {   // a-row of the next thread: M_b -= U_b Lt_a' ; U' = -U_b Ut_a' ; r' -= U_b rt_a'
-            lds_load_block<NB>(xch, T, tid + 1, 0, Q);
+            lds_load_block<NB, TS>(xch, tid + 1, 0, Q);
 #pragma unroll
             for (int r = 0; r < NB; ++r)
 #pragma unroll
               for (int cc = 0; cc < NB; ++cc)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) Mb[r][cc] = __builtin_fma(-Ub[r][j], Q[j][cc], Mb[r][cc]);
-            lds_load_block<NB>(xch, T, tid + 1, NB, Q);
+            lds_load_block<NB, TS>(xch, tid + 1, NB, Q);
             mm_sub<NB, NC>(Xb, NB, Ub, Q);
-            lds_load_rhs<NB>(xch, T, tid + 1, qv);
+            lds_load_rhs<NB, TS>(xch, tid + 1, qv);
 #pragma unroll
             for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -591,10 +618,23 @@ __global__ __launch_bounds__(TMAX) void newton_pair_kernel(const NewtonArgs A) {
           }
           block_solve<NB, NC, true>(Mb, Xb);
         }
+        // park the normalised a-row in device memory (coalesced, L2 resident) until the back-substitution: it
+        // would otherwise cost 2 NB^2 + NB registers through every PCR level
+        {
+          double* sp = stash + tid;
+#pragma unroll
+          for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int cc = NB; cc < NC; ++cc) sp[(size_t)(r * NC + cc) * TS] = Xa[r][cc];
+#pragma unroll
+          for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc) sp[(size_t)(r * NC + cc) * TS] = Xa[r][cc];
+        }
         // ---- PCR over the T reduced rows, own row in registers
         for (int s = 1; s < T; s <<= 1) {
           __syncthreads();                       // everyone has finished reading the previous contents of xch
-          lds_store_row<NB>(xch, T, tid, Xb);
+          lds_store_row<NB, TS>(xch, tid, Xb);
           __syncthreads();
           double D[NB][NB], Y[NB][NC], Lt[NB][NB], Ut[NB][NB], Q[NB][NB], qv[NB];
 #pragma unroll
@@ -610,22 +650,26 @@ __global__ __launch_bounds__(TMAX) void newton_pair_kernel(const NewtonArgs A) {
             Y[r][2 * NB] = Xb[r][2 * NB];
           }
           if (tid - s >= 0) {
-            lds_load_block<NB>(xch, T, tid - s, NB, Q);     // Ut[-s]
+            lds_load_block<NB, TS>(xch, tid - s, NB, Q);     // Ut[-s]
             mm_sub<NB, NB>(D, 0, Lt, Q);
-            lds_load_block<NB>(xch, T, tid - s, 0, Q);      // Lt[-s]
+            __builtin_amdgcn_sched_barrier(0);
+            lds_load_block<NB, TS>(xch, tid - s, 0, Q);      // Lt[-s]
             mm_sub<NB, NC>(Y, 0, Lt, Q);
-            lds_load_rhs<NB>(xch, T, tid - s, qv);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_load_rhs<NB, TS>(xch, tid - s, qv);
 #pragma unroll
             for (int r = 0; r < NB; ++r)
 #pragma unroll
               for (int j = 0; j < NB; ++j) Y[r][2 * NB] = __builtin_fma(-Lt[r][j], qv[j], Y[r][2 * NB]);
           }
           if (tid + s < T) {
-            lds_load_block<NB>(xch, T, tid + s, 0, Q);      // Lt[+s]
+            lds_load_block<NB, TS>(xch, tid + s, 0, Q);      // Lt[+s]
             mm_sub<NB, NB>(D, 0, Ut, Q);
-            lds_load_block<NB>(xch, T, tid + s, NB, Q);     // Ut[+s]
+            __builtin_amdgcn_sched_barrier(0);
+            lds_load_block<NB, TS>(xch, tid + s, NB, Q);     // Ut[+s]
             mm_sub<NB, NC>(Y, NB, Ut, Q);
-            lds_load_rhs<NB>(xch, T, tid + s, qv);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_load_rhs<NB, TS>(xch, tid + s, qv);
 #pragma unroll
             for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -643,21 +687,24 @@ __global__ __launch_bounds__(TMAX) void newton_pair_kernel(const NewtonArgs A) {
         for (int r = 0; r < NB; ++r) dub[r] = Xb[r][2 * NB];
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < NB; ++r) xch[r * T + tid] = dub[r];
+        for (int r = 0; r < NB; ++r) xch[r * TS + tid] = dub[r];
         __syncthreads();
+        {
+          const double* sp = stash + tid;
 #pragma unroll
-        for (int r = 0; r < NB; ++r) {
-          double acc = Xa[r][2 * NB];
+          for (int r = 0; r < NB; ++r) {
+            double acc = sp[(size_t)(r * NC + 2 * NB) * TS];
 #pragma unroll
-          for (int j = 0; j < NB; ++j) acc = __builtin_fma(-Xa[r][NB + j], dub[j], acc);
-          dua[r] = acc;
-        }
-        if (tid > 0) {
+            for (int j = 0; j < NB; ++j) acc = __builtin_fma(-sp[(size_t)(r * NC + NB + j) * TS], dub[j], acc);
+            dua[r] = acc;
+          }
+          if (tid > 0) {
 #pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            const double xl = xch[j * T + tid - 1];
+            for (int j = 0; j < NB; ++j) {
+              const double xl = xch[j * TS + tid - 1];
 #pragma unroll
-            for (int r = 0; r < NB; ++r) dua[r] = __builtin_fma(-Xa[r][j], xl, dua[r]);
+              for (int r = 0; r < NB; ++r) dua[r] = __builtin_fma(-sp[(size_t)(r * NC + j) * TS], xl, dua[r]);
+            }
           }
         }
         // ---- damping, update, convergence (oracle/pnp_physical.py: newton_step)
@@ -768,35 +815,52 @@ size_t newton_exchange_doubles(int nb, int nx) {   // both ping-pong buffers of 
   return 2 * (size_t)(2 * nb * nb + nb) * rs;
 }
 
-bool newton_exchange_in_lds(int nb, int nx) { return newton_exchange_doubles(nb, nx) * sizeof(double) <= kLdsBudget; }
+bool newton_exchange_in_lds(int nb, int nx) {
+  const char* e = getenv("CATINT_NEWTON_EXCHANGE");        // "global" keeps the row-per-thread kernel's buffers in device memory (tests)
+  if (e && e[0] == 'g') return false;
+  return newton_exchange_doubles(nb, nx) * sizeof(double) <= kLdsBudget;
+}
 
-// pair kernel: nx <= 2*T with T <= TMAX threads and the exchange buffer in LDS
-template <int NB>
-static constexpr int pair_tmax() { return NB <= 4 ? 512 : 256; }
-
+// pair kernel: nx <= 2*T threads, exchange buffer (2 NB^2 + NB) * TS doubles in LDS with a compile-time row stride
+// TS = 256 or 512; instantiated for N <= 4 species (larger blocks do not fit the register file, they take the
+// row-per-thread kernel)
 int newton_pair_threads(int nb, int nx) {
+  if (nb > 5) return 0;
   const int tmax = nb <= 4 ? 512 : 256;
   const int t = ((nx + 1) / 2 + 63) / 64 * 64;
   if (t > tmax) return 0;
-  if ((size_t)(2 * nb * nb + nb) * t * sizeof(double) > kLdsBudget) return 0;
+  const int ts = t <= 256 ? 256 : 512;
+  if ((size_t)(2 * nb * nb + nb) * ts * sizeof(double) > kLdsBudget) return 0;
   return t;
+}
+
+int newton_pair_stride(int nb, int nx) {
+  const int t = newton_pair_threads(nb, nx);
+  return t == 0 ? 0 : (t <= 256 ? 256 : 512);
+}
+
+template <int NB, int TS>
+static hipError_t launch_pair(const NewtonArgs& a, int blocks, int tp, hipStream_t stream) {
+  const size_t lds = (size_t)(2 * NB * NB + NB) * TS * sizeof(double);
+  if (a.mpb) {
+    (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((newton_pair_kernel<NB, TS, true>), dim3(blocks), dim3(tp), lds, stream, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((newton_pair_kernel<NB, TS, false>), dim3(blocks), dim3(tp), lds, stream, a);
+  }
+  return hipGetLastError();
 }
 
 template <int NB, int TMAX>
 static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t stream) {
   const char* force = getenv("CATINT_NEWTON_KERNEL");     // "generic" forces the row-per-thread kernel (tests)
   const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
-  if (tp > 0) {
-    const size_t lds = (size_t)(2 * NB * NB + NB) * tp * sizeof(double);
-    constexpr int TP = pair_tmax<NB>();
-    if (a.mpb) {
-      (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((newton_pair_kernel<NB, TP, true>), dim3(blocks), dim3(tp), lds, stream, a);
-    } else {
-      (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((newton_pair_kernel<NB, TP, false>), dim3(blocks), dim3(tp), lds, stream, a);
+  if constexpr (NB <= 5) {
+    if (tp > 0) {
+      if (tp <= 256) return launch_pair<NB, 256>(a, blocks, tp, stream);
+      if constexpr (NB <= 4) return launch_pair<NB, 512>(a, blocks, tp, stream);
     }
-    return hipGetLastError();
   }
   const int T = newton_threads(NB, a.nx);
   const size_t lds = a.work ? 0 : newton_exchange_doubles(NB, a.nx) * sizeof(double);
@@ -817,11 +881,11 @@ hipError_t launch_newton(const NewtonArgs& a, int blocks, hipStream_t stream) {
     case 2: return launch_newton_nb<2, 512>(a, blocks, stream);
     case 3: return launch_newton_nb<3, 512>(a, blocks, stream);
     case 4: return launch_newton_nb<4, 512>(a, blocks, stream);
-    case 5: return launch_newton_nb<5, 256>(a, blocks, stream);
-    case 6: return launch_newton_nb<6, 256>(a, blocks, stream);
-    case 7: return launch_newton_nb<7, 256>(a, blocks, stream);
-    case 8: return launch_newton_nb<8, 256>(a, blocks, stream);
-    case 9: return launch_newton_nb<9, 256>(a, blocks, stream);
+    case 5: return launch_newton_nb<5, 512>(a, blocks, stream);
+    case 6: return launch_newton_nb<6, 512>(a, blocks, stream);
+    case 7: return launch_newton_nb<7, 512>(a, blocks, stream);
+    case 8: return launch_newton_nb<8, 512>(a, blocks, stream);
+    case 9: return launch_newton_nb<9, 512>(a, blocks, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -82,6 +82,19 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
     return (c, phi, its, st), (ref_c, ref_phi, ref_it)
 
 
+def run_gpu_only(N, nx, B, seed):
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, seed)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    with _capi.PnpSolver(N, nx, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+        s.set_newton()
+        s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+        s.solve_stationary()
+        c, phi, _, _ = s.get_state()
+        return c, phi, s.newton_iterations()
+
+
 def assert_close(got, ref, rtol=2e-9):
     c, phi, its, st = got
     rc, rphi, rit = ref
@@ -111,6 +124,13 @@ def test_row_per_thread_kernel(N, nx, monkeypatch):
 def test_more_rows_than_threads(N, nx):
     got, ref = run_both(N, nx, B=3, seed=nx, points_per_debye=20.0)
     assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx", [(3, 512), (4, 100), (6, 96), (7, 50), (8, 40)])
+def test_bitwise_reproducible(N, nx):
+    a = run_gpu_only(N, nx, 4, 99)
+    b = run_gpu_only(N, nx, 4, 99)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
 def test_transient_steps_match_oracle():
