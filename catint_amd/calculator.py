@@ -19,8 +19,12 @@ from .host import pb_mode_from_bound
 from .units import unit_F
 
 CALC_LIST = ['FTCS', 'Crank-Nicolson', 'odeint', 'vode', 'lsoda', 'dopri5', 'dop853', 'odeint', 'odespy', 'comsol']
+CALC_LIST = CALC_LIST + ['Newton']
 GPU_CALCS = ('FTCS', 'Crank-Nicolson')
 MOL_CALCS = ('odeint', 'lsoda', 'dopri5', 'dop853')   # method of lines: scipy driver, RHS on the GPU
+# physical mode: what run_single_step asks COMSOL for (calculator.py:408-535, comsol_wrapper.py:145,158) solved on the
+# GPU by the fully implicit coupled Newton kernel; 'comsol' is accepted as its name so reference scripts keep working
+PHYSICAL_CALCS = ('comsol', 'Newton')
 
 
 class CalculatorError(ValueError):
@@ -40,7 +44,7 @@ def make_itout(nt, ntout):
 
 class Calculator(object):
     def __init__(self, transport=None, dt=None, tmax=None, ntout=1, calc=None, scale_pb_grid=None, tau_jacobi=1e-7,
-                 tau_scf=5e-5, mix_scf=0.5, mode='time-dependent', desc_method='external', device=0):
+                 tau_scf=5e-5, mix_scf=0.5, mode=None, desc_method='external', device=0):
         if transport is None:
             raise CalculatorError('No transport object provided for calculator.')
         self.tp = transport
@@ -66,9 +70,12 @@ class Calculator(object):
         self.calc = string[0]
         if self.calc not in CALC_LIST:
             raise CalculatorError('No calculator found with this name. Aborting.')
-        if self.calc not in GPU_CALCS + MOL_CALCS:
+        if self.calc not in GPU_CALCS + MOL_CALCS + PHYSICAL_CALCS:
             raise CalculatorError("calculator '%s' is not part of the MI355X transport path "
-                                  "(supported: %s)" % (self.calc, ', '.join(GPU_CALCS + MOL_CALCS)))
+                                  "(supported: %s)" % (self.calc, ', '.join(GPU_CALCS + MOL_CALCS + PHYSICAL_CALCS)))
+        self.physical = self.calc in PHYSICAL_CALCS
+        if self.mode is None:      # COMSOL studies default to ['stat'] (transport.py:811-812); the FD integrators are transient
+            self.mode = 'stationary' if self.physical else 'time-dependent'
         if scale_pb_grid is not None:
             raise CalculatorError('scale_pb_grid is broken in the reference (calculator_old.py:686-687) and not supported')
         self.scale_pb_grid = scale_pb_grid
@@ -184,6 +191,54 @@ class Calculator(object):
         self.status = 0
         return [np.array(sol[n, :]) for n in range(0, nt) if n in tp.itout and n < len(sol)]
 
+    # -- physical mode ---------------------------------------------------------------------------
+    def _physical_solver(self, B, nx=None, dx=None, dt=None):
+        """Handle of the implicit coupled solver with the boundary model of the COMSOL generator: Stern Robin wall
+        (tp.system['Stern capacitance'] in muF/cm^2, ['phiPZC']; comsol_model.py:613,:982,:1167), bulk potential 0 V
+        (:662-663), size-modified drift for species carrying 'MPB_radius' (:1041-1063).
+        tp.system['wall potential'] = 'dirichlet' switches the Stern layer off (phi(0) = phiM)."""
+        tp = self.tp
+        nk = getattr(tp, 'newton', {})
+        s = PnpSolver(nspecies=tp.nspecies, nx=tp.nx if nx is None else nx, dx=tp.dx if dx is None else dx,
+                      dt=tp.dt if dt is None else dt, beta=tp.beta, eps=tp.eps, D=tp.D, charges=tp.charges, method='Newton',
+                      pb_mode=0, batch_capacity=B, device=self.device)
+        radii = [float(tp.species[sp].get('MPB_radius', 0.0)) for sp in tp.species]
+        cs = float(tp.system.get('Stern capacitance', 0.0)) * 1e-2          # muF/cm^2 -> F/m^2
+        stern = tp.system.get('wall potential', 'stern') == 'stern' and cs > 0
+        s.set_newton(wall_bc='stern' if stern else 'dirichlet', stern_capacitance=cs if stern else 0.0,
+                     phi_pzc=float(tp.system.get('phiPZC', 0.0)), tol=nk.get('tol', 1e-8), maxit=nk.get('maxit', 50),
+                     dphi_max=nk.get('dphi_max', 0.05), mpb_radius=radii if any(radii) else None)
+        return s
+
+    def solve_physical(self, solver, c0, phiM, flux, nramp=8, warm=False):
+        """One transport solve of every lane (run_single_step, calculator.py:408-535).  Stationary mode: Newton from the
+        current state (warm) or from the bulk state; if lanes do not converge from the bulk state, all lanes are restarted
+        with phiM and the fluxes ramped up in `nramp` stages (the reference's flux_factor / PZC continuation,
+        transport.py:877-893, comsol_model.py:1147-1167).  Time-dependent mode: tp.nt-1 backward-Euler steps.
+        Returns status [B]."""
+        B = len(phiM)
+        pb = np.zeros((B, 4)); pb[:, 0] = phiM
+        vz = np.zeros(B)
+        if not warm:
+            solver.set_batch(c0, pb, vz, flux)
+        else:
+            solver.set_flux(flux)
+        if self.mode != 'stationary':
+            solver.step(self.tp.nt - 1)
+            return solver.get_status()
+        st = solver.solve_stationary()
+        if (st != 0).any() and nramp > 1 and not warm:
+            for j in range(1, nramp + 1):
+                w = j / float(nramp)
+                pbj = pb.copy(); pbj[:, 0] = phiM * w
+                if j == 1:
+                    solver.set_batch(c0, pbj, vz, flux * w)
+                else:
+                    solver.set_pb(pbj, vz)
+                    solver.set_flux(flux * w)
+                st = solver.solve_stationary()
+        return st
+
     # ------------------------------------------------------------------------------------------
     def run(self):
         """Descriptor sweep (calculator.py:196-240) with every descriptor point as one GPU lane.
@@ -205,7 +260,15 @@ class Calculator(object):
             vz[i] = system['vzeta']
         c0 = np.repeat(tp.c0[None, :], B, axis=0)
         flux = np.repeat(tp.flux_bound[None, :, 0], B, axis=0)
-        cout, status, (v, g, l) = self.integrate_pnp_batch(c0, pb, vz, flux)
+        if self.physical:
+            phiM = np.array([dict(tp.system, **{keys[0]: v1, keys[1]: v2})['phiM'] for (v1, v2) in lanes], float)
+            with self._physical_solver(B) as s:
+                status = self.solve_physical(s, c0, phiM, flux)
+                cfin, v, g, l = s.get_state()
+                self.newton_iterations = s.newton_iterations()
+            cout = cfin.reshape(1, B, tp.nspecies * tp.nx)
+        else:
+            cout, status, (v, g, l) = self.integrate_pnp_batch(c0, pb, vz, flux)
         self.status = status
         names = list(tp.species.keys())
         for i in range(B):
@@ -271,9 +334,10 @@ class Calculator(object):
         solver = None
         c0 = np.repeat(tp.c0[None, :], B, axis=0)
         if transport_fn is None:
-            solver = self._solver(B, pb_mode_from_bound(pb[0]), tp.dx, tp.nx, tp.dt)
+            solver = self._physical_solver(B) if self.physical else self._solver(B, pb_mode_from_bound(pb[0]), tp.dx, tp.nx, tp.dt)
         istep = 0
         history = []
+        restart = False
         try:
             while active.any() and istep < max_iter:       # :316
                 istep += 1
@@ -299,6 +363,19 @@ class Calculator(object):
                 if transport_fn is not None:                                                # :385 run_single_step
                     cs, vs, es = transport_fn(flux)
                     status = np.zeros(B, np.int32)
+                elif self.physical:
+                    # warm start from the previous SCF iterate (restart=True of comsol.run, calculator.py:523)
+                    warm = istep > 1 and self.mode == 'stationary' and not restart
+                    status = self.solve_physical(solver, c0, phiM, flux, nramp=1 if istep > 1 else 8, warm=warm)
+                    cs, vs, es = solver.get_surface()
+                    # Wall fluxes that would drive a concentration negative have no solution inside the positive cone the
+                    # damped Newton stays in: COMSOL hands the SCF loop a negative surface concentration there
+                    # (calculator.py:328-344 falls back to the previous iterate); a lane that did not converge is reported
+                    # the same way, and the next solve starts again from the bulk state
+                    stuck = status == 1
+                    cs = np.where(stuck[:, None], -1.0, cs)
+                    restart = bool(stuck.any() or (status == 2).any())
+                    status = np.where(stuck, 0, status)
                 else:
                     solver.set_batch(c0, pb, vz, flux)
                     n_first = 1 if self.calc == 'Crank-Nicolson' else 0
