@@ -79,9 +79,11 @@ def test_charge_parser_and_errors():
     tp = Transport()
     with pytest.raises(CalculatorError):
         Calculator(transport=tp, calc='nonsense', dt=1e-10, tmax=1e-9)
-    for broken in ('vode', 'odespy', 'comsol'):     # not runnable in the reference either / external binary
+    for broken in ('vode', 'odespy'):     # not runnable in the reference either
         with pytest.raises(CalculatorError):
             Calculator(transport=tp, calc=broken, dt=1e-10, tmax=1e-9)
+    phys = Calculator(transport=tp, calc='comsol')          # the production path's name selects the implicit GPU mode
+    assert phys.physical and phys.mode == 'stationary'
     with pytest.raises(CalculatorError):
         Calculator(transport=None, calc='FTCS')
     with pytest.raises(ValueError):
