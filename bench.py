@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--large-batch', type=int, default=8192,
                     help='extra (non-headline) timed run at this batch size to show the oversubscribed regime; 0 = skip')
+    ap.add_argument('--physical-steps', type=int, default=20,
+                    help='extra (non-headline) timed run of the implicit physical mode (coupled Newton, block cyclic reduction) '
+                         'on the same workload shape; 0 = skip')
     ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'hbm_traffic_latest.json'),
                     help='rocprofv3 PMC result (tools/pmc_traffic.py) for this workload; merged into roofline.traffic')
     return ap.parse_args()
@@ -91,6 +94,47 @@ def cpu_reference_faithful(prob, c0, pb, vz, fl, method):
     for i in range(n):
         R.cn_step(C, COLD, C0, p, first=(i == 0), solver='dense')
     return n / (time.perf_counter() - t0)
+
+
+def physical_mode(args, device, with_cpu):
+    """Implicit physical mode (PNP_METHOD_NEWTON) on the headline shape with SURVEY 8(d)'s synthetic inputs:
+    phiM ~ U(-0.2, 0.2) V, dt = 0.1 lambda_D L / D_max, Newton to a scaled update of 1e-8."""
+    from catint_amd import _capi
+    from catint_amd.synthetic import make_batch
+    B, N, nx = args.batch, args.nspecies, args.nx
+    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=4242, phi_max=0.2, dt_factor=0.1)
+    pb = np.nan_to_num(pb)
+    s = _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=B,
+                        device=device)
+    s.set_newton(tol=1e-8)
+    s.set_batch(c0, pb, vz, fl)
+    s.step(5)
+    s.synchronize()
+    s.timer_start()
+    s.step(args.physical_steps)
+    ms = s.timer_stop()
+    it = s.newton_iterations()
+    ok = int((s.get_status() == 0).sum())
+    s.close()
+    sec = ms * 1e-3
+    # fp64 VALU instructions per Newton iteration and lane of the pair kernel for N = 3 (static count of the ISA,
+    # tools/probe/census_newton.py: 256 threads x (760 + 552 + 8 x 288 + 100)); peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+    out = {'workload': 'batch=%d, %d species, %d points, backward Euler dt=%.3g s, Dirichlet wall, tol 1e-8' % (B, N, nx, prob.dt),
+           'timesteps_per_s': B * args.physical_steps / sec, 'newton_iterations_per_s': float(it.sum()) / sec,
+           'mean_newton_iterations_per_step': float(it.sum()) / (B * args.physical_steps),
+           'ms_per_step': ms / args.physical_steps, 'lanes_ok': ok, 'bound': 'fp64 VALU issue / LDS exchange (not HBM)'}
+    if N == 3 and nx <= 512:
+        out['fp64_valu_util'] = 256 * 3716.0 * out['newton_iterations_per_s'] / (256 * 4 * 16 * 2.4e9)
+    if with_cpu:
+        from oracle import pnp_physical as PH
+        nl, ns = 2, 2
+        t0 = time.perf_counter()
+        for b in range(nl):
+            p = PH.PhysicalProblem(D=prob.D, charges=prob.charges, beta=prob.beta, eps=prob.eps, dx=prob.dx, nx=nx,
+                                   c_bulk=c0[b].reshape(N, nx)[:, -1], phiM=pb[b, 0])
+            PH.integrate(p, c0[b].reshape(N, nx), np.zeros(nx), prob.dt, ns, tol=1e-8)
+        out['cpu_port_timesteps_per_s_1core'] = nl * ns / (time.perf_counter() - t0)
+    return out
 
 
 def main():
@@ -231,6 +275,8 @@ def main():
             out['per_step_launch'] = fused
         if large:
             out['large_batch'] = large
+        if world == 1 and args.physical_steps > 0:
+            out['physical_mode'] = physical_mode(args, device, not args.no_cpu_baseline)
         if gather_ms is not None:
             out['gather_ms'] = gather_ms
         if world == 1 and not args.no_cpu_baseline:

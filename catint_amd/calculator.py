@@ -208,6 +208,12 @@ class Calculator(object):
         s.set_newton(wall_bc='stern' if stern else 'dirichlet', stern_capacitance=cs if stern else 0.0,
                      phi_pzc=float(tp.system.get('phiPZC', 0.0)), tol=nk.get('tol', 1e-8), maxit=nk.get('maxit', 50),
                      dphi_max=nk.get('dphi_max', 0.05), mpb_radius=radii if any(radii) else None)
+        if getattr(tp, 'use_reactions', False) and getattr(tp, 'reactions', None):      # tp.reactions[r]['reactants'], ['rates']
+            names = list(tp.species.keys())
+            s.set_reactions([([names.index(x) for x in rx['reactants'][0] if x in names],
+                              [names.index(x) for x in rx['reactants'][1] if x in names],
+                              float(rx['rates'][0]), float(rx['rates'][1]))
+                             for rx in tp.reactions.values() if 'rates' in rx])
         return s
 
     def solve_physical(self, solver, c0, phiM, flux, nramp=8, warm=False):

@@ -40,6 +40,7 @@ struct pnp_handle {
   double* c_old = nullptr;
   double* work = nullptr;
   double* stash = nullptr;
+  ReactionTable* rt_dev = nullptr;
   int64_t stash_stride = 0;
   int32_t* iters = nullptr;
   int nw_blocks = 0;
@@ -83,7 +84,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -262,9 +263,7 @@ int pnp_set_reactions(pnp_handle* h, int32_t nreactions, const int32_t* n_lhs, c
                       const int32_t* rhs, const double* kf, const double* kr) {
   if (!h) return PNP_EINVAL;
   if (nreactions < 0 || nreactions > PNP_MAX_REACTIONS) return fail(h, PNP_EINVAL, "pnp_set_reactions: too many reactions");
-  if (nreactions > 0 && h->newton)
-    return fail(h, PNP_EINVAL, "pnp_set_reactions: homogeneous reactions are not implemented in the physical mode yet");
-  if (nreactions > 0 && h->cfg.method != PNP_METHOD_FTCS)
+  if (nreactions > 0 && h->cfg.method != PNP_METHOD_FTCS && !h->newton)
     return fail(h, PNP_EINVAL, "pnp_set_reactions: only FTCS has a rate term (calculator_old.py:1022; CN has none)");
   ReactionTable& rt = h->rt;
   memset(&rt, 0, sizeof(rt));
@@ -286,6 +285,15 @@ int pnp_set_reactions(pnp_handle* h, int32_t nreactions, const int32_t* n_lhs, c
     }
     rt.kf[r] = kf[r];
     rt.kr[r] = kr[r];
+  }
+  if (h->newton) {
+    // physical mode: mass action in activities with every reaction summed (comsol_model.py:781-867); the table lives
+    // in device memory and is read by the assembly
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->rt_dev) HIP_TRY(h, dev_alloc(h, &h->rt_dev, 1));
+    HIP_TRY(h, hipMemcpyAsync(h->rt_dev, &rt, sizeof(rt), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PNP_OK;
   }
   if (nreactions > 0 && !h->rates) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -431,9 +439,11 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
     a.fl[k] = dx / h->Dk[k];
     a.peq[k] = dx * dx / eps * h->qk[k];
     a.vol[k] = h->volk[k];
+    a.rs[k] = dx * dx / h->Dk[k];
     if (fabs(h->qk[k]) > qmax) qmax = fabs(h->qk[k]);
   }
   a.vt_inv = beta * qmax;
+  a.rt = (h->rt_dev && h->rt.n > 0) ? h->rt_dev : nullptr;
   a.c = h->c;
   a.c_old = h->c_old;
   a.phi = h->v;

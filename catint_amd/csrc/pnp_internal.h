@@ -110,6 +110,8 @@ struct NewtonArgs {
   double fl[PNP_NEWTON_MAX_SPECIES];     // dx/D_k      (scales the wall flux)
   double peq[PNP_NEWTON_MAX_SPECIES];    // dx^2/eps*q_k
   double vol[PNP_NEWTON_MAX_SPECIES];    // N_A a_k^3   (MPB, comsol_model.py:1041-1063)
+  double rs[PNP_NEWTON_MAX_SPECIES];     // dx^2/D_k    (scales the reaction source)
+  const struct ReactionTable* rt;        // device copy of the mass-action table, or null
   double* c;                             // [B][N][ldx] state = Newton iterate, in place
   double* c_old;                         // [B][N][ldx] previous time level
   double* phi;                           // [B][ldx]

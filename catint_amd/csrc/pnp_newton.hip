@@ -199,33 +199,36 @@ __device__ __forceinline__ Edge edge_flux(double u, double cl, double cr) {
 }
 
 // State of one grid point as the assembly needs it: concentrations, potential and (MPB) w = -ln(1-phi0), dw/dc_j.
-template <int N, bool MPB>
+template <int N, int MODE>
 struct Point {
-  double c[N], phi, w, g[N];
+  double c[N], phi, w, g[N], gam;     // gam = 1/(1-phi0): activity coefficient (comsol_model.py:1060)
 };
 
-template <int N, bool MPB>
-__device__ __forceinline__ Point<N, MPB> load_point(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ phi,
+template <int N, int MODE>
+__device__ __forceinline__ Point<N, MODE> load_point(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ phi,
                                                    int i) {
-  Point<N, MPB> P;
+  constexpr bool MPB = MODE >= 1;
+  Point<N, MODE> P;
   P.phi = phi[i];
 #pragma unroll
   for (int k = 0; k < N; ++k) P.c[k] = c[k * A.ldx + i];
   P.w = 0.0;
+  P.gam = 1.0;
   if constexpr (MPB) {
     double f = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) f = __builtin_fma(A.vol[k], P.c[k], f);
     P.w = -log1p(-f);
     const double inv = 1.0 / (1.0 - f);
+    P.gam = inv;
 #pragma unroll
     for (int k = 0; k < N; ++k) P.g[k] = A.vol[k] * inv;
   }
   return P;
 }
 
-template <int N, bool MPB>
-__device__ __forceinline__ void edge_fluxes(const NewtonArgs& A, const Point<N, MPB>& Pl, const Point<N, MPB>& Pr, Edge (&e)[N]) {
+template <int N, int MODE>
+__device__ __forceinline__ void edge_fluxes(const NewtonArgs& A, const Point<N, MODE>& Pl, const Point<N, MODE>& Pr, Edge (&e)[N]) {
   const double dphi = Pr.phi - Pl.phi, dw = Pr.w - Pl.w;
 #pragma unroll
   for (int k = 0; k < N; ++k) e[k] = edge_flux(A.qb[k] * dphi + dw, Pl.c[k], Pr.c[k]);
@@ -236,14 +239,16 @@ __device__ __forceinline__ void edge_fluxes(const NewtonArgs& A, const Point<N, 
 // (oracle/pnp_physical.py: residual_and_jacobian; same scaling: species rows dx^2/D_k, Poisson row dx^2/eps).
 // At the wall the left edge, at the bulk both edges are switched off by 0/1 weights (their values are finite: the
 // neighbour index is clamped).
-template <int NB, bool MPB>
+template <int NB, int MODE>
 __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __restrict__ co, const double* __restrict__ flux,
                                          const double* __restrict__ cb, double phiM, double phiB, int i,
-                                         const Point<NB - 1, MPB>& Pm, const Point<NB - 1, MPB>& P0,
-                                         const Point<NB - 1, MPB>& Pp, const Edge (&em)[NB - 1], const Edge (&ep)[NB - 1],
+                                         const Point<NB - 1, MODE>& Pm, const Point<NB - 1, MODE>& P0,
+                                         const Point<NB - 1, MODE>& Pp, const Edge (&em)[NB - 1], const Edge (&ep)[NB - 1],
                                          double (&M)[NB][NB], double (&X)[NB][2 * NB + 1]) {
   constexpr int N = NB - 1;
   constexpr int NC = 2 * NB + 1;
+  constexpr bool MPB = MODE >= 1;
+  constexpr bool REACT = MODE == 2;
   const int nx = A.nx, ldx = A.ldx;
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
@@ -257,6 +262,54 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
   const double wm = (wall || bulk) ? 0.0 : 1.0;
   const double ws = bulk ? 0.0 : (wall ? 0.5 : 1.0);
   const double wf = wall ? 1.0 : 0.0;
+  // homogeneous reactions: mass action in activities a_j = c_j gam, every reaction summed
+  // (comsol_model.py:781-867, :1064-1084; oracle/pnp_physical.py: reaction_rates).  The species indices of the table
+  // are run-time values, so this block works on small thread-private arrays (scratch memory).
+  double Rk[N], dR[N][N];
+  if constexpr (REACT) {
+    const ReactionTable* __restrict__ rt = A.rt;
+    double cl[N], gl[N], dprod[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      cl[k] = P0.c[k];
+      gl[k] = P0.g[k];
+      Rk[k] = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) dR[k][j] = 0.0;
+    }
+    const int nr = rt->n;
+    for (int r = 0; r < nr; ++r) {
+      const int nl = rt->n_lhs[r], nrh = rt->n_rhs[r];
+      for (int side = 0; side < 2; ++side) {
+        const int n = side == 0 ? nl : nrh;
+        const int32_t* idx = side == 0 ? rt->lhs[r] : rt->rhs[r];
+        const double kk = side == 0 ? rt->kf[r] : rt->kr[r];
+        if (kk == 0.0 || n == 0) continue;
+        double pre = kk;
+        for (int a = 0; a < n; ++a) pre *= P0.gam;
+        double prod = pre;
+        for (int a = 0; a < n; ++a) prod *= cl[idx[a]];
+        for (int j = 0; j < N; ++j) dprod[j] = prod * n * gl[j];     // through gam; gl = 0 for point ions
+        for (int a = 0; a < n; ++a) {
+          double rest = pre;
+          for (int b2 = 0; b2 < n; ++b2)
+            if (b2 != a) rest *= cl[idx[b2]];
+          dprod[idx[a]] += rest;
+        }
+        const double sgn = side == 0 ? 1.0 : -1.0;                    // forward minus backward
+        for (int a = 0; a < nl; ++a) {
+          const int j = rt->lhs[r][a];
+          Rk[j] -= sgn * prod;
+          for (int jj = 0; jj < N; ++jj) dR[j][jj] -= sgn * dprod[jj];
+        }
+        for (int a = 0; a < nrh; ++a) {
+          const int j = rt->rhs[r][a];
+          Rk[j] += sgn * prod;
+          for (int jj = 0; jj < N; ++jj) dR[j][jj] += sgn * dprod[jj];
+        }
+      }
+    }
+  }
   double rho = 0.0;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -280,6 +333,12 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
         X[k][NB + j] += Jup * Pp.g[j];
         X[k][j] += Jum * Pm.g[j];
       }
+    }
+    if constexpr (REACT) {       // source term on the (half) cell: -(dx^2/D_k) R_k, none on the bulk Dirichlet row
+      const double wr = ws * A.rs[k];
+      X[k][2 * NB] += wr * Rk[k];
+#pragma unroll
+      for (int j = 0; j < N; ++j) M[k][j] -= wr * dR[k][j];
     }
   }
   const double p0 = P0.phi, pp = Pp.phi, pm = Pm.phi;
@@ -305,7 +364,7 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
   }
 }
 
-template <int NB, bool MPB>
+template <int NB, int MODE>
 __device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ co,
                                              const double* __restrict__ phi, const double* __restrict__ flux,
                                              const double* __restrict__ cb, double phiM, double phiB, int i,
@@ -313,13 +372,13 @@ __device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* 
   constexpr int N = NB - 1;
   const int im = i > 0 ? i - 1 : 0;
   const int ip = i < A.nx - 1 ? i + 1 : A.nx - 1;
-  const Point<N, MPB> Pm = load_point<N, MPB>(A, c, phi, im);
-  const Point<N, MPB> P0 = load_point<N, MPB>(A, c, phi, i);
-  const Point<N, MPB> Pp = load_point<N, MPB>(A, c, phi, ip);
+  const Point<N, MODE> Pm = load_point<N, MODE>(A, c, phi, im);
+  const Point<N, MODE> P0 = load_point<N, MODE>(A, c, phi, i);
+  const Point<N, MODE> Pp = load_point<N, MODE>(A, c, phi, ip);
   Edge em[N], ep[N];
-  edge_fluxes<N, MPB>(A, Pm, P0, em);
-  edge_fluxes<N, MPB>(A, P0, Pp, ep);
-  fill_row<NB, MPB>(A, co, flux, cb, phiM, phiB, i, Pm, P0, Pp, em, ep, M, X);
+  edge_fluxes<N, MODE>(A, Pm, P0, em);
+  edge_fluxes<N, MODE>(A, P0, Pp, ep);
+  fill_row<NB, MODE>(A, co, flux, cb, phiM, phiB, i, Pm, P0, Pp, em, ep, M, X);
 }
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -334,9 +393,10 @@ __device__ __forceinline__ double wave_max(double v) {
 // 512-register budget (bound 256) the N >= 6 instances spilled into the accumulator half of the register file and
 // then produced run-to-run different, sometimes wrong, solutions on MI355X (tools/probe/repro_newton.py); with 256
 // they are bitwise reproducible.  The larger blocks pay with scratch traffic instead.
-template <int NB, int TMAX, bool MPB>
+template <int NB, int TMAX, int MODE>
 __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
   constexpr int N = NB - 1;
+  constexpr bool MPB = MODE >= 1;
   constexpr int NE = 2 * NB * NB + NB;
   extern __shared__ double newton_lds[];
   __shared__ double red[2][16];
@@ -360,7 +420,7 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
       for (; it <= A.maxit; ++it) {
         for (int row = tid; row < nx; row += T) {
           double M[NB][NB], X[NB][2 * NB + 1];
-          assemble_row<NB, MPB>(A, c, co, phi, flux, cb, phiM, phiB, row, M, X);
+          assemble_row<NB, MODE>(A, c, co, phi, flux, cb, phiM, phiB, row, M, X);
           block_solve<NB, 2 * NB + 1, true>(M, X);
           store_row<NB>(buf0, RS, row, X);
         }
@@ -511,9 +571,10 @@ __device__ __forceinline__ void mm_sub(double (&acc)[NB][NC], int c0, const doub
       for (int j = 0; j < NB; ++j) acc[r][c0 + cc] = __builtin_fma(-A[r][j], Q[j][cc], acc[r][c0 + cc]);
 }
 
-template <int NB, int TS, bool MPB>
+template <int NB, int TS, int MODE>
 __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
   constexpr int N = NB - 1;
+  constexpr bool MPB = MODE >= 1;
   constexpr int NC = 2 * NB + 1;
   extern __shared__ double newton_lds[];
   __shared__ double red[2][16];
@@ -543,16 +604,16 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
           const int last = nx - 1;
           const int i0 = ra > 0 ? (ra - 1 < last ? ra - 1 : last) : 0;
           const int i1 = ra < last ? ra : last, i2 = rb < last ? rb : last, i3 = rb + 1 < last ? rb + 1 : last;
-          const Point<N, MPB> P0 = load_point<N, MPB>(A, c, phi, i0);
-          const Point<N, MPB> P1 = load_point<N, MPB>(A, c, phi, i1);
-          const Point<N, MPB> P2 = load_point<N, MPB>(A, c, phi, i2);
-          const Point<N, MPB> P3 = load_point<N, MPB>(A, c, phi, i3);
+          const Point<N, MODE> P0 = load_point<N, MODE>(A, c, phi, i0);
+          const Point<N, MODE> P1 = load_point<N, MODE>(A, c, phi, i1);
+          const Point<N, MODE> P2 = load_point<N, MODE>(A, c, phi, i2);
+          const Point<N, MODE> P3 = load_point<N, MODE>(A, c, phi, i3);
           Edge e0[N], e1[N], e2[N];
-          edge_fluxes<N, MPB>(A, P0, P1, e0);
-          edge_fluxes<N, MPB>(A, P1, P2, e1);
-          edge_fluxes<N, MPB>(A, P2, P3, e2);
+          edge_fluxes<N, MODE>(A, P0, P1, e0);
+          edge_fluxes<N, MODE>(A, P1, P2, e1);
+          edge_fluxes<N, MODE>(A, P2, P3, e2);
           if (ra < nx) {
-            fill_row<NB, MPB>(A, co, flux, cb, phiM, phiB, ra, P0, P1, P2, e0, e1, Ma, Xa);
+            fill_row<NB, MODE>(A, co, flux, cb, phiM, phiB, ra, P0, P1, P2, e0, e1, Ma, Xa);
             block_solve<NB, NC, true>(Ma, Xa);
           } else {
 #pragma unroll
@@ -562,7 +623,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
           }
           lds_store_row<NB, TS>(xch, tid, Xa);
           if (rb < nx) {
-            fill_row<NB, MPB>(A, co, flux, cb, phiM, phiB, rb, P1, P2, P3, e1, e2, Mb, Xb);
+            fill_row<NB, MODE>(A, co, flux, cb, phiM, phiB, rb, P1, P2, P3, e1, e2, Mb, Xb);
           } else {
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
@@ -842,12 +903,16 @@ int newton_pair_stride(int nb, int nx) {
 template <int NB, int TS>
 static hipError_t launch_pair(const NewtonArgs& a, int blocks, int tp, hipStream_t stream) {
   const size_t lds = (size_t)(2 * NB * NB + NB) * TS * sizeof(double);
-  if (a.mpb) {
-    (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((newton_pair_kernel<NB, TS, true>), dim3(blocks), dim3(tp), lds, stream, a);
+  // variants: 0 point ions, 1 steric (MPB) drift, 2 steric drift + homogeneous reactions (point ions: zero volumes)
+  if (a.rt) {
+    (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((newton_pair_kernel<NB, TS, 2>), dim3(blocks), dim3(tp), lds, stream, a);
+  } else if (a.mpb) {
+    (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((newton_pair_kernel<NB, TS, 1>), dim3(blocks), dim3(tp), lds, stream, a);
   } else {
-    (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((newton_pair_kernel<NB, TS, false>), dim3(blocks), dim3(tp), lds, stream, a);
+    (void)hipFuncSetAttribute((const void*)newton_pair_kernel<NB, TS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((newton_pair_kernel<NB, TS, 0>), dim3(blocks), dim3(tp), lds, stream, a);
   }
   return hipGetLastError();
 }
@@ -864,14 +929,18 @@ static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t 
   }
   const int T = newton_threads(NB, a.nx);
   const size_t lds = a.work ? 0 : newton_exchange_doubles(NB, a.nx) * sizeof(double);
-  if (a.mpb) {
+  if (a.rt) {
     if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((newton_kernel<NB, TMAX, true>), dim3(blocks), dim3(T), lds, stream, a);
+      (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((newton_kernel<NB, TMAX, 2>), dim3(blocks), dim3(T), lds, stream, a);
+  } else if (a.mpb) {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((newton_kernel<NB, TMAX, 1>), dim3(blocks), dim3(T), lds, stream, a);
   } else {
     if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((newton_kernel<NB, TMAX, false>), dim3(blocks), dim3(T), lds, stream, a);
+      (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((newton_kernel<NB, TMAX, 0>), dim3(blocks), dim3(T), lds, stream, a);
   }
   return hipGetLastError();
 }

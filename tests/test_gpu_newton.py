@@ -44,7 +44,7 @@ def make_lanes(N, nx, B, seed, phi_lo=-0.15, phi_hi=0.15, points_per_debye=6.0, 
     return D, q, cb, dx, phiM
 
 
-def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None, flux=None, **lane_kw):
+def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None, flux=None, reactions=None, **lane_kw):
     newton_kw = dict(newton_kw or {})
     D, q, cb, dx, phiM = make_lanes(N, nx, B, seed, **lane_kw)
     c0 = np.repeat(cb[:, :, None], nx, axis=2)
@@ -53,6 +53,8 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
     fl = np.zeros((B, N)) if flux is None else flux
     s = _capi.PnpSolver(N, nx, dx, dt if dt else 1.0, BETA, EPS, D, q, method='Newton', pb_mode=_capi.PB_DD, batch_capacity=B)
     s.set_newton(**newton_kw)
+    if reactions:
+        s.set_reactions([(r['lhs'], r['rhs'], r['kf'], r['kr']) for r in reactions])
     s.set_batch(c0, pb, np.zeros(B), fl)
     if stationary:
         st = s.solve_stationary()
@@ -69,7 +71,7 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
     for b in range(B):
         p = PH.PhysicalProblem(D=D, charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=cb[b], phiM=phiM[b], flux=fl[b],
                                stern_capacitance=newton_kw.get('stern_capacitance') if newton_kw.get('wall_bc') == 'stern' else None,
-                               phi_pzc=newton_kw.get('phi_pzc', 0.0), mpb_radius=newton_kw.get('mpb_radius'))
+                               phi_pzc=newton_kw.get('phi_pzc', 0.0), mpb_radius=newton_kw.get('mpb_radius'), reactions=reactions)
         cc, ph = c0[b].copy(), np.zeros(nx)
         if stationary:
             cc, ph, it, _ = PH.newton_step(p, cc, ph, cc, np.inf, **okw)
@@ -156,6 +158,28 @@ def test_wall_fluxes():
     B, N = 4, 3
     flux = rng.uniform(-2e-4, 2e-4, (B, N))
     got, ref = run_both(N, 96, B=B, seed=13, flux=flux)
+    assert_close(got, ref)
+
+
+def test_homogeneous_reactions_point_ions():
+    # K+ / HCO3- / CO3^2- style buffer: species 1 <-> species 4 exchange plus a dimerisation, bulk out of equilibrium
+    rx = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [2, 2], 'rhs': [3], 'kf': 3e3, 'kr': 0.0},
+          {'lhs': [0, 1], 'rhs': [3], 'kf': 1e3, 'kr': 2e4}]
+    got, ref = run_both(4, 120, B=4, seed=31, reactions=rx, points_per_debye=2.0)
+    assert_close(got, ref)
+
+
+def test_homogeneous_reactions_with_steric_ions_and_stern_layer():
+    rx = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [0, 2], 'rhs': [1], 'kf': 2e3, 'kr': 1e4}]
+    got, ref = run_both(3, 200, B=5, seed=37, reactions=rx, phi_lo=-1.0, phi_hi=0.8, cref=100.0,
+                        newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=[4.1e-10, 3e-10, 0.0], maxit=60))
+    assert_close(got, ref)
+
+
+def test_reactions_in_the_row_per_thread_kernel(monkeypatch):
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'generic')
+    rx = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [0, 2, 2], 'rhs': [4, 5], 'kf': 5.0, 'kr': 1e2}]
+    got, ref = run_both(6, 64, B=3, seed=41, reactions=rx, dt=1e-7, nsteps=3, stationary=False)
     assert_close(got, ref)
 
 
