@@ -33,7 +33,7 @@ SYMBOLS = [
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
-    'pnp_set_potential',
+    'pnp_set_potential', 'pnp_set_wall_kinetics',
 ]
 
 
@@ -105,6 +105,8 @@ def load_library():
     lib.pnp_solve_stationary.argtypes = [vp, C.c_double, C.c_int32, ip]
     lib.pnp_get_newton_iterations.argtypes = [vp, ip]
     lib.pnp_set_potential.argtypes = [vp, dp]
+    lib.pnp_set_wall_kinetics.argtypes = [vp, C.c_int32, ip, dp, dp]
+    lib.pnp_set_wall_kinetics.restype = C.c_int
     for name in ('pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations', 'pnp_set_potential'):
         getattr(lib, name).restype = C.c_int
     for name in ('pnp_set_species', 'pnp_set_reactions', 'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step',
@@ -221,6 +223,17 @@ class PnpSolver(object):
                             float(stern_capacitance), float(phi_pzc), float(tol), float(dphi_max))
         r = None if mpb_radius is None else _f64(mpb_radius, (self.N,))
         self._check(self._lib.pnp_set_newton(self._h, C.byref(p), _dptr(r)))
+
+    def set_wall_kinetics(self, species, nu, k):
+        """First-order surface reactions coupled implicitly: species [n] (index, -1 = zeroth order), nu [n][N] stoichiometry
+        of the flux into the domain, k [B][n] rate constants per lane.  Empty lists remove the table."""
+        n = len(species)
+        if n == 0:
+            self._check(self._lib.pnp_set_wall_kinetics(self._h, 0, None, None, None))
+            return
+        sp = np.ascontiguousarray(species, dtype=np.int32)
+        self._check(self._lib.pnp_set_wall_kinetics(self._h, n, _iptr(sp), _dptr(_f64(nu, (n, self.N))),
+                                                    _dptr(_f64(k, (self.B, n)))))
 
     def solve_stationary(self, tol=0.0, maxit=0):
         st = np.zeros(self.B, np.int32)

@@ -216,6 +216,40 @@ class Calculator(object):
                              for rx in tp.reactions.values() if 'rates' in rx])
         return s
 
+    def set_surface_kinetics(self, reactions):
+        """First-order electrode kinetics solved WITH the transport instead of around it (physical mode only):
+        reactions = [{'species': name (or None: zeroth order), 'rate': K(phiM[B]) -> [B] in m/s (mol m^-2 s^-1 if zeroth order),
+        'stoichiometry': {species name: nu}}], flux into the electrolyte nu*K*c_species(x=0) (educts negative,
+        calculator.py:415-432).  One stationary solve then returns what run_scf_cycle iterates towards."""
+        if not self.physical:
+            raise CalculatorError('surface kinetics are part of the physical mode (calc="comsol")')
+        self.surface_kinetics = list(reactions)
+
+    def _apply_surface_kinetics(self, solver, phiM):
+        rx = getattr(self, 'surface_kinetics', None)
+        if not rx:
+            return
+        names = list(self.tp.species.keys())
+        species = [names.index(r['species']) if r.get('species') is not None else -1 for r in rx]
+        nu = np.zeros((len(rx), len(names)))
+        for i, r in enumerate(rx):
+            for sp, v in r['stoichiometry'].items():
+                nu[i, names.index(sp)] = v
+        k = np.stack([np.broadcast_to(np.asarray(r['rate'](phiM) if callable(r['rate']) else r['rate'], float), phiM.shape)
+                      for r in rx], axis=1)
+        solver.set_wall_kinetics(species, nu, k)
+
+    def surface_kinetic_fluxes(self, csurf, phiM):
+        """Flux [B][N] into the electrolyte implied by set_surface_kinetics at the surface state csurf [B][N]."""
+        names = list(self.tp.species.keys())
+        out = np.zeros_like(csurf)
+        for r in getattr(self, 'surface_kinetics', []):
+            K = np.broadcast_to(np.asarray(r['rate'](phiM) if callable(r['rate']) else r['rate'], float), phiM.shape)
+            cs = csurf[:, names.index(r['species'])] if r.get('species') is not None else 1.0
+            for sp, v in r['stoichiometry'].items():
+                out[:, names.index(sp)] += v * K * cs
+        return out
+
     def solve_physical(self, solver, c0, phiM, flux, nramp=8, warm=False):
         """One transport solve of every lane (run_single_step, calculator.py:408-535).  Stationary mode: Newton from the
         current state (warm) or from the bulk state; if lanes do not converge from the bulk state, all lanes are restarted
@@ -227,6 +261,7 @@ class Calculator(object):
         vz = np.zeros(B)
         if not warm:
             solver.set_batch(c0, pb, vz, flux)
+            self._apply_surface_kinetics(solver, np.asarray(phiM, float))
         else:
             solver.set_flux(flux)
         if self.mode != 'stationary':
@@ -272,6 +307,8 @@ class Calculator(object):
                 status = self.solve_physical(s, c0, phiM, flux)
                 cfin, v, g, l = s.get_state()
                 self.newton_iterations = s.newton_iterations()
+                if getattr(self, 'surface_kinetics', None):
+                    self.kinetic_flux = self.surface_kinetic_fluxes(cfin[:, :, 0], phiM)
             cout = cfin.reshape(1, B, tp.nspecies * tp.nx)
         else:
             cout, status, (v, g, l) = self.integrate_pnp_batch(c0, pb, vz, flux)

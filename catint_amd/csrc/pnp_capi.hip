@@ -41,6 +41,10 @@ struct pnp_handle {
   double* work = nullptr;
   double* stash = nullptr;
   ReactionTable* rt_dev = nullptr;
+  int n_wk = 0;
+  int32_t wk_species[PNP_MAX_WALL_REACTIONS] = {0};
+  double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES] = {{0}};
+  double* wk_k = nullptr;
   int64_t stash_stride = 0;
   int32_t* iters = nullptr;
   int nw_blocks = 0;
@@ -84,7 +88,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -163,6 +167,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
     HIP_TRYC(dev_alloc(h, &h->c_old, (size_t)Bc * N * ldx));
     HIP_TRYC(dev_alloc(h, &h->v, (size_t)Bc * ldx));
     HIP_TRYC(dev_alloc(h, &h->iters, (size_t)Bc));
+    HIP_TRYC(dev_alloc(h, &h->wk_k, (size_t)Bc * PNP_MAX_WALL_REACTIONS));
     const int nb = N + 1;
     if (!newton_exchange_in_lds(nb, cfg->nx)) {
       const size_t slice = newton_exchange_doubles(nb, cfg->nx);
@@ -444,6 +449,10 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   }
   a.vt_inv = beta * qmax;
   a.rt = (h->rt_dev && h->rt.n > 0) ? h->rt_dev : nullptr;
+  a.n_wk = h->n_wk;
+  memcpy(a.wk_species, h->wk_species, sizeof(a.wk_species));
+  memcpy(a.wk_nu, h->wk_nu, sizeof(a.wk_nu));
+  a.wk_k = h->wk_k;
   a.c = h->c;
   a.c_old = h->c_old;
   a.phi = h->v;
@@ -453,6 +462,10 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.status = h->status;
   a.iters = h->iters;
   int blocks = h->nw_blocks;
+  if (const char* e = getenv("CATINT_NEWTON_BLOCKS")) {   // tuning: size of the persistent grid
+    const int v = atoi(e);
+    if (v >= 1 && v < blocks) blocks = v;
+  }
   if ((int64_t)blocks > h->B) blocks = (int)h->B;
   HIP_TRY(h, launch_newton(a, blocks, h->stream));
   h->steps_done += nsteps;
@@ -474,6 +487,32 @@ int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_
     h->volk[k] = 6.022140857e23 * a * a * a;       // unit_NA, catint/units.py
     if (h->volk[k] != 0.0) h->mpb = true;
   }
+  return PNP_OK;
+}
+
+int pnp_set_wall_kinetics(pnp_handle* h, int32_t n, const int32_t* species, const double* nu, const double* k) {
+  if (!h) return PNP_EINVAL;
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_set_wall_kinetics: the handle was not created with PNP_METHOD_NEWTON");
+  if (n < 0 || n > PNP_MAX_WALL_REACTIONS) return fail(h, PNP_EINVAL, "pnp_set_wall_kinetics: at most 8 surface reactions");
+  if (n == 0) {
+    h->n_wk = 0;
+    return PNP_OK;
+  }
+  if (!species || !nu || !k) return fail(h, PNP_EINVAL, "pnp_set_wall_kinetics: null argument");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_set_wall_kinetics: call pnp_set_batch first (rate constants are per lane)");
+  const int N = h->a.N;
+  for (int r = 0; r < n; ++r) {
+    if (species[r] < -1 || species[r] >= N) return fail(h, PNP_EINVAL, "pnp_set_wall_kinetics: species index out of range");
+    h->wk_species[r] = species[r];
+    for (int kk = 0; kk < PNP_NEWTON_MAX_SPECIES; ++kk) h->wk_nu[r][kk] = kk < N ? nu[r * N + kk] : 0.0;
+  }
+  std::vector<double> kp((size_t)h->B * PNP_MAX_WALL_REACTIONS, 0.0);
+  for (int64_t b = 0; b < h->B; ++b)
+    for (int r = 0; r < n; ++r) kp[(size_t)b * PNP_MAX_WALL_REACTIONS + r] = k[b * n + r];
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(h->wk_k, kp.data(), kp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->n_wk = n;
   return PNP_OK;
 }
 

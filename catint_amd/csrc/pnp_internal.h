@@ -112,6 +112,10 @@ struct NewtonArgs {
   double vol[PNP_NEWTON_MAX_SPECIES];    // N_A a_k^3   (MPB, comsol_model.py:1041-1063)
   double rs[PNP_NEWTON_MAX_SPECIES];     // dx^2/D_k    (scales the reaction source)
   const struct ReactionTable* rt;        // device copy of the mass-action table, or null
+  int32_t n_wk;                          // first-order surface reactions (pnp_set_wall_kinetics)
+  int32_t wk_species[PNP_MAX_WALL_REACTIONS];                     // species whose surface concentration enters, -1: zeroth order
+  double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES];   // stoichiometry of the flux INTO the domain
+  const double* wk_k;                    // [B][PNP_MAX_WALL_REACTIONS] rate constants per lane
   double* c;                             // [B][N][ldx] state = Newton iterate, in place
   double* c_old;                         // [B][N][ldx] previous time level
   double* phi;                           // [B][ldx]

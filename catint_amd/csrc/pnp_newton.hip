@@ -240,7 +240,8 @@ __device__ __forceinline__ void edge_fluxes(const NewtonArgs& A, const Point<N, 
 // At the wall the left edge, at the bulk both edges are switched off by 0/1 weights (their values are finite: the
 // neighbour index is clamped).
 template <int NB, int MODE>
-__device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __restrict__ co, const double* __restrict__ flux,
+__device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ co,
+                                         const double* __restrict__ flux, const double* __restrict__ wk,
                                          const double* __restrict__ cb, double phiM, double phiB, int i,
                                          const Point<NB - 1, MODE>& Pm, const Point<NB - 1, MODE>& P0,
                                          const Point<NB - 1, MODE>& Pp, const Edge (&em)[NB - 1], const Edge (&ep)[NB - 1],
@@ -341,6 +342,22 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
       for (int j = 0; j < N; ++j) M[k][j] -= wr * dR[k][j];
     }
   }
+  // first-order surface reactions: flux into the domain nu_k K c_s(0) joins the prescribed wall flux, so the kinetics <->
+  // transport fixed point of the SCF loop (calculator.py:294-406) is part of the Newton system
+  if (wall && A.n_wk > 0) {
+    for (int r = 0; r < A.n_wk; ++r) {
+      const int sp = A.wk_species[r];
+      const double kr = wk[r];
+      const double cs = sp >= 0 ? c[sp * ldx] : 1.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const double a = A.wk_nu[r][k] * kr * A.fl[k];
+        X[k][2 * NB] += a * cs;
+#pragma unroll
+        for (int j = 0; j < N; ++j) M[k][j] -= (j == sp) ? a : 0.0;
+      }
+    }
+  }
   const double p0 = P0.phi, pp = Pp.phi, pm = Pm.phi;
   if (bulk) {
     X[N][2 * NB] = -(p0 - phiB);
@@ -367,7 +384,8 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
 template <int NB, int MODE>
 __device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ co,
                                              const double* __restrict__ phi, const double* __restrict__ flux,
-                                             const double* __restrict__ cb, double phiM, double phiB, int i,
+                                             const double* __restrict__ wk, const double* __restrict__ cb, double phiM,
+                                             double phiB, int i,
                                              double (&M)[NB][NB], double (&X)[NB][2 * NB + 1]) {
   constexpr int N = NB - 1;
   const int im = i > 0 ? i - 1 : 0;
@@ -378,7 +396,7 @@ __device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* 
   Edge em[N], ep[N];
   edge_fluxes<N, MODE>(A, Pm, P0, em);
   edge_fluxes<N, MODE>(A, P0, Pp, ep);
-  fill_row<NB, MODE>(A, co, flux, cb, phiM, phiB, i, Pm, P0, Pp, em, ep, M, X);
+  fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, i, Pm, P0, Pp, em, ep, M, X);
 }
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -410,6 +428,7 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
     double* phi = A.phi + (size_t)b * ldx;
     const double* flux = A.flux + (size_t)b * N;
     const double* cb = A.cbulk + (size_t)b * N;
+    const double* wk = A.wk_k + (size_t)b * PNP_MAX_WALL_REACTIONS;     // per-lane surface rate constants (unused if n_wk = 0)
     const double phiM = A.pb[b * 4 + 0], phiB = A.pb[b * 4 + 1];
     int total_it = 0, st = PNP_STATUS_OK;
     for (int step = 0; step < A.nsteps; ++step) {
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
       for (; it <= A.maxit; ++it) {
         for (int row = tid; row < nx; row += T) {
           double M[NB][NB], X[NB][2 * NB + 1];
-          assemble_row<NB, MODE>(A, c, co, phi, flux, cb, phiM, phiB, row, M, X);
+          assemble_row<NB, MODE>(A, c, co, phi, flux, wk, cb, phiM, phiB, row, M, X);
           block_solve<NB, 2 * NB + 1, true>(M, X);
           store_row<NB>(buf0, RS, row, X);
         }
@@ -589,6 +608,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
     double* phi = A.phi + (size_t)b * ldx;
     const double* flux = A.flux + (size_t)b * N;
     const double* cb = A.cbulk + (size_t)b * N;
+    const double* wk = A.wk_k + (size_t)b * PNP_MAX_WALL_REACTIONS;     // per-lane surface rate constants (unused if n_wk = 0)
     const double phiM = A.pb[b * 4 + 0], phiB = A.pb[b * 4 + 1];
     int total_it = 0, st = PNP_STATUS_OK;
     for (int step = 0; step < A.nsteps; ++step) {
@@ -613,7 +633,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
           edge_fluxes<N, MODE>(A, P1, P2, e1);
           edge_fluxes<N, MODE>(A, P2, P3, e2);
           if (ra < nx) {
-            fill_row<NB, MODE>(A, co, flux, cb, phiM, phiB, ra, P0, P1, P2, e0, e1, Ma, Xa);
+            fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, ra, P0, P1, P2, e0, e1, Ma, Xa);
             block_solve<NB, NC, true>(Ma, Xa);
           } else {
 #pragma unroll
@@ -623,7 +643,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
           }
           lds_store_row<NB, TS>(xch, tid, Xa);
           if (rb < nx) {
-            fill_row<NB, MODE>(A, co, flux, cb, phiM, phiB, rb, P1, P2, P3, e1, e2, Mb, Xb);
+            fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, rb, P1, P2, P3, e1, e2, Mb, Xb);
           } else {
 #pragma unroll
             for (int r = 0; r < NB; ++r) {

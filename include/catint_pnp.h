@@ -50,6 +50,7 @@ extern "C" {
  * pb[b][0] = phiM of lane b, pb[b][1] = bulk potential; cfg.use_migration/lax_friedrich are ignored. */
 #define PNP_METHOD_NEWTON 2
 #define PNP_NEWTON_MAX_SPECIES 8
+#define PNP_MAX_WALL_REACTIONS 8
 
 /* Poisson boundary combination = which two slots of tp.pb_bound are set
  * (transport.py:1296-1311; branches of get_potential_and_gradient calculator_old.py:776-803) */
@@ -149,6 +150,13 @@ typedef struct pnp_newton_params {
 /* mpb_radius[N] (m, nullable = point ions): size-modified drift with phi0 = N_A sum a_k^3 c_k
  * (tp.species[sp]['MPB_radius'], comsol_model.py:1041-1063). */
 int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_radius);
+/* First-order surface reactions solved implicitly with the transport (physical mode): reaction r contributes the flux
+ * nu[r][k] * k[b][r] * c_{species[r]}(x=0) INTO the domain to species k of lane b (species[r] = -1: zeroth order), on top of
+ * the prescribed pnp_set_flux values.  With rate constants k(phiM) evaluated per lane this is the fixed point the reference's
+ * SCF loop (calculator.py:294-406: kinetics <-> transport with mixing) iterates towards when the kinetics are first order in
+ * a surface concentration -- obtained in ONE solve and without host round trips.  n = 0 removes the table.
+ * species[n], nu[n][N], k[B][n]; call after pnp_set_batch (k is per lane). */
+int pnp_set_wall_kinetics(pnp_handle* h, int32_t n, const int32_t* species, const double* nu, const double* k);
 /* Stationary solve of every lane from the current state as the initial guess (studies=['stat'], transport.py:811-812).
  * tol/maxit <= 0 keep the values of pnp_set_newton.  status[B] nullable. */
 int pnp_solve_stationary(pnp_handle* h, double tol, int32_t maxit, int32_t* status);

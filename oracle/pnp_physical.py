@@ -41,10 +41,13 @@ SERIES_U = 0.05                  # |u| below which B(u) and B'(u) use their Tayl
 
 
 class PhysicalProblem(object):
-    """One operating point.  reactions: list of dicts {'lhs': [species idx...], 'rhs': [...], 'kf':, 'kr':}."""
+    """One operating point.  reactions: list of dicts {'lhs': [species idx...], 'rhs': [...], 'kf':, 'kr':}.
+    wall_kinetics: list of dicts {'species': s (or -1 for zeroth order), 'k': K, 'nu': [nu_k]}: first-order surface
+    reactions whose flux INTO the domain, nu_k K c_s(x=0), is part of the nonlinear system (what the SCF loop of
+    catint/calculator.py:294-406 converges to when the kinetics are rate = K(phiM) c_surface)."""
 
     def __init__(self, D, charges, beta, eps, dx, nx, c_bulk, phiM, flux=None, phi_bulk=0.0, stern_capacitance=None,
-                 phi_pzc=0.0, mpb_radius=None, reactions=None):
+                 phi_pzc=0.0, mpb_radius=None, reactions=None, wall_kinetics=None):
         self.D = np.asarray(D, float)
         self.q = np.asarray(charges, float)        # z*F
         self.beta, self.eps, self.dx, self.nx = float(beta), float(eps), float(dx), int(nx)
@@ -58,6 +61,7 @@ class PhysicalProblem(object):
         self.vol = N_AVOGADRO * a ** 3                     # m^3/mol, phi0 = sum vol_k c_k
         self.mpb = bool(np.any(self.vol != 0.0))
         self.reactions = list(reactions or [])
+        self.wall_kinetics = list(wall_kinetics or [])
 
 
 def bernoulli(u):
@@ -151,7 +155,10 @@ def residual_and_jacobian(p, c, phi, c_old, dt, want_jacobian=True):
         J = -(Bm * cr - Bp * cl)                               # Jhat at edge e = i+1/2, index i
         Ju = -((dBp + 1.0) * cr - dBp * cl)                    # dJhat/du
         F[k, 1:-1] = sig * (c[k, 1:-1] - c_old[k, 1:-1]) + J[1:] - J[:-1] - rs * R[k, 1:-1]
-        F[k, 0] = 0.5 * sig * (c[k, 0] - c_old[k, 0]) + J[0] - p.flux[k] * dx / p.D[k] - 0.5 * rs * R[k, 0]
+        jw = p.flux[k]
+        for wk in p.wall_kinetics:
+            jw = jw + wk['nu'][k] * wk['k'] * (c[wk['species'], 0] if wk['species'] >= 0 else 1.0)
+        F[k, 0] = 0.5 * sig * (c[k, 0] - c_old[k, 0]) + J[0] - jw * dx / p.D[k] - 0.5 * rs * R[k, 0]
         F[k, -1] = c[k, -1] - p.c_bulk[k]
         if not want_jacobian:
             continue
@@ -166,6 +173,9 @@ def residual_and_jacobian(p, c, phi, c_old, dt, want_jacobian=True):
         U[0, k, k] += -Bm[0]
         M[0, k, N] += -Ju[0] * qb
         U[0, k, N] += Ju[0] * qb
+        for wk in p.wall_kinetics:
+            if wk['species'] >= 0:
+                M[0, k, wk['species']] += -wk['nu'][k] * wk['k'] * dx / p.D[k]
         for j in range(N):                                    # steric coupling through u and reactions
             if p.mpb:
                 M[ii, k, j] += -Ju[ii] * g[j, ii] - Ju[ii - 1] * g[j, ii]

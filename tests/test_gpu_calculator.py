@@ -239,3 +239,31 @@ def test_time_dependent_physical_mode_approaches_the_stationary_one():
     assert np.all(trans.status == 0)
     for i in range(2):
         assert np.abs(np.array(tp2.alldata[i]['system']['potential']) - ref[i]).max() < 1e-6
+
+
+def test_implicit_surface_kinetics_give_the_scf_fixed_point_in_one_solve():
+    phis = list(np.linspace(-0.6, -1.6, 11))
+    tp = _physical_transport(phis, mpb=False)
+    calc = Calculator(transport=tp, calc='comsol')
+    rate = lambda phiM: 1e-4 * np.exp(-12.0 * (phiM + 0.6))
+    calc.set_surface_kinetics([{'species': 'CO2', 'rate': rate, 'stoichiometry': {'CO2': -1.0, 'CO': 1.0}}])
+    calc.run()
+    assert np.all(calc.status == 0)
+    L = (tp.nx - 1) * tp.dx
+    kap = rate(np.array(phis)) * L / tp.D[2]
+    cs = np.array([tp.alldata[i]['species']['CO2']['surface_concentration'] for i in range(len(phis))])
+    assert np.allclose(cs, 34.0 / (1.0 + kap), rtol=1e-7)                      # analytic: neutral species, linear profile
+    assert np.allclose(-calc.kinetic_flux[:, 2], tp.D[2] * 34.0 / L * kap / (1.0 + kap), rtol=1e-7)
+    assert kap[-1] > 300 and cs[-1] < 0.2                                       # deep in the diffusion-limited plateau
+    # the same answer as the SCF loop around the transport solve (where the SCF converges at all)
+    tp2 = _physical_transport(phis[:9], mpb=False)
+    scf = Calculator(transport=tp2, calc='comsol', tau_scf=1e-7, mix_scf=0.02)
+
+    def flux_cb(state):
+        f = np.zeros((9, tp2.nspecies))
+        f[:, 2] = -rate(state['phiM']) * np.maximum(state['surface_concentration'][:, 2], 0.0)
+        f[:, 3] = -f[:, 2]
+        return f
+    out = scf.run_scf_cycle(flux_cb, max_iter=4000)
+    assert out['converged'].all()
+    assert np.allclose(out['surface_concentration'][:, 2], cs[:9], rtol=2e-4)

@@ -44,7 +44,7 @@ def make_lanes(N, nx, B, seed, phi_lo=-0.15, phi_hi=0.15, points_per_debye=6.0, 
     return D, q, cb, dx, phiM
 
 
-def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None, flux=None, reactions=None, **lane_kw):
+def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None, flux=None, reactions=None, wall_kinetics=None, **lane_kw):
     newton_kw = dict(newton_kw or {})
     D, q, cb, dx, phiM = make_lanes(N, nx, B, seed, **lane_kw)
     c0 = np.repeat(cb[:, :, None], nx, axis=2)
@@ -56,6 +56,9 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
     if reactions:
         s.set_reactions([(r['lhs'], r['rhs'], r['kf'], r['kr']) for r in reactions])
     s.set_batch(c0, pb, np.zeros(B), fl)
+    if wall_kinetics:
+        s.set_wall_kinetics([w['species'] for w in wall_kinetics], [w['nu'] for w in wall_kinetics],
+                            np.array([w['k'] for w in wall_kinetics]).T)
     if stationary:
         st = s.solve_stationary()
     else:
@@ -71,7 +74,8 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
     for b in range(B):
         p = PH.PhysicalProblem(D=D, charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=cb[b], phiM=phiM[b], flux=fl[b],
                                stern_capacitance=newton_kw.get('stern_capacitance') if newton_kw.get('wall_bc') == 'stern' else None,
-                               phi_pzc=newton_kw.get('phi_pzc', 0.0), mpb_radius=newton_kw.get('mpb_radius'), reactions=reactions)
+                               phi_pzc=newton_kw.get('phi_pzc', 0.0), mpb_radius=newton_kw.get('mpb_radius'), reactions=reactions,
+                               wall_kinetics=[dict(w, k=w['k'][b]) for w in (wall_kinetics or [])])
         cc, ph = c0[b].copy(), np.zeros(nx)
         if stationary:
             cc, ph, it, _ = PH.newton_step(p, cc, ph, cc, np.inf, **okw)
@@ -180,6 +184,17 @@ def test_reactions_in_the_row_per_thread_kernel(monkeypatch):
     monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'generic')
     rx = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [0, 2, 2], 'rhs': [4, 5], 'kf': 5.0, 'kr': 1e2}]
     got, ref = run_both(6, 64, B=3, seed=41, reactions=rx, dt=1e-7, nsteps=3, stationary=False)
+    assert_close(got, ref)
+
+
+def test_implicit_wall_kinetics():
+    B, N = 5, 4
+    rng = np.random.default_rng(9)
+    wk = [{'species': 2, 'k': rng.uniform(0.05, 5.0, B), 'nu': [0.0, 0.0, -1.0, 1.0]},
+          {'species': 0, 'k': rng.uniform(1e-3, 1e-2, B), 'nu': [-1.0, 0.0, 0.5, 0.0]},
+          {'species': -1, 'k': rng.uniform(1e-6, 1e-5, B), 'nu': [0.0, 1.0, 0.0, 0.0]}]
+    got, ref = run_both(N, 150, B=B, seed=17, wall_kinetics=wk,
+                        newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=[4.1e-10, 0.0, 0.0, 0.0]))
     assert_close(got, ref)
 
 
