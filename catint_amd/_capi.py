@@ -33,7 +33,7 @@ SYMBOLS = [
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
-    'pnp_set_potential', 'pnp_set_wall_kinetics',
+    'pnp_set_potential', 'pnp_set_wall_kinetics', 'pnp_set_grid',
 ]
 
 
@@ -107,6 +107,8 @@ def load_library():
     lib.pnp_set_potential.argtypes = [vp, dp]
     lib.pnp_set_wall_kinetics.argtypes = [vp, C.c_int32, ip, dp, dp]
     lib.pnp_set_wall_kinetics.restype = C.c_int
+    lib.pnp_set_grid.argtypes = [vp, dp]
+    lib.pnp_set_grid.restype = C.c_int
     for name in ('pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations', 'pnp_set_potential'):
         getattr(lib, name).restype = C.c_int
     for name in ('pnp_set_species', 'pnp_set_reactions', 'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step',
@@ -223,6 +225,10 @@ class PnpSolver(object):
                             float(stern_capacitance), float(phi_pzc), float(tol), float(dphi_max))
         r = None if mpb_radius is None else _f64(mpb_radius, (self.N,))
         self._check(self._lib.pnp_set_newton(self._h, C.byref(p), _dptr(r)))
+
+    def set_grid(self, x):
+        """Non-uniform grid x[nx] of the physical mode (electrode at x[0]); dx of the constructor stays the scaling length."""
+        self._check(self._lib.pnp_set_grid(self._h, _dptr(_f64(x, (self.nx,)))))
 
     def set_wall_kinetics(self, species, nu, k):
         """First-order surface reactions coupled implicitly: species [n] (index, -1 = zeroth order), nu [n][N] stoichiometry

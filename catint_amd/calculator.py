@@ -74,6 +74,8 @@ class Calculator(object):
             raise CalculatorError("calculator '%s' is not part of the MI355X transport path "
                                   "(supported: %s)" % (self.calc, ', '.join(GPU_CALCS + MOL_CALCS + PHYSICAL_CALCS)))
         self.physical = self.calc in PHYSICAL_CALCS
+        if not self.physical and not getattr(self.tp, 'mesh_uniform', True):
+            raise CalculatorError('the finite-difference integrators need a uniform mesh; graded meshes belong to calc="comsol"')
         if self.mode is None:      # COMSOL studies default to ['stat'] (transport.py:811-812); the FD integrators are transient
             self.mode = 'stationary' if self.physical else 'time-dependent'
         if scale_pb_grid is not None:
@@ -208,6 +210,8 @@ class Calculator(object):
         s.set_newton(wall_bc='stern' if stern else 'dirichlet', stern_capacitance=cs if stern else 0.0,
                      phi_pzc=float(tp.system.get('phiPZC', 0.0)), tol=nk.get('tol', 1e-8), maxit=nk.get('maxit', 50),
                      dphi_max=nk.get('dphi_max', 0.05), mpb_radius=radii if any(radii) else None)
+        if not getattr(tp, 'mesh_uniform', True):
+            s.set_grid(tp.xmesh)
         if getattr(tp, 'use_reactions', False) and getattr(tp, 'reactions', None):      # tp.reactions[r]['reactants'], ['rates']
             names = list(tp.species.keys())
             s.set_reactions([([names.index(x) for x in rx['reactants'][0] if x in names],

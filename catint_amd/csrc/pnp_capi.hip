@@ -45,6 +45,8 @@ struct pnp_handle {
   int32_t wk_species[PNP_MAX_WALL_REACTIONS] = {0};
   double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES] = {{0}};
   double* wk_k = nullptr;
+  double *gw = nullptr, *gv = nullptr;
+  std::vector<double> xgrid;
   int64_t stash_stride = 0;
   int32_t* iters = nullptr;
   int nw_blocks = 0;
@@ -88,7 +90,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -168,6 +170,17 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
     HIP_TRYC(dev_alloc(h, &h->v, (size_t)Bc * ldx));
     HIP_TRYC(dev_alloc(h, &h->iters, (size_t)Bc));
     HIP_TRYC(dev_alloc(h, &h->wk_k, (size_t)Bc * PNP_MAX_WALL_REACTIONS));
+    HIP_TRYC(dev_alloc(h, &h->gw, (size_t)cfg->nx));
+    HIP_TRYC(dev_alloc(h, &h->gv, (size_t)cfg->nx));
+    {
+      std::vector<double> x((size_t)cfg->nx);
+      for (int i = 0; i < cfg->nx; ++i) x[i] = i * cfg->dx;
+      h->xgrid = x;
+      std::vector<double> w((size_t)cfg->nx, 1.0), v((size_t)cfg->nx, 1.0);
+      v[0] = v[cfg->nx - 1] = 0.5;
+      HIP_TRYC(hipMemcpy(h->gw, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRYC(hipMemcpy(h->gv, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     const int nb = N + 1;
     if (!newton_exchange_in_lds(nb, cfg->nx)) {
       const size_t slice = newton_exchange_doubles(nb, cfg->nx);
@@ -453,6 +466,8 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   memcpy(a.wk_species, h->wk_species, sizeof(a.wk_species));
   memcpy(a.wk_nu, h->wk_nu, sizeof(a.wk_nu));
   a.wk_k = h->wk_k;
+  a.gw = h->gw;
+  a.gv = h->gv;
   a.c = h->c;
   a.c_old = h->c_old;
   a.phi = h->v;
@@ -487,6 +502,27 @@ int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_
     h->volk[k] = 6.022140857e23 * a * a * a;       // unit_NA, catint/units.py
     if (h->volk[k] != 0.0) h->mpb = true;
   }
+  return PNP_OK;
+}
+
+int pnp_set_grid(pnp_handle* h, const double* x) {
+  if (!h || !x) return fail(h, PNP_EINVAL, "pnp_set_grid: null argument");
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_set_grid: only the physical mode takes a non-uniform grid");
+  const int nx = h->a.nx;
+  const double dx = h->a.dx;
+  std::vector<double> w((size_t)nx, 1.0), v((size_t)nx, 0.0);
+  for (int i = 0; i + 1 < nx; ++i) {
+    const double hh = x[i + 1] - x[i];
+    if (!(hh > 0)) return fail(h, PNP_EINVAL, "pnp_set_grid: x must be strictly increasing");
+    w[i] = dx / hh;
+    v[i] += 0.5 * hh / dx;
+    v[i + 1] += 0.5 * hh / dx;
+  }
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(h->gw, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->gv, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->xgrid.assign(x, x + nx);
   return PNP_OK;
 }
 
@@ -670,9 +706,10 @@ int pnp_get_state(pnp_handle* h, double* c, double* v, double* grad_v, double* l
       if (grad_v) {
         const double* p = ph.data() + (size_t)b * nx;
         double* g = grad_v + (size_t)b * nx;
-        for (int i = 1; i < nx - 1; ++i) g[i] = (p[i + 1] - p[i - 1]) / (2 * dx);
-        g[0] = (p[1] - p[0]) / dx;
-        g[nx - 1] = (p[nx - 1] - p[nx - 2]) / dx;
+        const std::vector<double>& xg = h->xgrid;
+        for (int i = 1; i < nx - 1; ++i) g[i] = (p[i + 1] - p[i - 1]) / (xg[i + 1] - xg[i - 1]);
+        g[0] = (p[1] - p[0]) / (xg[1] - xg[0]);
+        g[nx - 1] = (p[nx - 1] - p[nx - 2]) / (xg[nx - 1] - xg[nx - 2]);
       }
       if (lapl_v)
         for (int i = 0; i < nx; ++i) {
@@ -714,7 +751,7 @@ int pnp_get_surface(pnp_handle* h, double* csurf, double* vsurf, double* esurf) 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (int64_t b = 0; b < B; ++b) {
       if (vsurf) vsurf[b] = p01[2 * b];
-      if (esurf) esurf[b] = -(p01[2 * b + 1] - p01[2 * b]) / h->a.dx;   // the one-sided field of the Stern condition
+      if (esurf) esurf[b] = -(p01[2 * b + 1] - p01[2 * b]) / (h->xgrid[1] - h->xgrid[0]);   // the one-sided field of the Stern condition
     }
     return PNP_OK;
   }

@@ -116,6 +116,8 @@ struct NewtonArgs {
   int32_t wk_species[PNP_MAX_WALL_REACTIONS];                     // species whose surface concentration enters, -1: zeroth order
   double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES];   // stoichiometry of the flux INTO the domain
   const double* wk_k;                    // [B][PNP_MAX_WALL_REACTIONS] rate constants per lane
+  const double* gw;                      // [nx] grid: dx/h_e of edge e (points e, e+1); 1 on the uniform grid
+  const double* gv;                      // [nx] grid: control volume V_i/dx; 1 inside a uniform grid, 1/2 at the ends
   double* c;                             // [B][N][ldx] state = Newton iterate, in place
   double* c_old;                         // [B][N][ldx] previous time level
   double* phi;                           // [B][ldx]

@@ -179,7 +179,7 @@ struct Edge {
   double Bp, Bm, J, Ju;
 };
 
-__device__ __forceinline__ Edge edge_flux(double u, double cl, double cr) {
+__device__ __forceinline__ Edge edge_flux(double u, double cl, double cr, double w) {   // w = dx/h_e (1 on a uniform grid)
   double B, dB;
   if (fabs(u) < 0.05) {   // oracle/pnp_physical.py: bernoulli, SERIES_U
     const double u2 = u * u;
@@ -191,10 +191,10 @@ __device__ __forceinline__ Edge edge_flux(double u, double cl, double cr) {
     dB = (1.0 - B - u) * rE;
   }
   Edge e;
-  e.Bp = B;
-  e.Bm = B + u;
-  e.J = -(e.Bm * cr - B * cl);
-  e.Ju = -((dB + 1.0) * cr - dB * cl);
+  e.Bp = w * B;
+  e.Bm = w * (B + u);
+  e.J = -(e.Bm * cr - e.Bp * cl);
+  e.Ju = -w * ((dB + 1.0) * cr - dB * cl);
   return e;
 }
 
@@ -228,10 +228,11 @@ __device__ __forceinline__ Point<N, MODE> load_point(const NewtonArgs& A, const 
 }
 
 template <int N, int MODE>
-__device__ __forceinline__ void edge_fluxes(const NewtonArgs& A, const Point<N, MODE>& Pl, const Point<N, MODE>& Pr, Edge (&e)[N]) {
+__device__ __forceinline__ void edge_fluxes(const NewtonArgs& A, const Point<N, MODE>& Pl, const Point<N, MODE>& Pr, double w,
+                                            Edge (&e)[N]) {
   const double dphi = Pr.phi - Pl.phi, dw = Pr.w - Pl.w;
 #pragma unroll
-  for (int k = 0; k < N; ++k) e[k] = edge_flux(A.qb[k] * dphi + dw, Pl.c[k], Pr.c[k]);
+  for (int k = 0; k < N; ++k) e[k] = edge_flux(A.qb[k] * dphi + dw, Pl.c[k], Pr.c[k], w);
 }
 
 // Residual F and Jacobian blocks (L, M, U) of block row i, returned as M and X = [L | U | -F], from the point states
@@ -245,7 +246,8 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
                                          const double* __restrict__ cb, double phiM, double phiB, int i,
                                          const Point<NB - 1, MODE>& Pm, const Point<NB - 1, MODE>& P0,
                                          const Point<NB - 1, MODE>& Pp, const Edge (&em)[NB - 1], const Edge (&ep)[NB - 1],
-                                         double (&M)[NB][NB], double (&X)[NB][2 * NB + 1]) {
+                                         double wem, double wep, double vi, double (&M)[NB][NB],
+                                         double (&X)[NB][2 * NB + 1]) {
   constexpr int N = NB - 1;
   constexpr int NC = 2 * NB + 1;
   constexpr bool MPB = MODE >= 1;
@@ -261,7 +263,7 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
   const bool wall = (i == 0), bulk = (i == nx - 1);
   const double wp = bulk ? 0.0 : 1.0;
   const double wm = (wall || bulk) ? 0.0 : 1.0;
-  const double ws = bulk ? 0.0 : (wall ? 0.5 : 1.0);
+  const double ws = bulk ? 0.0 : vi;     // control volume / dx: 1 inside a uniform grid, 1/2 at the wall
   const double wf = wall ? 1.0 : 0.0;
   // homogeneous reactions: mass action in activities a_j = c_j gam, every reaction summed
   // (comsol_model.py:781-867, :1064-1084; oracle/pnp_physical.py: reaction_rates).  The species indices of the table
@@ -367,17 +369,17 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
       X[N][2 * NB] = -(p0 - phiM);
       M[N][N] = 1.0;
     } else {
-      X[N][2 * NB] = -((pp - p0) + A.stern * (phiM - A.phi_pzc - p0));
-      M[N][N] = -1.0 - A.stern;
-      X[N][NB + N] = 1.0;
+      X[N][2 * NB] = -(wep * (pp - p0) + A.stern * (phiM - A.phi_pzc - p0));
+      M[N][N] = -wep - A.stern;
+      X[N][NB + N] = wep;
     }
   } else {
-    X[N][2 * NB] = -(pp - 2.0 * p0 + pm + rho);
+    X[N][2 * NB] = -(wep * (pp - p0) - wem * (p0 - pm) + vi * rho);
 #pragma unroll
-    for (int k = 0; k < N; ++k) M[N][k] = A.peq[k];
-    M[N][N] = -2.0;
-    X[N][N] = 1.0;
-    X[N][NB + N] = 1.0;
+    for (int k = 0; k < N; ++k) M[N][k] = vi * A.peq[k];
+    M[N][N] = -(wep + wem);
+    X[N][N] = wem;
+    X[N][NB + N] = wep;
   }
 }
 
@@ -393,10 +395,11 @@ __device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* 
   const Point<N, MODE> Pm = load_point<N, MODE>(A, c, phi, im);
   const Point<N, MODE> P0 = load_point<N, MODE>(A, c, phi, i);
   const Point<N, MODE> Pp = load_point<N, MODE>(A, c, phi, ip);
+  const double wem = A.gw[im], wep = A.gw[i < A.nx - 1 ? i : A.nx - 2];
   Edge em[N], ep[N];
-  edge_fluxes<N, MODE>(A, Pm, P0, em);
-  edge_fluxes<N, MODE>(A, P0, Pp, ep);
-  fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, i, Pm, P0, Pp, em, ep, M, X);
+  edge_fluxes<N, MODE>(A, Pm, P0, wem, em);
+  edge_fluxes<N, MODE>(A, P0, Pp, wep, ep);
+  fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, i, Pm, P0, Pp, em, ep, wem, wep, A.gv[i], M, X);
 }
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -628,12 +631,14 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
           const Point<N, MODE> P1 = load_point<N, MODE>(A, c, phi, i1);
           const Point<N, MODE> P2 = load_point<N, MODE>(A, c, phi, i2);
           const Point<N, MODE> P3 = load_point<N, MODE>(A, c, phi, i3);
+          const int le = nx - 2;
+          const double w0 = A.gw[i0 < le ? i0 : le], w1 = A.gw[i1 < le ? i1 : le], w2 = A.gw[i2 < le ? i2 : le];
           Edge e0[N], e1[N], e2[N];
-          edge_fluxes<N, MODE>(A, P0, P1, e0);
-          edge_fluxes<N, MODE>(A, P1, P2, e1);
-          edge_fluxes<N, MODE>(A, P2, P3, e2);
+          edge_fluxes<N, MODE>(A, P0, P1, w0, e0);
+          edge_fluxes<N, MODE>(A, P1, P2, w1, e1);
+          edge_fluxes<N, MODE>(A, P2, P3, w2, e2);
           if (ra < nx) {
-            fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, ra, P0, P1, P2, e0, e1, Ma, Xa);
+            fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, ra, P0, P1, P2, e0, e1, w0, w1, A.gv[i1], Ma, Xa);
             block_solve<NB, NC, true>(Ma, Xa);
           } else {
 #pragma unroll
@@ -643,7 +648,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
           }
           lds_store_row<NB, TS>(xch, tid, Xa);
           if (rb < nx) {
-            fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, rb, P1, P2, P3, e1, e2, Mb, Xb);
+            fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, rb, P1, P2, P3, e1, e2, w1, w2, A.gv[i2], Mb, Xb);
           } else {
 #pragma unroll
             for (int r = 0; r < NB; ++r) {

@@ -33,3 +33,27 @@ def solver_from_problem(p, method, batch_capacity=1, device=0):
     if getattr(p, 'reactions', None):
         s.set_reactions(p.reactions)
     return s
+
+
+def graded_mesh(length, h0, nx):
+    """Geometric grid x[nx] on [0, length] with first spacing h0 (the electrode end) and constant growth ratio: resolves a
+    nanometre double layer inside a micrometre diffusion layer, like the reference's COMSOL mesh
+    (hmax = L/grid_factor_domain in the domain, lambda_D/grid_factor_bound at the boundaries, comsol_model.py:588,593)."""
+    import numpy as np
+    n = int(nx) - 1
+    if n * h0 >= length:
+        return np.linspace(0.0, length, nx)
+    lo, hi = 1.0 + 1e-12, 2.0
+    f = lambda r: h0 * (r ** n - 1.0) / (r - 1.0) - length
+    while f(hi) < 0:
+        hi *= 2.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if f(mid) > 0:
+            hi = mid
+        else:
+            lo = mid
+    r = 0.5 * (lo + hi)
+    x = np.concatenate([[0.0], np.cumsum(h0 * r ** np.arange(n))])
+    x[-1] = length
+    return x

@@ -107,6 +107,7 @@ class Transport(object):
             self.dx = self.debye_length / nx_mod
         self.xmesh = np.arange(0, self.xmax + self.dx, self.dx)
         self.nx = len(self.xmesh)
+        self.mesh_uniform = True
         # initial / boundary conditions
         self.c0 = np.repeat([self.species[sp]['bulk_concentration'] for sp in self.species], self.nx).astype(float)
         if any(isinstance(self.species[sp]['flux'], str) for sp in self.species):
@@ -182,6 +183,14 @@ class Transport(object):
                 c0[k * self.nx + i] = self.species[sp]['bulk_concentration'] * \
                     np.exp(-self.beta * self.charges[k] * self.gouy_chapman(self.xmesh[i], phiM=phiM)[0])
         self.c0 = c0
+
+    def set_graded_mesh(self, h0):
+        """Replace the uniform mesh by a geometric one with the same end point and number of points and first spacing h0
+        (physical mode only; the legacy FD integrators assume a constant dx).  tp.dx becomes h0."""
+        from .host import graded_mesh
+        self.xmesh = graded_mesh(self.xmesh[-1], h0, self.nx)
+        self.dx = float(self.xmesh[1] - self.xmesh[0])
+        self.mesh_uniform = False
 
     def set_calculator(self, calc=None):   # transport.py:1514
         self.calc = calc

@@ -150,6 +150,10 @@ typedef struct pnp_newton_params {
 /* mpb_radius[N] (m, nullable = point ions): size-modified drift with phi0 = N_A sum a_k^3 c_k
  * (tp.species[sp]['MPB_radius'], comsol_model.py:1041-1063). */
 int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_radius);
+/* Non-uniform grid of the physical mode: x[nx] strictly increasing, x[0] = electrode, x[nx-1] = bulk boundary (the reference's
+ * COMSOL mesh is refined towards the electrode: hmax = L/grid_factor_domain, lambda_D/grid_factor_bound at the boundaries,
+ * comsol_model.py:588,593).  cfg.dx stays the reference length of the equation scaling (use x[1]-x[0]).  Default: x_i = i*dx. */
+int pnp_set_grid(pnp_handle* h, const double* x);
 /* First-order surface reactions solved implicitly with the transport (physical mode): reaction r contributes the flux
  * nu[r][k] * k[b][r] * c_{species[r]}(x=0) INTO the domain to species k of lane b (species[r] = -1: zeroth order), on top of
  * the prescribed pnp_set_flux values.  With rate constants k(phiM) evaluated per lane this is the fixed point the reference's

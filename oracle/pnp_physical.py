@@ -14,7 +14,9 @@ What pins it instead are analytic known answers the reference itself carries: th
 (catint/transport.py:1373-1383), Boltzmann profiles (:1325-1346), the Debye length (:439-443), plus mass
 conservation, the MPB saturation limit and Newton's quadratic convergence (tests/test_physical_oracle.py).
 
-Discretisation (uniform grid x_i = i*dx, i = 0..nx-1; conservative; exponentially fitted = Scharfetter-Gummel
+Discretisation (stated for the uniform grid x_i = i*dx, i = 0..nx-1; on a non-uniform grid every edge flux carries the
+weight dx/h_e and every storage/source term the control volume V_i/dx, see PhysicalProblem; conservative;
+exponentially fitted = Scharfetter-Gummel
 fluxes, which reproduce the Boltzmann distribution exactly on any grid and stay monotone at any bias):
   generalised drift potential of species k:  psi_k = q_k beta phi + w,   w = -ln(1 - phi0)   (w = 0 without MPB)
   edge i+1/2:  u = psi_k[i+1] - psi_k[i],   Jhat_k = J_k dx / D_k = -( B(-u) c_k[i+1] - B(u) c_k[i] ),
@@ -47,7 +49,7 @@ class PhysicalProblem(object):
     catint/calculator.py:294-406 converges to when the kinetics are rate = K(phiM) c_surface)."""
 
     def __init__(self, D, charges, beta, eps, dx, nx, c_bulk, phiM, flux=None, phi_bulk=0.0, stern_capacitance=None,
-                 phi_pzc=0.0, mpb_radius=None, reactions=None, wall_kinetics=None):
+                 phi_pzc=0.0, mpb_radius=None, reactions=None, wall_kinetics=None, x=None):
         self.D = np.asarray(D, float)
         self.q = np.asarray(charges, float)        # z*F
         self.beta, self.eps, self.dx, self.nx = float(beta), float(eps), float(dx), int(nx)
@@ -62,6 +64,16 @@ class PhysicalProblem(object):
         self.mpb = bool(np.any(self.vol != 0.0))
         self.reactions = list(reactions or [])
         self.wall_kinetics = list(wall_kinetics or [])
+        # grid: uniform x_i = i*dx, or any increasing x[nx] (then dx is only the reference length of the row scaling).
+        # w[e] = dx/h_e weights the flux across edge e (between points e and e+1), v[i] = V_i/dx is the control volume
+        # (half cells at the ends)
+        self.x = np.arange(self.nx) * self.dx if x is None else np.asarray(x, float)
+        h = np.diff(self.x)
+        self.w = self.dx / h
+        self.v = np.empty(self.nx)
+        self.v[1:-1] = 0.5 * (h[1:] + h[:-1]) / self.dx
+        self.v[0] = 0.5 * h[0] / self.dx
+        self.v[-1] = 0.5 * h[-1] / self.dx
 
 
 def bernoulli(u):
@@ -152,24 +164,26 @@ def residual_and_jacobian(p, c, phi, c_old, dt, want_jacobian=True):
         Bp, dBp = bernoulli(u)
         Bm = Bp + u
         cl, cr = c[k, :-1], c[k, 1:]
+        Bp, Bm = p.w * Bp, p.w * Bm                            # edge weights dx/h_e of a non-uniform grid (1 if uniform)
         J = -(Bm * cr - Bp * cl)                               # Jhat at edge e = i+1/2, index i
-        Ju = -((dBp + 1.0) * cr - dBp * cl)                    # dJhat/du
-        F[k, 1:-1] = sig * (c[k, 1:-1] - c_old[k, 1:-1]) + J[1:] - J[:-1] - rs * R[k, 1:-1]
+        Ju = -p.w * ((dBp + 1.0) * cr - dBp * cl)              # dJhat/du
+        v = p.v
+        F[k, 1:-1] = sig * v[1:-1] * (c[k, 1:-1] - c_old[k, 1:-1]) + J[1:] - J[:-1] - rs * v[1:-1] * R[k, 1:-1]
         jw = p.flux[k]
         for wk in p.wall_kinetics:
             jw = jw + wk['nu'][k] * wk['k'] * (c[wk['species'], 0] if wk['species'] >= 0 else 1.0)
-        F[k, 0] = 0.5 * sig * (c[k, 0] - c_old[k, 0]) + J[0] - jw * dx / p.D[k] - 0.5 * rs * R[k, 0]
+        F[k, 0] = sig * v[0] * (c[k, 0] - c_old[k, 0]) + J[0] - jw * dx / p.D[k] - rs * v[0] * R[k, 0]
         F[k, -1] = c[k, -1] - p.c_bulk[k]
         if not want_jacobian:
             continue
         # interior row i: +J[i] (left point i, right point i+1)  -J[i-1] (left point i-1, right point i)
-        M[ii, k, k] += sig + Bp[ii] + Bm[ii - 1]               # dJ[i]/dc_l = +Bp ; -dJ[i-1]/dc_r = +Bm
+        M[ii, k, k] += sig * v[ii] + Bp[ii] + Bm[ii - 1]       # dJ[i]/dc_l = +Bp ; -dJ[i-1]/dc_r = +Bm
         U[ii, k, k] += -Bm[ii]
         L[ii, k, k] += -Bp[ii - 1]
         M[ii, k, N] += Ju[ii] * (-qb) - Ju[ii - 1] * qb
         U[ii, k, N] += Ju[ii] * qb
         L[ii, k, N] += Ju[ii - 1] * qb
-        M[0, k, k] += 0.5 * sig + Bp[0]
+        M[0, k, k] += sig * v[0] + Bp[0]
         U[0, k, k] += -Bm[0]
         M[0, k, N] += -Ju[0] * qb
         U[0, k, N] += Ju[0] * qb
@@ -183,28 +197,29 @@ def residual_and_jacobian(p, c, phi, c_old, dt, want_jacobian=True):
                 L[ii, k, j] += Ju[ii - 1] * g[j, ii - 1]
                 M[0, k, j] += -Ju[0] * g[j, 0]
                 U[0, k, j] += Ju[0] * g[j, 1]
-            M[ii, k, j] += -rs * dR[k, j, ii]
-            M[0, k, j] += -0.5 * rs * dR[k, j, 0]
+            M[ii, k, j] += -rs * v[ii] * dR[k, j, ii]
+            M[0, k, j] += -rs * v[0] * dR[k, j, 0]
         M[nx - 1, k, k] = 1.0
     pe = dx * dx / p.eps
     rho = (p.q[:, None] * c).sum(axis=0)
-    F[N, 1:-1] = phi[2:] - 2.0 * phi[1:-1] + phi[:-2] + pe * rho[1:-1]
+    w, v = p.w, p.v
+    F[N, 1:-1] = w[1:] * (phi[2:] - phi[1:-1]) - w[:-1] * (phi[1:-1] - phi[:-2]) + pe * v[1:-1] * rho[1:-1]
     if p.CS is None:
         F[N, 0] = phi[0] - p.phiM
     else:
-        F[N, 0] = (phi[1] - phi[0]) + (dx * p.CS / p.eps) * (p.phiM - p.phi_pzc - phi[0])
+        F[N, 0] = w[0] * (phi[1] - phi[0]) + (dx * p.CS / p.eps) * (p.phiM - p.phi_pzc - phi[0])
     F[N, -1] = phi[-1] - p.phi_bulk
     if want_jacobian:
         for k in range(N):
-            M[ii, N, k] = pe * p.q[k]
-        M[ii, N, N] = -2.0
-        L[ii, N, N] = 1.0
-        U[ii, N, N] = 1.0
+            M[ii, N, k] = pe * v[ii] * p.q[k]
+        M[ii, N, N] = -(w[ii] + w[ii - 1])
+        L[ii, N, N] = w[ii - 1]
+        U[ii, N, N] = w[ii]
         if p.CS is None:
             M[0, N, N] = 1.0
         else:
-            M[0, N, N] = -1.0 - dx * p.CS / p.eps
-            U[0, N, N] = 1.0
+            M[0, N, N] = -w[0] - dx * p.CS / p.eps
+            U[0, N, N] = w[0]
         M[nx - 1, N, N] = 1.0
     return F, L, M, U
 

@@ -44,7 +44,7 @@ def make_lanes(N, nx, B, seed, phi_lo=-0.15, phi_hi=0.15, points_per_debye=6.0, 
     return D, q, cb, dx, phiM
 
 
-def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None, flux=None, reactions=None, wall_kinetics=None, **lane_kw):
+def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None, flux=None, reactions=None, wall_kinetics=None, x=None, **lane_kw):
     newton_kw = dict(newton_kw or {})
     D, q, cb, dx, phiM = make_lanes(N, nx, B, seed, **lane_kw)
     c0 = np.repeat(cb[:, :, None], nx, axis=2)
@@ -53,6 +53,9 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
     fl = np.zeros((B, N)) if flux is None else flux
     s = _capi.PnpSolver(N, nx, dx, dt if dt else 1.0, BETA, EPS, D, q, method='Newton', pb_mode=_capi.PB_DD, batch_capacity=B)
     s.set_newton(**newton_kw)
+    if x is not None:
+        x = x * dx            # given in units of dx
+        s.set_grid(x)
     if reactions:
         s.set_reactions([(r['lhs'], r['rhs'], r['kf'], r['kr']) for r in reactions])
     s.set_batch(c0, pb, np.zeros(B), fl)
@@ -75,7 +78,7 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
         p = PH.PhysicalProblem(D=D, charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=cb[b], phiM=phiM[b], flux=fl[b],
                                stern_capacitance=newton_kw.get('stern_capacitance') if newton_kw.get('wall_bc') == 'stern' else None,
                                phi_pzc=newton_kw.get('phi_pzc', 0.0), mpb_radius=newton_kw.get('mpb_radius'), reactions=reactions,
-                               wall_kinetics=[dict(w, k=w['k'][b]) for w in (wall_kinetics or [])])
+                               wall_kinetics=[dict(w, k=w['k'][b]) for w in (wall_kinetics or [])], x=x)
         cc, ph = c0[b].copy(), np.zeros(nx)
         if stationary:
             cc, ph, it, _ = PH.newton_step(p, cc, ph, cc, np.inf, **okw)
@@ -195,6 +198,20 @@ def test_implicit_wall_kinetics():
           {'species': -1, 'k': rng.uniform(1e-6, 1e-5, B), 'nu': [0.0, 1.0, 0.0, 0.0]}]
     got, ref = run_both(N, 150, B=B, seed=17, wall_kinetics=wk,
                         newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=[4.1e-10, 0.0, 0.0, 0.0]))
+    assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx,kw", [(3, 96, {}), (3, 257, dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=[4.1e-10, 3e-10, 0.0])),
+                                     (6, 80, {})])
+def test_graded_grid(N, nx, kw, monkeypatch):
+    from catint_amd.host import graded_mesh
+    x = graded_mesh(4000.0, 1.0, nx)              # first cell = dx, domain 4000 dx, growth ratio ~1.03-1.1
+    rx = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}]
+    wk = [{'species': 2, 'k': np.full(3, 0.05), 'nu': [0.0, 0.0, -1.0] + [0.0] * (N - 3)}]
+    got, ref = run_both(N, nx, B=3, seed=nx, x=x, reactions=rx, wall_kinetics=wk, newton_kw=kw, points_per_debye=8.0)
+    assert_close(got, ref)
+    # transient on the same grid
+    got, ref = run_both(N, nx, B=3, seed=nx + 1, x=x, newton_kw=kw, points_per_debye=8.0, dt=1e-7, nsteps=3, stationary=False)
     assert_close(got, ref)
 
 
