@@ -255,33 +255,52 @@ class Calculator(object):
         return out
 
     def solve_physical(self, solver, c0, phiM, flux, nramp=8, warm=False):
-        """One transport solve of every lane (run_single_step, calculator.py:408-535).  Stationary mode: Newton from the
-        current state (warm) or from the bulk state; if lanes do not converge from the bulk state, all lanes are restarted
-        with phiM and the fluxes ramped up in `nramp` stages (the reference's flux_factor / PZC continuation,
-        transport.py:877-893, comsol_model.py:1147-1167).  Time-dependent mode: tp.nt-1 backward-Euler steps.
-        Returns status [B]."""
+        """One transport solve of every lane (run_single_step, calculator.py:408-535).
+        Stationary mode: Newton from the current state (warm) or from the bulk state.  If lanes do not converge from the
+        bulk state -- or the potentials are far from phiPZC, or surface kinetics are coupled in, where that is the rule --
+        every lane walks a continuation path instead: the wall potential goes from phiPZC (uncharged interface) to its phiM
+        in stages of at most tp.newton['dphi_stage'] (0.1 V), the prescribed fluxes grow proportionally and the surface
+        rate constants are evaluated at the stage potential, each stage warm-started from the previous one (the reference's
+        parametric sweeps: flux_factor / PZC / CS ramps, transport.py:877-893, comsol_model.py:1147-1167).
+        Time-dependent mode: tp.nt-1 backward-Euler steps.  Returns status [B]."""
+        phiM = np.asarray(phiM, float)
         B = len(phiM)
         pb = np.zeros((B, 4)); pb[:, 0] = phiM
         vz = np.zeros(B)
-        if not warm:
-            solver.set_batch(c0, pb, vz, flux)
-            self._apply_surface_kinetics(solver, np.asarray(phiM, float))
-        else:
+        if warm:
             solver.set_flux(flux)
+            if self.mode != 'stationary':
+                solver.step(self.tp.nt - 1)
+                return solver.get_status()
+            return solver.solve_stationary()
         if self.mode != 'stationary':
+            solver.set_batch(c0, pb, vz, flux)
+            self._apply_surface_kinetics(solver, phiM)
             solver.step(self.tp.nt - 1)
             return solver.get_status()
-        st = solver.solve_stationary()
-        if (st != 0).any() and nramp > 1 and not warm:
-            for j in range(1, nramp + 1):
-                w = j / float(nramp)
-                pbj = pb.copy(); pbj[:, 0] = phiM * w
-                if j == 1:
-                    solver.set_batch(c0, pbj, vz, flux * w)
-                else:
-                    solver.set_pb(pbj, vz)
-                    solver.set_flux(flux * w)
-                st = solver.solve_stationary()
+        nk = getattr(self.tp, 'newton', {})
+        stern = self.tp.system.get('wall potential', 'stern') == 'stern' and float(self.tp.system.get('Stern capacitance', 0.0)) > 0
+        start = float(self.tp.system.get('phiPZC', 0.0)) if stern else 0.0
+        span = float(np.abs(phiM - start).max())
+        direct = nramp <= 1 or (span <= nk.get('direct_span', 0.6) and not getattr(self, 'surface_kinetics', None))
+        if direct:
+            solver.set_batch(c0, pb, vz, flux)
+            self._apply_surface_kinetics(solver, phiM)
+            st = solver.solve_stationary()
+            if not (st != 0).any() or nramp <= 1:
+                return st
+        nst = max(int(nramp), int(np.ceil(span / nk.get('dphi_stage', 0.1))))
+        self.continuation_stages = nst
+        for j in range(1, nst + 1):
+            w = j / float(nst)
+            pbj = pb.copy(); pbj[:, 0] = start + (phiM - start) * w
+            if j == 1:
+                solver.set_batch(c0, pbj, vz, flux * w)
+            else:
+                solver.set_pb(pbj, vz)
+                solver.set_flux(flux * w)
+            self._apply_surface_kinetics(solver, pbj[:, 0])
+            st = solver.solve_stationary()
         return st
 
     # ------------------------------------------------------------------------------------------

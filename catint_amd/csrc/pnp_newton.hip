@@ -287,7 +287,7 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
         const int n = side == 0 ? nl : nrh;
         const int32_t* idx = side == 0 ? rt->lhs[r] : rt->rhs[r];
         const double kk = side == 0 ? rt->kf[r] : rt->kr[r];
-        if (kk == 0.0 || n == 0) continue;
+        if (kk == 0.0) continue;             // n = 0: constant rate (the side consists of excluded species, e.g. H2O)
         double pre = kk;
         for (int a = 0; a < n; ++a) pre *= P0.gam;
         double prod = pre;

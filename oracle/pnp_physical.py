@@ -116,7 +116,7 @@ def reaction_rates(p, c):
         dgam = np.zeros((N, nx))
     for r in p.reactions:
         for side, kk, sign in ((r['lhs'], r['kf'], 1.0), (r['rhs'], r['kr'], -1.0)):
-            if kk == 0.0 or len(side) == 0:
+            if kk == 0.0:                       # an empty side is a constant rate (excluded species such as H2O)
                 continue
             m = len(side)
             prod = kk * gam ** m

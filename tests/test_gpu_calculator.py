@@ -267,3 +267,44 @@ def test_implicit_surface_kinetics_give_the_scf_fixed_point_in_one_solve():
     out = scf.run_scf_cycle(flux_cb, max_iter=4000)
     assert out['converged'].all()
     assert np.allclose(out['surface_concentration'][:, 2], cs[:9], rtol=2e-4)
+
+
+def test_co2r_physical_example_matches_the_oracle_along_the_polarization_curve():
+    """examples/co2r_physical_sweep.py (BASELINE configs[2] in the physical mode: 7 species, 5 stiff buffer reactions, steric K+,
+    Stern layer, graded mesh, implicit Tafel kinetics) at test size, against the CPU oracle walking the same continuation."""
+    import importlib.util
+    from oracle import pnp_physical as PH
+    spec = importlib.util.spec_from_file_location('co2r_physical_sweep', os.path.join(os.path.dirname(__file__), '..', 'examples',
+                                                                                       'co2r_physical_sweep.py'))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    tp, phis = ex.build(4, 160)
+    names = list(tp.species.keys())
+    rate = ex.tafel_rate(tp)
+    calc = Calculator(transport=tp, calc='comsol')
+    tp.newton = {'tol': 1e-9, 'maxit': 80}
+    calc.set_surface_kinetics([{'species': 'CO2', 'rate': rate, 'stoichiometry': {'CO2': -1.0, 'CO': 1.0, 'OH-': 2.0}}])
+    calc.run()
+    assert np.all(calc.status == 0) and calc.continuation_stages >= 20
+    rx = [{'lhs': [names.index(x) for x in r['reactants'][0]], 'rhs': [names.index(x) for x in r['reactants'][1]],
+           'kf': r['rates'][0], 'kr': r['rates'][1]} for r in tp.reactions.values()]
+    cb = np.array([tp.species[s]['bulk_concentration'] for s in names])
+    nu = [0.0] * 7
+    nu[names.index('CO2')], nu[names.index('CO')], nu[names.index('OH-')] = -1.0, 1.0, 2.0
+    for lane in (0, 3):
+        c = np.repeat(cb[:, None], tp.nx, axis=1); phi = np.zeros(tp.nx)
+        for w in np.arange(1, calc.continuation_stages + 1) / float(calc.continuation_stages):
+            pm = 0.16 + (phis[lane] - 0.16) * w
+            p = PH.PhysicalProblem(D=tp.D, charges=tp.charges, beta=tp.beta, eps=tp.eps, dx=tp.dx, nx=tp.nx, c_bulk=cb, phiM=pm,
+                                   stern_capacitance=0.2, phi_pzc=0.16, mpb_radius=[tp.species[s].get('MPB_radius', 0.0) for s in names],
+                                   reactions=rx, x=tp.xmesh,
+                                   wall_kinetics=[{'species': names.index('CO2'), 'k': float(rate(np.array([pm]))[0]), 'nu': nu}])
+            c, phi, it, _ = PH.newton_step(p, c, phi, c, np.inf, tol=1e-9, maxit=80)
+            assert it <= 80
+        d = tp.alldata[lane]
+        got = np.array([d['species'][sp]['concentration'] for sp in names])
+        scale = np.abs(c).max(axis=1, keepdims=True)
+        assert (np.abs(got - c) / scale).max() < 1e-6
+        assert np.abs(np.array(d['system']['potential']) - phi).max() < 1e-7
+    j = calc.kinetic_flux[:, names.index('CO')]
+    assert j[0] > 0 and j[1] > 5 * j[0]           # Tafel region, then the CO2-transport plateau

@@ -171,7 +171,7 @@ def test_wall_fluxes():
 def test_homogeneous_reactions_point_ions():
     # K+ / HCO3- / CO3^2- style buffer: species 1 <-> species 4 exchange plus a dimerisation, bulk out of equilibrium
     rx = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [2, 2], 'rhs': [3], 'kf': 3e3, 'kr': 0.0},
-          {'lhs': [0, 1], 'rhs': [3], 'kf': 1e3, 'kr': 2e4}]
+          {'lhs': [0, 1], 'rhs': [3], 'kf': 1e3, 'kr': 2e4}, {'lhs': [], 'rhs': [0, 1], 'kf': 2e3, 'kr': 1.5e2}]   # last: H2O <-> A+ + B-
     got, ref = run_both(4, 120, B=4, seed=31, reactions=rx, points_per_debye=2.0)
     assert_close(got, ref)
 
