@@ -337,6 +337,8 @@ class Calculator(object):
             cout, status, (v, g, l) = self.integrate_pnp_batch(c0, pb, vz, flux)
         self.status = status
         names = list(tp.species.keys())
+        from .units import unit_NA
+        radii = np.array([float(tp.species[sp].get('MPB_radius', 0.0)) for sp in names])
         for i in range(B):
             cfin = cout[-1, i].reshape(tp.nspecies, tp.nx)
             d = tp.alldata[i]
@@ -345,6 +347,29 @@ class Calculator(object):
             d['system'] = {'potential': v[i].copy(), 'efield': -g[i], 'charge_density': -l[i] * tp.eps,
                            'surface_potential': float(v[i, 0]), 'surface_efield': float(-g[i, 0]),
                            keys[0]: lanes[i][0], keys[1]: lanes[i][1], 'status': int(status[i])}
+            if self.physical:
+                # derived fields of the COMSOL reader (comsol_reader.py:57-90, :196-230, :241-261)
+                gamma = 1.0 / (1.0 - (unit_NA * radii[:, None] ** 3 * cfin).sum(axis=0))
+                kf = getattr(self, 'kinetic_flux', None)
+                for k, sp in enumerate(names):
+                    d['species'][sp]['activity_coefficient'] = gamma.copy()
+                    d['species'][sp]['surface_activity_coefficient'] = float(gamma[0])
+                    d['species'][sp]['electrode_flux'] = float(flux[i, k] + (kf[i, k] if kf is not None else 0.0))
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    if 'H+' in names:
+                        ph = -np.log10(cfin[names.index('H+')] / 1000.)
+                    elif 'OH-' in names:
+                        ph = 14 + np.log10(cfin[names.index('OH-')] / 1000.)
+                    else:
+                        ph = None
+                if ph is not None:
+                    d['system']['pH'] = ph - np.log10(gamma)
+                    d['system']['surface_pH'] = float(ph[0] - np.log10(gamma[0]))
+                d['system']['activity_coefficient'] = gamma.copy()
+                es = tp.system.get('Stern epsilon', None)
+                if isinstance(es, (int, float)) and es:
+                    d['system']['Stern_efield'] = float(-g[i, 0]) * tp.system['epsilon'] / es
+                    d['system']['Stern_epsilon_func'] = es
         return cout
 
     # ------------------------------------------------------------------------------------------

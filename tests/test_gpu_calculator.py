@@ -195,6 +195,11 @@ def test_comsol_calculator_is_the_implicit_gpu_solve_and_matches_the_oracle():
         assert np.abs(d['system']['potential'] - phi).max() <= 1e-7
         # most of the applied potential drops over the Stern layer; the diffuse layer sees what is left
         assert abs(d['system']['surface_potential']) < abs(phiM - 0.1)
+    # derived fields of the COMSOL reader (comsol_reader.py:57-90): activity coefficient, (no H+/OH- here -> no pH)
+    d0 = tp.alldata[0]
+    g0 = 1.0 / (1.0 - 6.022140857e23 * 4.1e-10 ** 3 * np.array(d0['species']['K+']['concentration']))
+    assert np.allclose(d0['species']['CO2']['activity_coefficient'], g0) and d0['species']['K+']['surface_activity_coefficient'] == g0[0]
+    assert np.allclose(d0['system']['efield'][1:-1], -(np.array(d0['system']['potential'])[2:] - np.array(d0['system']['potential'])[:-2]) / (2 * tp.dx))
     cK = [tp.alldata[i]['species']['K+']['surface_concentration'] for i in range(len(phis))]
     assert cK[0] > cK[1] > cK[2] > cK[3]                   # cations pile up at negative potentials ...
     assert cK[0] < 1.0 / (6.022140857e23 * 4.1e-10 ** 3)   # ... but never beyond close packing
