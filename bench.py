@@ -5,7 +5,7 @@
 One "step" = one pass of the integrator's time-loop body (reference catint/calculator_old.py:512-558)
 over one batch of B operating points.  Headline ("state written every step
 (ntout = nt)", algorithmic bytes 16*(N+1)*nx per lane-step): the reference's time loop runs inside the
-kernel, `--steps-per-launch` timesteps per launch (default 64, what pnp_integrate uses); every step's new
+kernel, `--steps-per-launch` timesteps per launch (default 256, what pnp_step/pnp_integrate use); every step's new
 state is written to HBM, the previous state is re-used from registers/LDS instead of being re-read, so the
 MEASURED HBM traffic (roofline.traffic, rocprofv3) is about half the algorithmic figure.  The
 one-launch-per-timestep variant (state read from and written to HBM by every launch) is reported next to
@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--nspecies', type=int, default=3)
     ap.add_argument('--nx', type=int, default=512)
     ap.add_argument('--method', default='Crank-Nicolson')
-    ap.add_argument('--steps-per-launch', type=int, default=64,
+    ap.add_argument('--steps-per-launch', type=int, default=256,
                     help='timesteps fused into one launch (state written to HBM every step); 1 = one launch per step')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline sample length')
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -593,7 +593,7 @@ int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch) {
     if (nsteps == 0) return PNP_OK;
     return run_newton(h, nsteps, false, 0.0, 0);
   }
-  int spl = steps_per_launch <= 0 ? 64 : steps_per_launch;
+  int spl = steps_per_launch <= 0 ? 256 : steps_per_launch;   // kernel boundaries cost ~6 us each
   if (h->a.has_rates) spl = 1;
   int left = nsteps;
   while (left > 0) {

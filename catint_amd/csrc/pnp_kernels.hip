@@ -557,6 +557,7 @@ __global__ __launch_bounds__(64 * W, (step_min_waves<P, G>())) void step_kernel(
 
   for (int step = 0; step < A.nsteps; ++step) {
     const bool resident = single_round && step > 0;   // rows (and LV) already in LDS from the last step
+    const bool last_step = step + 1 == A.nsteps;
     // ---- 0. all global reads of the first round go out together ------------------------------------
     if (!resident) {
       RowRegs<P> rl, rr[G];
@@ -755,10 +756,12 @@ __global__ __launch_bounds__(64 * W, (step_min_waves<P, G>())) void step_kernel(
           accp[it].x = __builtin_fma(-t.x, qe, accp[it].x);
           accp[it].y = __builtin_fma(-t.y, qe, accp[it].y);
           // beyond the pitch the staged row holds the don't-care values of the padded unknowns
-          const bool inrow = 2 * tid + 128 * W * it < ldx;
-          const double sx = inrow ? t.x : 0.0, sy = inrow ? t.y : 0.0;
-          chk += (sx - sx) + (sy - sy);
-          mn = fmin(mn, fmin(sx, sy));
+          if (last_step) {   // status of the state this launch leaves behind (the reference tests after the solve, calculator.py:409-414)
+            const bool inrow = 2 * tid + 128 * W * it < ldx;
+            const double sx = inrow ? t.x : 0.0, sy = inrow ? t.y : 0.0;
+            chk += (sx - sx) + (sy - sy);
+            mn = fmin(mn, fmin(sx, sy));
+          }
         }
       }
       wg_sync<W>();
@@ -914,6 +917,7 @@ __global__ __launch_bounds__(64 * W, (step_rr_min_waves<P, W>())) void step_kern
   double lw[P + 2];        // lagged charge row window: lapl_v[r0 + t]
   double cc[P + 2];        // concentration window of the species in flight: C[k][r0 + t]
   for (int step = 0; step < A.nsteps; ++step) {
+    const bool last_step = step + 1 == A.nsteps;
     const bool resident = single_round && step > 0;
     if (!resident) {
       if (A.use_mig) load_window<P>(row_rsrc(lin, ldx), lw, lane);
@@ -1047,11 +1051,15 @@ __global__ __launch_bounds__(64 * W, (step_rr_min_waves<P, W>())) void step_kern
       for (int j = 0; j < P; ++j) {
         const double xv = (r0 + j < m) ? x[0][j] : 0.0;
         acc[j] = __builtin_fma(-xv, qe, acc[j]);
-        chk += xv - xv;
-        mn = fmin(mn, xv);
+        if (last_step) {   // status of the state this launch leaves behind (calculator.py:409-414 tests after the solve)
+          chk += xv - xv;
+          mn = fmin(mn, xv);
+        }
       }
-      chk += c0new - c0new;
-      mn = fmin(mn, c0new);
+      if (last_step) {
+        chk += c0new - c0new;
+        mn = fmin(mn, c0new);
+      }
       acc0 = __builtin_fma(-c0new, qe, acc0);
       accL = __builtin_fma(-cL, qe, accL);
       if (single_round) {   // next step's window from registers: own rows + one DPP hop for each halo point
@@ -1391,6 +1399,7 @@ __global__ __launch_bounds__(64 * WY, 1) void step_kernel_mw(const DevArgs A) {
   const int ls2 = pidx<P>(2 * tid);
 
   for (int step = 0; step < A.nsteps; ++step) {
+    const bool last_step = step + 1 == A.nsteps;
     // ---- 1. lagged potential ---------------------------------------------------------------------
     double v1 = 0.0;
     if (A.use_mig) {
@@ -1499,10 +1508,12 @@ __global__ __launch_bounds__(64 * WY, 1) void step_kernel_mw(const DevArgs A) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), rs, tid * 16 + it * (1024 * WY), 0, 0);
         accp[it].x = __builtin_fma(-t.x, qe, accp[it].x);
         accp[it].y = __builtin_fma(-t.y, qe, accp[it].y);
-        const bool inrow = 2 * tid + 128 * WY * it < ldx;
-        const double sx = inrow ? t.x : 0.0, sy = inrow ? t.y : 0.0;
-        chk += (sx - sx) + (sy - sy);
-        mn = fmin(mn, fmin(sx, sy));
+        if (last_step) {
+          const bool inrow = 2 * tid + 128 * WY * it < ldx;
+          const double sx = inrow ? t.x : 0.0, sy = inrow ? t.y : 0.0;
+          chk += (sx - sx) + (sy - sy);
+          mn = fmin(mn, fmin(sx, sy));
+        }
       }
       wg_sync<2>();
     }

@@ -42,7 +42,7 @@ toks = args.split()
 def opt(name, default):
     return int(toks[toks.index(name) + 1]) if name in toks else default
 rec = {'batch': opt('--batch', 1024), 'nspecies': opt('--nspecies', 3), 'nx': opt('--nx', 512),
-       'steps_per_launch': opt('--steps-per-launch', 64), 'method': 'Crank-Nicolson',
+       'steps_per_launch': opt('--steps-per-launch', 256), 'method': 'Crank-Nicolson',
        'hbm_bytes_per_launch': hbm, 'fetch_size_kib': fs, 'write_size_kib': ws,
        'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024',
        'kernel': meta.get('Kernel_Name')}

@@ -4,7 +4,7 @@
 tag=${1:-r01}; shift
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 O=$R/gpurun_out/profile_$tag; mkdir -p $O
-ARGS="--no-cpu-baseline --no-fused --large-batch 0 --physical-steps 0 --steps 256 --warmup 64 $@"
+ARGS="--no-cpu-baseline --no-fused --large-batch 0 --physical-steps 0 --steps 256 --warmup 256 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py $ARGS > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py $ARGS > $O/write.log 2>&1
