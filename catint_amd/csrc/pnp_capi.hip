@@ -700,7 +700,6 @@ int pnp_get_state(pnp_handle* h, double* c, double* v, double* grad_v, double* l
       HIP_TRY(h, hipMemcpy2DAsync(cc.data(), w, h->c, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const double dx = h->a.dx;
     for (int64_t b = 0; b < B; ++b) {
       if (v) memcpy(v + (size_t)b * nx, ph.data() + (size_t)b * nx, w);
       if (grad_v) {

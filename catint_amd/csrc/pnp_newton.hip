@@ -11,9 +11,10 @@
 //
 // Mapping: one operating point per workgroup; a thread owns whole block rows (all N+1 unknowns of a grid point), so
 // the dense (N+1)^3 block algebra of cyclic reduction runs in registers with no cross-lane traffic, and rows are
-// exchanged between PCR levels through element-major ping-pong buffers (coalesced: consecutive threads touch
-// consecutive addresses).  The buffers live in LDS when both fit, else in a per-workgroup slice of device memory that
-// stays L2/MALL resident.
+// exchanged between reduction levels through element-major buffers (coalesced: consecutive threads touch consecutive
+// addresses) in LDS or, for shapes that do not fit, in a per-workgroup slice of device memory.  Two kernels:
+// newton_pair_kernel (N <= 4, nx <= 1024: register-resident rows, parallel cyclic reduction through one LDS buffer) and
+// newton_kernel (everything else: in-place cyclic reduction).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -75,7 +76,7 @@ __device__ __forceinline__ void block_solve(double (&M)[NB][NB], double (&X)[NB]
 // Element-major row store: element e of block row `row` lives at buf[e*RS + row].
 // Element order: Ltilde (NB*NB, row-major), Utilde (NB*NB), rtilde (NB).
 template <int NB>
-__device__ __forceinline__ void store_row(double* __restrict__ buf, int RS, int row, const double (&X)[NB][2 * NB + 1]) {
+__device__ __forceinline__ void store_row(double* buf, int RS, int row, const double (&X)[NB][2 * NB + 1]) {
   double* p = buf + row;
 #pragma unroll
   for (int r = 0; r < NB; ++r)
@@ -89,7 +90,7 @@ __device__ __forceinline__ void store_row(double* __restrict__ buf, int RS, int 
 }
 
 template <int NB>
-__device__ __forceinline__ void load_block(const double* __restrict__ buf, int RS, int row, int which, double (&Bk)[NB][NB]) {
+__device__ __forceinline__ void load_block(const double* buf, int RS, int row, int which, double (&Bk)[NB][NB]) {
   const double* p = buf + row + (size_t)which * NB * NB * RS;
 #pragma unroll
   for (int r = 0; r < NB; ++r)
@@ -98,7 +99,7 @@ __device__ __forceinline__ void load_block(const double* __restrict__ buf, int R
 }
 
 template <int NB>
-__device__ __forceinline__ void load_rhs(const double* __restrict__ buf, int RS, int row, double (&v)[NB]) {
+__device__ __forceinline__ void load_rhs(const double* buf, int RS, int row, double (&v)[NB]) {
   const double* p = buf + row + (size_t)2 * NB * NB * RS;
 #pragma unroll
   for (int r = 0; r < NB; ++r) v[r] = p[(size_t)r * RS];
@@ -108,7 +109,7 @@ __device__ __forceinline__ void load_rhs(const double* __restrict__ buf, int RS,
 // Substituting rows row-s and row+s (absent rows beyond either end contribute nothing):
 //   (I - Lt Ut[-s] - Ut Lt[+s]) x[row] - Lt Lt[-s] x[row-2s] - Ut Ut[+s] x[row+2s] = rt - Lt rt[-s] - Ut rt[+s]
 template <int NB>
-__device__ __forceinline__ void pcr_row(const double* __restrict__ src, double* __restrict__ dst, int RS, int row, int s, int n) {
+__device__ __forceinline__ void pcr_row(const double* src, double* dst, int RS, int row, int s, int n) {   // dst may be src
   constexpr int NC = 2 * NB + 1;
   double Lt[NB][NB], Ut[NB][NB], rt[NB];
   load_block<NB>(src, RS, row, 0, Lt);
@@ -173,6 +174,33 @@ __device__ __forceinline__ void pcr_row(const double* __restrict__ src, double* 
   store_row<NB>(dst, RS, row, X);
 }
 
+// Back-substitution of cyclic reduction for a row eliminated at stride s:  x[row] = rt - Lt x[row-s] - Ut x[row+s];
+// solutions live in the rhs slots.
+template <int NB>
+__device__ __forceinline__ void cr_backsub_row(double* buf, int RS, int row, int s, int n) {
+  double x[NB], Q[NB][NB], xv[NB];
+  load_rhs<NB>(buf, RS, row, x);
+  if (row - s >= 0) {
+    load_block<NB>(buf, RS, row, 0, Q);
+    load_rhs<NB>(buf, RS, row - s, xv);
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) x[r] = __builtin_fma(-Q[r][j], xv[j], x[r]);
+  }
+  if (row + s < n) {
+    load_block<NB>(buf, RS, row, 1, Q);
+    load_rhs<NB>(buf, RS, row + s, xv);
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) x[r] = __builtin_fma(-Q[r][j], xv[j], x[r]);
+  }
+  double* p = buf + row + (size_t)2 * NB * NB * RS;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) p[(size_t)r * RS] = x[r];
+}
+
 // Scharfetter-Gummel flux of one species across one edge (left point l, right point r), scaled by dx/D:
 //   J = -(B(-u) c_r - B(u) c_l),  u = psi_r - psi_l;   Ju = dJ/du;   dJ/dc_l = Bp, dJ/dc_r = -Bm
 struct Edge {
@@ -205,7 +233,7 @@ struct Point {
 };
 
 template <int N, int MODE>
-__device__ __forceinline__ Point<N, MODE> load_point(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ phi,
+__device__ __forceinline__ Point<N, MODE> load_point(const NewtonArgs& A, const double* c, const double* phi,
                                                    int i) {
   constexpr bool MPB = MODE >= 1;
   Point<N, MODE> P;
@@ -241,9 +269,9 @@ __device__ __forceinline__ void edge_fluxes(const NewtonArgs& A, const Point<N, 
 // At the wall the left edge, at the bulk both edges are switched off by 0/1 weights (their values are finite: the
 // neighbour index is clamped).
 template <int NB, int MODE>
-__device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ co,
-                                         const double* __restrict__ flux, const double* __restrict__ wk,
-                                         const double* __restrict__ cb, double phiM, double phiB, int i,
+__device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* c, const double* co,
+                                         const double* flux, const double* wk,
+                                         const double* cb, double phiM, double phiB, int i,
                                          const Point<NB - 1, MODE>& Pm, const Point<NB - 1, MODE>& P0,
                                          const Point<NB - 1, MODE>& Pp, const Edge (&em)[NB - 1], const Edge (&ep)[NB - 1],
                                          double wem, double wep, double vi, double (&M)[NB][NB],
@@ -265,54 +293,6 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
   const double wm = (wall || bulk) ? 0.0 : 1.0;
   const double ws = bulk ? 0.0 : vi;     // control volume / dx: 1 inside a uniform grid, 1/2 at the wall
   const double wf = wall ? 1.0 : 0.0;
-  // homogeneous reactions: mass action in activities a_j = c_j gam, every reaction summed
-  // (comsol_model.py:781-867, :1064-1084; oracle/pnp_physical.py: reaction_rates).  The species indices of the table
-  // are run-time values, so this block works on small thread-private arrays (scratch memory).
-  double Rk[N], dR[N][N];
-  if constexpr (REACT) {
-    const ReactionTable* __restrict__ rt = A.rt;
-    double cl[N], gl[N], dprod[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      cl[k] = P0.c[k];
-      gl[k] = P0.g[k];
-      Rk[k] = 0.0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) dR[k][j] = 0.0;
-    }
-    const int nr = rt->n;
-    for (int r = 0; r < nr; ++r) {
-      const int nl = rt->n_lhs[r], nrh = rt->n_rhs[r];
-      for (int side = 0; side < 2; ++side) {
-        const int n = side == 0 ? nl : nrh;
-        const int32_t* idx = side == 0 ? rt->lhs[r] : rt->rhs[r];
-        const double kk = side == 0 ? rt->kf[r] : rt->kr[r];
-        if (kk == 0.0) continue;             // n = 0: constant rate (the side consists of excluded species, e.g. H2O)
-        double pre = kk;
-        for (int a = 0; a < n; ++a) pre *= P0.gam;
-        double prod = pre;
-        for (int a = 0; a < n; ++a) prod *= cl[idx[a]];
-        for (int j = 0; j < N; ++j) dprod[j] = prod * n * gl[j];     // through gam; gl = 0 for point ions
-        for (int a = 0; a < n; ++a) {
-          double rest = pre;
-          for (int b2 = 0; b2 < n; ++b2)
-            if (b2 != a) rest *= cl[idx[b2]];
-          dprod[idx[a]] += rest;
-        }
-        const double sgn = side == 0 ? 1.0 : -1.0;                    // forward minus backward
-        for (int a = 0; a < nl; ++a) {
-          const int j = rt->lhs[r][a];
-          Rk[j] -= sgn * prod;
-          for (int jj = 0; jj < N; ++jj) dR[j][jj] -= sgn * dprod[jj];
-        }
-        for (int a = 0; a < nrh; ++a) {
-          const int j = rt->rhs[r][a];
-          Rk[j] += sgn * prod;
-          for (int jj = 0; jj < N; ++jj) dR[j][jj] += sgn * dprod[jj];
-        }
-      }
-    }
-  }
   double rho = 0.0;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -337,11 +317,56 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
         X[k][j] += Jum * Pm.g[j];
       }
     }
-    if constexpr (REACT) {       // source term on the (half) cell: -(dx^2/D_k) R_k, none on the bulk Dirichlet row
-      const double wr = ws * A.rs[k];
-      X[k][2 * NB] += wr * Rk[k];
+  }
+  // homogeneous reactions: mass action in activities a_j = c_j gam, every reaction summed
+  // (comsol_model.py:781-867, :1064-1084; oracle/pnp_physical.py: reaction_rates): source -(dx^2/D_k) v_i R_k on the (half)
+  // cell, none on the bulk Dirichlet row.  The species indices of the table are run-time values; every access is a
+  // compile-time-indexed loop with a compare and the contributions go straight into M and the right-hand side.
+  if constexpr (REACT) {
+    const ReactionTable* rt = A.rt;
+    auto pick = [&](int idx) {
+      double v = 0.0;
 #pragma unroll
-      for (int j = 0; j < N; ++j) M[k][j] -= wr * dR[k][j];
+      for (int k = 0; k < N; ++k) v = (k == idx) ? P0.c[k] : v;
+      return v;
+    };
+    const int nr = rt->n;
+    for (int r = 0; r < nr; ++r) {
+      const int nl = rt->n_lhs[r], nrh = rt->n_rhs[r];
+      for (int side = 0; side < 2; ++side) {
+        const int n = side == 0 ? nl : nrh;
+        const int32_t* idx = side == 0 ? rt->lhs[r] : rt->rhs[r];
+        const double kk = side == 0 ? rt->kf[r] : rt->kr[r];
+        if (kk == 0.0) continue;             // n = 0: constant rate (the side consists of excluded species, e.g. H2O)
+        double pre = kk;
+        for (int a = 0; a < n; ++a) pre *= P0.gam;
+        double prod = pre;
+        for (int a = 0; a < n; ++a) prod *= pick(idx[a]);
+        double dprod[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) dprod[j] = MPB ? prod * n * P0.g[j] : 0.0;     // through gam; g = 0 for point ions
+        for (int a = 0; a < n; ++a) {
+          double rest = pre;
+          for (int b2 = 0; b2 < n; ++b2)
+            if (b2 != a) rest *= pick(idx[b2]);
+          const int ia = idx[a];
+#pragma unroll
+          for (int j = 0; j < N; ++j) dprod[j] += (j == ia) ? rest : 0.0;
+        }
+        const double sgn = side == 0 ? 1.0 : -1.0;                    // forward minus backward
+        for (int a = 0; a < nl + nrh; ++a) {
+          const bool left = a < nl;
+          const int jsp = left ? rt->lhs[r][a] : rt->rhs[r][a - nl];
+          const double w = left ? -sgn : sgn;                          // educts lose, products gain
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const double wr = (k == jsp) ? w * ws * A.rs[k] : 0.0;
+            X[k][2 * NB] = __builtin_fma(wr, prod, X[k][2 * NB]);
+#pragma unroll
+            for (int jj = 0; jj < N; ++jj) M[k][jj] = __builtin_fma(-wr, dprod[jj], M[k][jj]);
+          }
+        }
+      }
     }
   }
   // first-order surface reactions: flux into the domain nu_k K c_s(0) joins the prescribed wall flux, so the kinetics <->
@@ -384,9 +409,9 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* __re
 }
 
 template <int NB, int MODE>
-__device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* __restrict__ c, const double* __restrict__ co,
-                                             const double* __restrict__ phi, const double* __restrict__ flux,
-                                             const double* __restrict__ wk, const double* __restrict__ cb, double phiM,
+__device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* c, const double* co,
+                                             const double* phi, const double* flux,
+                                             const double* wk, const double* cb, double phiM,
                                              double phiB, int i,
                                              double (&M)[NB][NB], double (&X)[NB][2 * NB + 1]) {
   constexpr int N = NB - 1;
@@ -409,7 +434,7 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // One workgroup per operating point (grid-stride over the batch).  blockDim.x = T threads, thread t owns block rows
-// t, t+T, ...  Dynamic LDS: the two PCR buffers when A.work == nullptr.
+// t, t+T, ...  Dynamic LDS: the row buffer when A.work == nullptr.
 // Launch bounds: every kernel of this file is compiled for at most 256 registers per thread (bound 512).  With the
 // 512-register budget (bound 256) the N >= 6 instances spilled into the accumulator half of the register file and
 // then produced run-to-run different, sometimes wrong, solutions on MI355X (tools/probe/repro_newton.py); with 256
@@ -418,13 +443,11 @@ template <int NB, int TMAX, int MODE>
 __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
   constexpr int N = NB - 1;
   constexpr bool MPB = MODE >= 1;
-  constexpr int NE = 2 * NB * NB + NB;
   extern __shared__ double newton_lds[];
   __shared__ double red[2][16];
   const int tid = threadIdx.x, T = blockDim.x;
   const int nx = A.nx, ldx = A.ldx, RS = A.RS;
   double* buf0 = A.work ? A.work + (size_t)blockIdx.x * A.work_stride : newton_lds;
-  double* buf1 = buf0 + (size_t)NE * RS;
   for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
     double* c = A.c + (size_t)b * N * ldx;
     double* co = A.c_old + (size_t)b * N * ldx;
@@ -447,14 +470,19 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
           store_row<NB>(buf0, RS, row, X);
         }
         __syncthreads();
+        // Block cyclic reduction, in place: at stride s the rows i = 2s-1 (mod 2s) absorb their neighbours i-s, i+s
+        // (which nobody writes at this level and which keep their form for the back-substitution).  Total work ~2 nx
+        // row operations instead of nx log2(nx) for PCR: this kernel serves the large blocks / long grids whose rows do
+        // not fit on chip, where the exchange traffic through device memory is what binds.
         double* src = buf0;
-        double* dst = buf1;
-        for (int s = 1; s < nx; s <<= 1) {
-          for (int row = tid; row < nx; row += T) pcr_row<NB>(src, dst, RS, row, s, nx);
+        int s = 1;
+        for (; s < nx; s <<= 1) {
+          for (int row = 2 * s - 1 + tid * 2 * s; row < nx; row += T * 2 * s) pcr_row<NB>(src, src, RS, row, s, nx);
           __syncthreads();
-          double* t_ = src;
-          src = dst;
-          dst = t_;
+        }
+        for (s >>= 1; s >= 1; s >>= 1) {
+          for (int row = s - 1 + tid * 2 * s; row < nx; row += T * 2 * s) cr_backsub_row<NB>(src, RS, row, s, nx);
+          __syncthreads();
         }
         // src holds the Newton update in its rhs slots
         double mphi = 0.0, upd = 0.0;
@@ -896,9 +924,9 @@ int newton_threads(int nb, int nx) {
   return t < tmax ? t : tmax;
 }
 
-size_t newton_exchange_doubles(int nb, int nx) {   // both ping-pong buffers of one workgroup
+size_t newton_exchange_doubles(int nb, int nx) {   // the row buffer of one workgroup (cyclic reduction works in place)
   const size_t rs = (size_t)(nx + 15) / 16 * 16;
-  return 2 * (size_t)(2 * nb * nb + nb) * rs;
+  return (size_t)(2 * nb * nb + nb) * rs;
 }
 
 bool newton_exchange_in_lds(int nb, int nx) {

@@ -215,6 +215,27 @@ def test_graded_grid(N, nx, kw, monkeypatch):
     assert_close(got, ref)
 
 
+@pytest.mark.parametrize("N", [2, 3, 4, 5, 6, 7, 8])
+def test_zero_rate_reaction_table_changes_nothing(N, monkeypatch):
+    """The reaction-enabled kernel variant with an all-zero rate table must reproduce the plain variant bit for bit, in both
+    kernel families (guards the instantiation-specific miscompile seen for N = 7)."""
+    for kern in ('', 'generic'):
+        monkeypatch.setenv('CATINT_NEWTON_KERNEL', kern)
+        D, q, cb, dx, phiM = make_lanes(N, 72, 3, 5)
+        c0 = np.repeat(cb[:, :, None], 72, axis=2)
+        pb = np.zeros((3, 4)); pb[:, 0] = phiM
+        out = []
+        for table in (None, [([0, min(1, N - 1)], [0], 0.0, 0.0)]):
+            with _capi.PnpSolver(N, 72, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=3) as s:
+                s.set_newton(mpb_radius=[4.1e-10] + [0.0] * (N - 1))
+                if table:
+                    s.set_reactions(table)
+                s.set_batch(c0, pb, np.zeros(3), np.zeros((3, N)))
+                st = s.solve_stationary()
+                out.append((s.get_state()[0], s.newton_iterations(), st))
+        assert np.all(out[0][2] == 0) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+
+
 def test_not_converged_is_reported():
     got, ref = run_both(2, 64, B=3, seed=3, newton_kw=dict(maxit=2))
     assert np.all(got[3] == _capi.STATUS_MAXIT)
