@@ -236,6 +236,28 @@ def test_zero_rate_reaction_table_changes_nothing(N, monkeypatch):
         assert np.all(out[0][2] == 0) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
 
 
+def test_integrate_entry_point_writes_outputs_at_itout():
+    N, nx, B = 3, 96, 3
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 23)
+    dt = 5e-9
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4)); pb[:, 0] = phiM
+    itout = [2, 5, 7]
+    with _capi.PnpSolver(N, nx, dx, dt, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+        s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+        cout, st = s.integrate(8, itout)              # loop n = 1..7: the state after n backward-Euler steps is t_n
+    assert np.all(st == 0) and cout.shape == (3, B, N * nx)
+    for b in range(B):
+        p = PH.PhysicalProblem(D=D, charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=cb[b], phiM=phiM[b])
+        cc, ph = c0[b].copy(), np.zeros(nx)
+        k = 0
+        for n in range(1, 8):
+            cc, ph, _, _ = PH.newton_step(p, cc, ph, cc, dt)
+            if n in itout:
+                assert np.abs(cout[k, b].reshape(N, nx) - cc).max() <= 2e-9 * np.abs(cc).max()
+                k += 1
+
+
 def test_not_converged_is_reported():
     got, ref = run_both(2, 64, B=3, seed=3, newton_kw=dict(maxit=2))
     assert np.all(got[3] == _capi.STATUS_MAXIT)
