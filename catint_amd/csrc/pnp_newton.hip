@@ -943,14 +943,16 @@ int newton_pair_threads(int nb, int nx) {
   const int tmax = nb <= 4 ? 512 : 256;
   const int t = ((nx + 1) / 2 + 63) / 64 * 64;
   if (t > tmax) return 0;
-  const int ts = t <= 256 ? 256 : 512;
+  const int ts = t <= 64 ? 64 : (t <= 128 ? 128 : (t <= 256 ? 256 : 512));
   if ((size_t)(2 * nb * nb + nb) * ts * sizeof(double) > kLdsBudget) return 0;
   return t;
 }
 
+// compile-time row stride of the LDS exchange buffer: the smallest of 64/128/256/512 that holds the threads (a short grid
+// then leaves LDS for several workgroups per CU)
 int newton_pair_stride(int nb, int nx) {
   const int t = newton_pair_threads(nb, nx);
-  return t == 0 ? 0 : (t <= 256 ? 256 : 512);
+  return t == 0 ? 0 : (t <= 64 ? 64 : (t <= 128 ? 128 : (t <= 256 ? 256 : 512)));
 }
 
 template <int NB, int TS>
@@ -976,6 +978,8 @@ static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t 
   const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
   if constexpr (NB <= 5) {
     if (tp > 0) {
+      if (tp <= 64) return launch_pair<NB, 64>(a, blocks, tp, stream);
+      if (tp <= 128) return launch_pair<NB, 128>(a, blocks, tp, stream);
       if (tp <= 256) return launch_pair<NB, 256>(a, blocks, tp, stream);
       if constexpr (NB <= 4) return launch_pair<NB, 512>(a, blocks, tp, stream);
     }

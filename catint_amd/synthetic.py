@@ -17,6 +17,7 @@ SPECIES_TABLE = {
 SPECIES_SETS = {
     2: ['K+', 'HCO3-'],
     3: ['K+', 'Cl-', 'HCO3-'],
+    4: ['K+', 'Na+', 'Cl-', 'HCO3-'],
     6: ['K+', 'Na+', 'Cl-', 'HCO3-', 'CO32-', 'OH-'],
     8: ['K+', 'Na+', 'Cl-', 'HCO3-', 'CO32-', 'OH-', 'Cs+', 'ClO4-'],
 }
