@@ -174,6 +174,114 @@ __device__ __forceinline__ void pcr_row(const double* src, double* dst, int RS, 
   store_row<NB>(dst, RS, row, X);
 }
 
+// The same row operation organised for blocks that do not fit the register file (used for N = 4..6): only D (then D^-1,
+// inverted in place) and one operand block stay in registers.  D is accumulated as a sum of outer products, the new row is
+// produced column by column (y = -Lt Lm[:,j], x = D^-1 y) and every column is stored as soon as it is complete; the other
+// operands are streamed from the row buffer.  Live set ~ 2 NB^2 + 3 NB doubles instead of ~ 6 NB^2 (measured: +20 % at
+// N = 6; for N >= 7 even two blocks overflow the 256 registers and the plain version is as fast).  Works in place: the own
+// Lt (Ut) block is in registers before its new columns are stored, neighbours are never written at this level.
+template <int NB>
+__device__ __forceinline__ void cr_row_streamed(double* buf, int RS, int row, int s, int n) {
+  const bool hm = row - s >= 0, hp = row + s < n;
+  double* own = buf + row;
+  const double* nm = buf + (hm ? row - s : row);
+  const double* np_ = buf + (hp ? row + s : row);
+  auto EL = [&](const double* p, int which, int r, int cc) { return p[(size_t)(which * NB * NB + r * NB + cc) * RS]; };
+  auto ER = [&](const double* p, int r) { return p[(size_t)(2 * NB * NB + r) * RS]; };
+  // ---- D = I - Lt Um - Ut Lp as a sum of outer products (column j of Lt/Ut times row j of Um/Lp)
+  double D[NB][NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int cc = 0; cc < NB; ++cc) D[r][cc] = (r == cc) ? 1.0 : 0.0;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const bool have = half == 0 ? hm : hp;
+    const double* nb_ = half == 0 ? nm : np_;
+    if (have) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        double a[NB], b[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) a[r] = EL(own, half, r, j);
+#pragma unroll
+        for (int cc = 0; cc < NB; ++cc) b[cc] = EL(nb_, 1 - half, j, cc);
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+          for (int cc = 0; cc < NB; ++cc) D[r][cc] = __builtin_fma(-a[r], b[cc], D[r][cc]);
+      }
+    }
+  }
+  // ---- D <- D^-1 (Gauss-Jordan in place; D = I - small products, no pivoting)
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const double p = nrcp(D[k][k]);
+    D[k][k] = 1.0;
+#pragma unroll
+    for (int cc = 0; cc < NB; ++cc) D[k][cc] *= p;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      if (r == k) continue;
+      const double f = D[r][k];
+      D[r][k] = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < NB; ++cc) D[r][cc] = __builtin_fma(-f, D[k][cc], D[r][cc]);
+    }
+  }
+  double xr[NB];        // new right-hand side, before the multiplication with D^-1
+#pragma unroll
+  for (int r = 0; r < NB; ++r) xr[r] = ER(own, r);
+  // ---- the two halves: new Lt = D^-1 (-Lt Lm), new Ut = D^-1 (-Ut Up)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const bool have = half == 0 ? hm : hp;
+    const double* nb_ = half == 0 ? nm : np_;
+    double W[NB][NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+      for (int cc = 0; cc < NB; ++cc) W[r][cc] = EL(own, half, r, cc);
+    double* o = own + (size_t)half * NB * NB * RS;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double col[NB], y[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) col[k] = have ? EL(nb_, half, k, j) : 0.0;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc = __builtin_fma(-W[r][k], col[k], acc);
+        y[r] = acc;
+      }
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc = __builtin_fma(D[r][k], y[k], acc);
+        o[(size_t)(r * NB + j) * RS] = acc;
+      }
+    }
+    if (have) {
+      double col[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) col[k] = ER(nb_, k);
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) xr[r] = __builtin_fma(-W[r][k], col[k], xr[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc = __builtin_fma(D[r][k], xr[k], acc);
+    own[(size_t)(2 * NB * NB + r) * RS] = acc;
+  }
+}
+
 // Back-substitution of cyclic reduction for a row eliminated at stride s:  x[row] = rt - Lt x[row-s] - Ut x[row+s];
 // solutions live in the rhs slots.
 template <int NB>
@@ -477,7 +585,10 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
         double* src = buf0;
         int s = 1;
         for (; s < nx; s <<= 1) {
-          for (int row = 2 * s - 1 + tid * 2 * s; row < nx; row += T * 2 * s) pcr_row<NB>(src, src, RS, row, s, nx);
+          for (int row = 2 * s - 1 + tid * 2 * s; row < nx; row += T * 2 * s) {
+            if constexpr (NB >= 5 && NB <= 7) cr_row_streamed<NB>(src, RS, row, s, nx);
+            else pcr_row<NB>(src, src, RS, row, s, nx);
+          }
           __syncthreads();
         }
         for (s >>= 1; s >= 1; s >>= 1) {
