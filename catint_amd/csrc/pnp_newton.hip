@@ -555,7 +555,12 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
   __shared__ double red[2][16];
   const int tid = threadIdx.x, T = blockDim.x;
   const int nx = A.nx, ldx = A.ldx, RS = A.RS;
-  double* buf0 = A.work ? A.work + (size_t)blockIdx.x * A.work_stride : newton_lds;
+  // N >= 4: the row buffer always lives in device memory, so its accesses compile to global_load/store; a pointer that
+  // may also be LDS costs flat instructions (both address paths, both wait counters) -- measured 90 % of the wave time
+  // waiting at N = 6 with flat accesses
+  double* buf0;
+  if constexpr (NB >= 5) buf0 = A.work + (size_t)blockIdx.x * A.work_stride;
+  else buf0 = A.work ? A.work + (size_t)blockIdx.x * A.work_stride : newton_lds;
   for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
     double* c = A.c + (size_t)b * N * ldx;
     double* co = A.c_old + (size_t)b * N * ldx;
@@ -1043,6 +1048,7 @@ size_t newton_exchange_doubles(int nb, int nx) {   // the row buffer of one work
 bool newton_exchange_in_lds(int nb, int nx) {
   const char* e = getenv("CATINT_NEWTON_EXCHANGE");        // "global" keeps the row-per-thread kernel's buffers in device memory (tests)
   if (e && e[0] == 'g') return false;
+  if (nb >= 5) return false;               // large blocks: always device memory (global instead of flat instructions)
   return newton_exchange_doubles(nb, nx) * sizeof(double) <= kLdsBudget;
 }
 
