@@ -239,7 +239,19 @@ def main():
         lsec = lms * 1e-3 / ls
         large = {'batch': LB, 'steps': ls, 'timesteps_per_s': LB / lsec, 'launch_us': lsec * 1e6,
                  'achieved_GBs': 16.0 * (N + 1) * nx * LB / lsec / 1e9,
-                 'frac': 16.0 * (N + 1) * nx * LB / lsec / 1e9 / HBM_PEAK_GBS, 'lanes_ok': lok}
+                 'frac': 16.0 * (N + 1) * nx * LB / lsec / 1e9 / HBM_PEAK_GBS, 'lanes_ok': lok, 'steps_per_launch': 1}
+        # the same batch in fused launches (like the headline)
+        s3 = solver_from_problem(lp, args.method, batch_capacity=LB, device=device)
+        s3.set_batch(lc0, lpb, lvz, lfl)
+        s3.step(8, 8)
+        s3.set_batch(lc0, lpb, lvz, lfl)
+        s3.synchronize()
+        s3.timer_start()
+        s3.step(args.steps, args.steps_per_launch)
+        fms = s3.timer_stop()
+        s3.close()
+        large['fused'] = {'timesteps_per_s': LB * args.steps / (fms * 1e-3), 'steps_per_launch': args.steps_per_launch,
+                          'frac': 16.0 * (N + 1) * nx * LB * args.steps / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
         # 2*8*(N+1)*nx bytes per lane-timestep; a launch advances B lanes by steps_per_launch steps
