@@ -48,6 +48,7 @@ struct pnp_handle {
   double *gw = nullptr, *gv = nullptr;
   std::vector<double> xgrid;
   int64_t stash_stride = 0;
+  int64_t work_stride = 0;
   int32_t* iters = nullptr;
   int nw_blocks = 0;
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
@@ -183,7 +184,9 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
     }
     const int nb = N + 1;
     if (!newton_exchange_in_lds(nb, cfg->nx)) {
-      const size_t slice = newton_exchange_doubles(nb, cfg->nx);
+      size_t slice = newton_exchange_doubles(nb, cfg->nx);
+      if (nb >= 6 && newton_team_doubles(nb, cfg->nx) > slice) slice = newton_team_doubles(nb, cfg->nx);
+      h->work_stride = (int64_t)slice;
       int64_t blocks = Bc < 1024 ? Bc : 1024;
       const int64_t cap = (int64_t)((size_t)4 << 30) / (int64_t)(slice * sizeof(double));
       if (blocks > cap) blocks = cap < 1 ? 1 : cap;
@@ -445,7 +448,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.RS = (nx + 15) / 16 * 16;
   a.B = h->B;
   a.work = h->work;
-  a.work_stride = (int64_t)newton_exchange_doubles(N + 1, nx);
+  a.work_stride = h->work_stride ? h->work_stride : (int64_t)newton_exchange_doubles(N + 1, nx);
   a.stash = h->stash;
   a.stash_stride = h->stash_stride;
   a.tol = tol > 0 ? tol : h->np.tol;

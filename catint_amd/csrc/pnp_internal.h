@@ -132,6 +132,7 @@ struct NewtonArgs {
 };
 int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);
+size_t newton_team_doubles(int nb, int nx);      // row buffer of the lane-team kernel (N >= 5)
 bool newton_exchange_in_lds(int nb, int nx);
 int newton_pair_threads(int nb, int nx);   // threads of the pair kernel, 0 if the shape does not fit it
 int newton_pair_stride(int nb, int nx);    // its compile-time row stride (256 or 512)

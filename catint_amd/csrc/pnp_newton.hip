@@ -1029,6 +1029,454 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Lane-team kernel for large blocks (N >= 5): a block row does not fit the registers of one thread (the row-per-thread kernel
+// spills and spends 90 % of its time in s_waitcnt), so NB = N+1 adjacent lanes share it -- lane r of a team holds ROW r of
+// [Lt | Ut | rt] (2 NB + 1 doubles), i.e. the equation of species r (r < N) or the Poisson equation (r = N).
+//   * assembly: every lane evaluates its own equation (two Scharfetter-Gummel fluxes for a species lane); the few
+//     quantities that couple the lanes of a point (occupied volume fraction at i-1, i, i+1, charge density) are team sums;
+//   * block algebra: products with neighbour blocks read the neighbour's rows as broadcast loads (the NB lanes of a team ask
+//     for the same addresses); Gauss-Jordan runs across the team, the pivot row travelling through a per-team LDS strip
+//     (partial pivoting over the lanes for the raw Jacobian block, none inside cyclic reduction);
+//   * the grid is reduced by in-place block cyclic reduction in a device-memory row buffer, layout [row][r][2 NB + 2].
+// ~110 registers per lane (bound: 4 waves per SIMD), no scratch.  64/NB teams per wave; the leftover lanes of a wave
+// form a dummy team that runs along (same control flow, no stores).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void team_sync() {   // LDS hand-off inside one wave (all lanes run the same code)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NB>
+struct TeamLayout {
+  static constexpr int NC = 2 * NB + 1;
+  static constexpr int NCP = NC + 1;               // row record padded to an even number of doubles
+  static constexpr int TPW = 64 / NB;              // teams per wave (+1 dummy team of the leftover lanes)
+  static constexpr int SV = NB;                    // strip: NB scalars (reductions / pivot search) ...
+  static constexpr int SL = ((NB + NB + NC) + 1) / 2 * 2;   // ... + pivot row (NB of M/D + NC of X)
+};
+
+// Gauss-Jordan across a team on rows Dr (NB) | Xr (NC):  X <- D^-1 X.  PIVOT: the lane with the largest |D[.][k]| among the
+// lanes not used yet provides pivot row k; on return `myk` is the unknown whose solution row the lane holds.
+template <int NB, bool PIVOT>
+__device__ __forceinline__ void team_solve(double (&Dr)[NB], double (&Xr)[2 * NB + 1], double* strip, int r, int& myk) {
+  constexpr int NC = 2 * NB + 1;
+  double* sv = strip;             // [NB] scalars
+  double* sp = strip + NB;        // pivot row
+  bool used = false;
+  myk = PIVOT ? -1 : r;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    int piv = k;
+    if constexpr (PIVOT) {
+      sv[r] = used ? -1.0 : fabs(Dr[k]);
+      team_sync();
+      double best = -2.0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const double v = sv[j];
+        if (v > best) {
+          best = v;
+          piv = j;
+        }
+      }
+    }
+    if (r == piv) {
+      const double inv = nrcp(Dr[k]);
+#pragma unroll
+      for (int j = k + 1; j < NB; ++j) {
+        Dr[j] *= inv;
+        sp[j] = Dr[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        Xr[j] *= inv;
+        sp[NB + j] = Xr[j];
+      }
+      used = true;
+      myk = k;
+    }
+    team_sync();
+    if (r != piv) {
+      const double f = Dr[k];
+#pragma unroll
+      for (int j = k + 1; j < NB; ++j) Dr[j] = __builtin_fma(-f, sp[j], Dr[j]);
+#pragma unroll
+      for (int j = 0; j < NC; ++j) Xr[j] = __builtin_fma(-f, sp[NB + j], Xr[j]);
+    }
+    if constexpr (!PIVOT) team_sync();      // (with pivoting the next search's sync separates the strip reuse)
+  }
+}
+
+template <int NB, int MODE>
+__global__ __launch_bounds__(256, 4) void newton_team_kernel(const NewtonArgs A) {
+  using TL = TeamLayout<NB>;
+  constexpr int N = NB - 1, NC = TL::NC, NCP = TL::NCP, TPW = TL::TPW;
+  constexpr bool MPB = MODE >= 1, REACT = MODE == 2;
+  extern __shared__ double newton_lds[];
+  __shared__ double red[2][16];
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+  const int tw = lane / NB;                       // team inside the wave; tw == TPW: dummy team
+  const int r = lane - tw * NB;                   // row of the block = equation this lane owns
+  const bool real_team = tw < TPW;
+  const int team = wave * TPW + (real_team ? tw : 0);
+  const int nteams = nwaves * TPW;
+  double* strip = newton_lds + (size_t)(wave * (TPW + 1) + tw) * TL::SL;
+  const int nx = A.nx, ldx = A.ldx;
+  double* rowbuf = A.work + (size_t)blockIdx.x * A.work_stride;
+  auto REC = [&](int row, int rr) { return rowbuf + ((size_t)row * NB + rr) * NCP; };
+  // per-lane species constants (lane N: Poisson row, constants unused)
+  double qb_r = 0.0, sig_r = 0.0, fl_r = 0.0, peq_r = 0.0, vol_r = 0.0, rs_r = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (k == r) {
+      qb_r = A.qb[k];
+      sig_r = A.sig[k];
+      fl_r = A.fl[k];
+      peq_r = A.peq[k];
+      vol_r = A.vol[k];
+      rs_r = A.rs[k];
+    }
+  const bool spec = r < N;
+  const int rs_ = spec ? r : 0;                   // clamped species index for loads
+  for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+    double* c = A.c + (size_t)b * N * ldx;
+    double* co = A.c_old + (size_t)b * N * ldx;
+    double* phi = A.phi + (size_t)b * ldx;
+    const double* cb = A.cbulk + (size_t)b * N;
+    const double* wk = A.wk_k + (size_t)b * PNP_MAX_WALL_REACTIONS;
+    const double flux_r = A.flux[(size_t)b * N + rs_];
+    const double cb_r = cb[rs_];
+    const double phiM = A.pb[b * 4 + 0], phiB = A.pb[b * 4 + 1];
+    int total_it = 0, st = PNP_STATUS_OK;
+    for (int step = 0; step < A.nsteps; ++step) {
+      for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
+      __syncthreads();
+      bool conv = false;
+      int it = 1;
+      for (; it <= A.maxit; ++it) {
+        // ---- assembly + normalisation, one block row per team -------------------------------------------------
+        for (int row0 = 0; row0 < nx; row0 += nteams) {
+          const int i = min(row0 + team, nx - 1);
+          const bool valid = real_team && row0 + team < nx;
+          const int im = i > 0 ? i - 1 : 0, ip = i < nx - 1 ? i + 1 : nx - 1;
+          const bool wall = (i == 0), bulk = (i == nx - 1);
+          const double pm = phi[im], p0 = phi[i], pp = phi[ip];
+          const double cm = c[rs_ * ldx + im], c0 = c[rs_ * ldx + i], cp = c[rs_ * ldx + ip];
+          // team sums: occupied volume fraction at the three points, scaled charge density at i
+          auto team_sum = [&](double v) {
+            strip[r] = v;
+            team_sync();
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc += strip[j];
+            team_sync();
+            return acc;
+          };
+          double fm = 0.0, f0 = 0.0, fp = 0.0;
+          if constexpr (MPB) {
+            fm = team_sum(spec ? vol_r * cm : 0.0);
+            f0 = team_sum(spec ? vol_r * c0 : 0.0);
+            fp = team_sum(spec ? vol_r * cp : 0.0);
+          }
+          const double rho = team_sum(spec ? peq_r * c0 : 0.0);
+          double wm_ = 0.0, w0_ = 0.0, wp_ = 0.0, invm = 1.0, inv0 = 1.0, invp = 1.0;
+          if constexpr (MPB) {
+            wm_ = -log1p(-fm);
+            w0_ = -log1p(-f0);
+            wp_ = -log1p(-fp);
+            invm = 1.0 / (1.0 - fm);
+            inv0 = 1.0 / (1.0 - f0);
+            invp = 1.0 / (1.0 - fp);
+          }
+          const double wem = A.gw[im], wep = A.gw[i < nx - 1 ? i : nx - 2], vi = A.gv[i];
+          double Dr[NB], Xr[NC];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) Dr[j] = 0.0;
+#pragma unroll
+          for (int j = 0; j < NC; ++j) Xr[j] = 0.0;
+          if (spec) {
+            const double wpp = bulk ? 0.0 : 1.0, wmm = (wall || bulk) ? 0.0 : 1.0, ws = bulk ? 0.0 : vi;
+            const Edge em = edge_flux(qb_r * (p0 - pm) + (w0_ - wm_), cm, c0, wem);
+            const Edge ep = edge_flux(qb_r * (pp - p0) + (wp_ - w0_), c0, cp, wep);
+            const double sg = ws * sig_r;
+            const double Jp = wpp * ep.J, Jup = wpp * ep.Ju, Jm = wmm * em.J, Jum = wmm * em.Ju;
+            double F = sg * (c0 - co[rs_ * ldx + i]) + Jp - Jm - (wall ? flux_r * fl_r : 0.0);
+            if (bulk) F = c0 - cb_r;
+            double rhs = -F;
+            const double diag = sg + wpp * ep.Bp + wmm * em.Bm + (bulk ? 1.0 : 0.0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const double own = (j == r) ? 1.0 : 0.0, pot = (j == N) ? 1.0 : 0.0;
+              Dr[j] = own * diag - pot * qb_r * (Jup + Jum);
+              Xr[NB + j] = -own * (wpp * ep.Bm) + pot * Jup * qb_r;
+              Xr[j] = -own * (wmm * em.Bp) + pot * Jum * qb_r;
+              if constexpr (MPB) {
+                if (j < N) {
+                  const double vj = A.vol[j];
+                  Dr[j] += -(Jup + Jum) * vj * inv0;
+                  Xr[NB + j] += Jup * vj * invp;
+                  Xr[j] += Jum * vj * invm;
+                }
+              }
+            }
+            if constexpr (REACT) {       // mass action in activities, see fill_row
+              const ReactionTable* rt = A.rt;
+              double call[N];
+#pragma unroll
+              for (int k = 0; k < N; ++k) call[k] = c[k * ldx + i];
+              auto pick = [&](int idx) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) v = (k == idx) ? call[k] : v;
+                return v;
+              };
+              const double wr = ws * rs_r;
+              const int nr = rt->n;
+              for (int q = 0; q < nr; ++q) {
+                const int nl = rt->n_lhs[q], nrh = rt->n_rhs[q];
+                // net stoichiometry of this lane's species in reaction q (products - educts)
+                int mult = 0;
+                for (int a = 0; a < nl; ++a) mult -= (rt->lhs[q][a] == r) ? 1 : 0;
+                for (int a = 0; a < nrh; ++a) mult += (rt->rhs[q][a] == r) ? 1 : 0;
+                for (int side = 0; side < 2; ++side) {
+                  const int n = side == 0 ? nl : nrh;
+                  const int32_t* idx = side == 0 ? rt->lhs[q] : rt->rhs[q];
+                  const double kk = side == 0 ? rt->kf[q] : rt->kr[q];
+                  if (kk == 0.0) continue;
+                  double pre = kk;
+                  for (int a = 0; a < n; ++a) pre *= inv0;
+                  double prod = pre;
+                  for (int a = 0; a < n; ++a) prod *= pick(idx[a]);
+                  const double w = (side == 0 ? 1.0 : -1.0) * mult * wr;      // forward minus backward
+                  rhs = __builtin_fma(w, prod, rhs);
+#pragma unroll
+                  for (int j = 0; j < N; ++j) {
+                    double dp = MPB ? prod * n * A.vol[j] * inv0 : 0.0;
+                    for (int a = 0; a < n; ++a) {
+                      if (idx[a] != j) continue;
+                      double rest = pre;
+                      for (int b2 = 0; b2 < n; ++b2)
+                        if (b2 != a) rest *= pick(idx[b2]);
+                      dp += rest;
+                    }
+                    Dr[j] = __builtin_fma(-w, dp, Dr[j]);
+                  }
+                }
+              }
+            }
+            if (wall && A.n_wk > 0) {   // implicit first-order surface kinetics, see fill_row
+              for (int q = 0; q < A.n_wk; ++q) {
+                const int sp = A.wk_species[q];
+                double nu = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) nu = (k == r) ? A.wk_nu[q][k] : nu;
+                const double a = nu * wk[q] * fl_r;
+                const double cs = sp >= 0 ? c[sp * ldx] : 1.0;
+                rhs += a * cs;
+#pragma unroll
+                for (int j = 0; j < N; ++j) Dr[j] -= (j == sp) ? a : 0.0;
+              }
+            }
+            Xr[2 * NB] = rhs;
+          } else {
+            if (bulk) {
+              Xr[2 * NB] = -(p0 - phiB);
+              Dr[N] = 1.0;
+            } else if (wall) {
+              if (A.wall_bc == 0) {
+                Xr[2 * NB] = -(p0 - phiM);
+                Dr[N] = 1.0;
+              } else {
+                Xr[2 * NB] = -(wep * (pp - p0) + A.stern * (phiM - A.phi_pzc - p0));
+                Dr[N] = -wep - A.stern;
+                Xr[NB + N] = wep;
+              }
+            } else {
+              Xr[2 * NB] = -(wep * (pp - p0) - wem * (p0 - pm) + vi * rho);
+#pragma unroll
+              for (int k = 0; k < N; ++k) Dr[k] = vi * A.peq[k];
+              Dr[N] = -(wep + wem);
+              Xr[N] = wem;
+              Xr[NB + N] = wep;
+            }
+          }
+          int myk;
+          team_solve<NB, true>(Dr, Xr, strip, r, myk);
+          if (valid) {
+            double* o = REC(i, myk);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) o[j] = Xr[j];
+          }
+          team_sync();
+        }
+        __syncthreads();
+        // ---- block cyclic reduction in place ---------------------------------------------------------------------
+        int s = 1;
+        for (; s < nx; s <<= 1) {
+          const int nact = (nx - (2 * s - 1) + 2 * s - 1) / (2 * s);      // rows 2s-1 + t*2s < nx
+          for (int t0 = 0; t0 < nact; t0 += nteams) {
+            const int t = t0 + team;
+            const bool valid = real_team && t < nact;
+            const int row = valid ? 2 * s - 1 + t * 2 * s : 2 * s - 1;
+            const bool hm = row - s >= 0, hp = row + s < nx;
+            const double* own = REC(row, r);
+            double Lt[NB], Ut[NB], Dr[NB], Xr[NC];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              Lt[j] = own[j];
+              Ut[j] = own[NB + j];
+              Dr[j] = (j == r) ? 1.0 : 0.0;
+              Xr[j] = 0.0;
+              Xr[NB + j] = 0.0;
+            }
+            Xr[2 * NB] = own[2 * NB];
+            if (hm) {
+#pragma unroll
+              for (int q = 0; q < NB; ++q) {
+                const double* nb_ = REC(row - s, q);
+                const double lq = Lt[q];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                  Dr[j] = __builtin_fma(-lq, nb_[NB + j], Dr[j]);       // - Lt Ut[-s]
+                  Xr[j] = __builtin_fma(-lq, nb_[j], Xr[j]);            // - Lt Lt[-s]
+                }
+                Xr[2 * NB] = __builtin_fma(-lq, nb_[2 * NB], Xr[2 * NB]);
+              }
+            }
+            if (hp) {
+#pragma unroll
+              for (int q = 0; q < NB; ++q) {
+                const double* nb_ = REC(row + s, q);
+                const double uq = Ut[q];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                  Dr[j] = __builtin_fma(-uq, nb_[j], Dr[j]);            // - Ut Lt[+s]
+                  Xr[NB + j] = __builtin_fma(-uq, nb_[NB + j], Xr[NB + j]);   // - Ut Ut[+s]
+                }
+                Xr[2 * NB] = __builtin_fma(-uq, nb_[2 * NB], Xr[2 * NB]);
+              }
+            }
+            int myk;
+            team_solve<NB, false>(Dr, Xr, strip, r, myk);
+            if (valid) {
+              double* o = REC(row, r);
+#pragma unroll
+              for (int j = 0; j < NC; ++j) o[j] = Xr[j];
+            }
+          }
+          __syncthreads();
+        }
+        for (s >>= 1; s >= 1; s >>= 1) {
+          const int nact = (nx - (s - 1) + 2 * s - 1) / (2 * s);          // rows s-1 + t*2s < nx
+          for (int t0 = 0; t0 < nact; t0 += nteams) {
+            const int t = t0 + team;
+            if (real_team && t < nact) {
+              const int row = s - 1 + t * 2 * s;
+              const double* own = REC(row, r);
+              double x = own[2 * NB];
+              if (row - s >= 0) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) x = __builtin_fma(-own[q], REC(row - s, q)[2 * NB], x);
+              }
+              if (row + s < nx) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) x = __builtin_fma(-own[NB + q], REC(row + s, q)[2 * NB], x);
+              }
+              REC(row, r)[2 * NB] = x;
+            }
+          }
+          __syncthreads();
+        }
+        // ---- damping, update, convergence: one thread per grid point (oracle/pnp_physical.py: newton_step) ---------
+        double mphi = 0.0, upd = 0.0;
+        for (int row = tid; row < nx; row += T) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const double du = REC(row, k)[2 * NB];
+            const double ck = c[k * ldx + row];
+            upd = fmax(upd, fabs(du) / (fabs(ck) + fabs(cb[k]) + 1e-300));
+            if (!(du == du)) upd = INFINITY;
+          }
+          const double a = fabs(REC(row, N)[2 * NB]);
+          mphi = fmax(mphi, a);
+          if (!(a == a)) mphi = INFINITY;
+        }
+        upd = fmax(upd, mphi * A.vt_inv);
+        mphi = wave_max(mphi);
+        upd = wave_max(upd);
+        if ((tid & 63) == 0) {
+          red[0][tid >> 6] = mphi;
+          red[1][tid >> 6] = upd;
+        }
+        __syncthreads();
+        mphi = 0.0;
+        upd = 0.0;
+        for (int w = 0; w < nwaves; ++w) {
+          mphi = fmax(mphi, red[0][w]);
+          upd = fmax(upd, red[1][w]);
+        }
+        double lam = 1.0;
+        if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+        for (int row = tid; row < nx; row += T) {
+          double cn[N], cc_[N];
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            cc_[k] = c[k * ldx + row];
+            const double t_ = __builtin_fma(lam, REC(row, k)[2 * NB], cc_[k]);
+            const double lo = 0.1 * cc_[k];
+            cn[k] = t_ < lo ? lo : t_;
+          }
+          if constexpr (MPB) {
+            double f_old = 0.0, f_new = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              f_old = __builtin_fma(A.vol[k], cc_[k], f_old);
+              f_new = __builtin_fma(A.vol[k], cn[k], f_new);
+            }
+            const double free_ = 1.0 - f_old;
+            const double target = fmax(0.1 * free_, 1e-12);
+            if ((1.0 - f_new) < target) {
+              const double theta = (free_ - target) / (f_new - f_old);
+#pragma unroll
+              for (int k = 0; k < N; ++k) cn[k] = __builtin_fma(theta, cn[k] - cc_[k], cc_[k]);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < N; ++k) c[k * ldx + row] = cn[k];
+          phi[row] = __builtin_fma(lam, REC(row, N)[2 * NB], phi[row]);
+        }
+        __syncthreads();
+        if (upd < A.tol && lam == 1.0) {
+          conv = true;
+          break;
+        }
+      }
+      total_it += conv ? it : A.maxit + 1;
+      if (!conv) st = PNP_STATUS_MAXIT;
+    }
+    double bad = 0.0;
+    for (int e = tid; e < nx; e += T) {
+      double sacc = phi[e];
+#pragma unroll
+      for (int k = 0; k < N; ++k) sacc += c[k * ldx + e];
+      if (!(fabs(sacc) < INFINITY)) bad = 1.0;
+    }
+    bad = wave_max(bad);
+    if ((tid & 63) == 0) red[0][tid >> 6] = bad;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 0; w < nwaves; ++w) bad = fmax(bad, red[0][w]);
+      A.status[b] = bad > 0.0 ? PNP_STATUS_NAN : st;
+      A.iters[b] = total_it;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1089,9 +1537,26 @@ static hipError_t launch_pair(const NewtonArgs& a, int blocks, int tp, hipStream
   return hipGetLastError();
 }
 
+// lane-team kernel (N >= 5): row buffer [nx][NB][2 NB + 2] doubles per workgroup, 256 threads, 64/NB teams per wave
+size_t newton_team_doubles(int nb, int nx) { return (size_t)nx * nb * (2 * nb + 2); }
+
+template <int NB>
+static hipError_t launch_team(const NewtonArgs& a, int blocks, hipStream_t stream) {
+  using TL = TeamLayout<NB>;
+  const int T = 256;
+  const size_t lds = (size_t)(T / 64) * (TL::TPW + 1) * TL::SL * sizeof(double);
+  if (a.rt) hipLaunchKernelGGL((newton_team_kernel<NB, 2>), dim3(blocks), dim3(T), lds, stream, a);
+  else if (a.mpb) hipLaunchKernelGGL((newton_team_kernel<NB, 1>), dim3(blocks), dim3(T), lds, stream, a);
+  else hipLaunchKernelGGL((newton_team_kernel<NB, 0>), dim3(blocks), dim3(T), lds, stream, a);
+  return hipGetLastError();
+}
+
 template <int NB, int TMAX>
 static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t stream) {
   const char* force = getenv("CATINT_NEWTON_KERNEL");     // "generic" forces the row-per-thread kernel (tests)
+  if constexpr (NB >= 6) {
+    if (!(force && force[0] == 'g')) return launch_team<NB>(a, blocks, stream);
+  }
   const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
   if constexpr (NB <= 5) {
     if (tp > 0) {
