@@ -185,7 +185,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
     const int nb = N + 1;
     if (!newton_exchange_in_lds(nb, cfg->nx)) {
       size_t slice = newton_exchange_doubles(nb, cfg->nx);
-      if (nb >= 6 && newton_team_doubles(nb, cfg->nx) > slice) slice = newton_team_doubles(nb, cfg->nx);
+      if (nb >= 3 && newton_team_doubles(nb, cfg->nx) > slice) slice = newton_team_doubles(nb, cfg->nx);
       h->work_stride = (int64_t)slice;
       int64_t blocks = Bc < 1024 ? Bc : 1024;
       const int64_t cap = (int64_t)((size_t)4 << 30) / (int64_t)(slice * sizeof(double));

@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void team_solve(double (&Dr)[NB], double (&Xr)[2 * NB
 }
 
 template <int NB, int MODE>
-__global__ __launch_bounds__(256, 4) void newton_team_kernel(const NewtonArgs A) {
+__global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A) {
   using TL = TeamLayout<NB>;
   constexpr int N = NB - 1, NC = TL::NC, NCP = TL::NCP, TPW = TL::TPW;
   constexpr bool MPB = MODE >= 1, REACT = MODE == 2;
@@ -1543,7 +1543,13 @@ size_t newton_team_doubles(int nb, int nx) { return (size_t)nx * nb * (2 * nb + 
 template <int NB>
 static hipError_t launch_team(const NewtonArgs& a, int blocks, hipStream_t stream) {
   using TL = TeamLayout<NB>;
-  const int T = 256;
+  // threads per operating point: a small batch cannot fill the chip with 256-thread workgroups (4 resident per CU), so it
+  // gets wider ones (shorter passes over the rows, same registers)
+  int T = a.B * 4 <= 1024 ? 1024 : (a.B * 2 <= 1024 ? 512 : 256);
+  if (const char* e = getenv("CATINT_NEWTON_TEAM_THREADS")) {
+    const int v = atoi(e);
+    if (v == 256 || v == 512 || v == 1024) T = v;
+  }
   const size_t lds = (size_t)(T / 64) * (TL::TPW + 1) * TL::SL * sizeof(double);
   if (a.rt) hipLaunchKernelGGL((newton_team_kernel<NB, 2>), dim3(blocks), dim3(T), lds, stream, a);
   else if (a.mpb) hipLaunchKernelGGL((newton_team_kernel<NB, 1>), dim3(blocks), dim3(T), lds, stream, a);
@@ -1554,10 +1560,10 @@ static hipError_t launch_team(const NewtonArgs& a, int blocks, hipStream_t strea
 template <int NB, int TMAX>
 static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t stream) {
   const char* force = getenv("CATINT_NEWTON_KERNEL");     // "generic" forces the row-per-thread kernel (tests)
-  if constexpr (NB >= 6) {
-    if (!(force && force[0] == 'g')) return launch_team<NB>(a, blocks, stream);
-  }
   const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
+  if constexpr (NB >= 3) {     // lane teams: every large block, and the N = 2..4 grids too long for the pair kernel
+    if (a.work && !(force && force[0] == 'g') && (NB >= 6 || tp == 0)) return launch_team<NB>(a, blocks, stream);
+  }
   if constexpr (NB <= 5) {
     if (tp > 0) {
       if (tp <= 64) return launch_pair<NB, 64>(a, blocks, tp, stream);
