@@ -258,6 +258,14 @@ def test_integrate_entry_point_writes_outputs_at_itout():
                 k += 1
 
 
+def test_config5_shape_size_modified_eight_species_4096_points():
+    """BASELINE configs[4]: 8-species size-modified PNP on 4096 grid points (lane-team kernel), two lanes against the oracle."""
+    a = [4.1e-10, 3.0e-10, 3.3e-10, 3.6e-10, 0.0, 3.5e-10, 3.2e-10, 0.0]
+    got, ref = run_both(8, 4096, B=2, seed=4096, points_per_debye=40.0, phi_lo=-0.9, phi_hi=-0.5, cref=50.0,
+                        newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=a, maxit=60))
+    assert_close(got, ref)
+
+
 def test_not_converged_is_reported():
     got, ref = run_both(2, 64, B=3, seed=3, newton_kw=dict(maxit=2))
     assert np.all(got[3] == _capi.STATUS_MAXIT)
