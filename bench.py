@@ -125,6 +125,26 @@ def physical_mode(args, device, with_cpu):
            'ms_per_step': ms / args.physical_steps, 'lanes_ok': ok, 'bound': 'fp64 VALU issue / LDS exchange (not HBM)'}
     if N == 3 and nx <= 512:
         out['fp64_valu_util'] = 256 * 3716.0 * out['newton_iterations_per_s'] / (256 * 4 * 16 * 2.4e9)
+    # BASELINE configs[4] shape in the same mode: 8 species (size-modified, Stern wall), 4096 points -- lane-team kernel
+    try:
+        LB = max(64, min(1024, B))
+        p8, c8, pb8, vz8, fl8 = make_batch(LB, 8, 4096, seed=4343, phi_max=0.2, dt_factor=0.1)
+        s8 = _capi.PnpSolver(8, 4096, p8.dx, p8.dt, p8.beta, p8.eps, p8.D, p8.charges, method='Newton', batch_capacity=LB, device=device)
+        s8.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=1e-8, mpb_radius=[4.1e-10, 3.6e-10, 3.3e-10, 3e-10, 3e-10, 3e-10, 4.5e-10, 3.5e-10])
+        s8.set_batch(c8, np.nan_to_num(pb8), vz8, fl8)
+        s8.step(1)
+        s8.synchronize()
+        s8.timer_start()
+        s8.step(3)
+        ms8 = s8.timer_stop()
+        it8 = s8.newton_iterations()
+        ok8 = int((s8.get_status() == 0).sum())
+        s8.close()
+        out['config4_shape'] = {'workload': 'batch=%d, 8 species size-modified, 4096 points, Stern wall' % LB,
+                                'timesteps_per_s': LB * 3 / (ms8 * 1e-3), 'newton_iterations_per_s': float(it8.sum()) / (ms8 * 1e-3),
+                                'lanes_ok': ok8}
+    except Exception as e:      # never let the extra line break the headline
+        out['config4_shape'] = {'error': str(e)}
     if with_cpu:
         from oracle import pnp_physical as PH
         nl, ns = 2, 2
