@@ -1572,22 +1572,29 @@ static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t 
       if constexpr (NB <= 4) return launch_pair<NB, 512>(a, blocks, tp, stream);
     }
   }
-  const int T = newton_threads(NB, a.nx);
-  const size_t lds = a.work ? 0 : newton_exchange_doubles(NB, a.nx) * sizeof(double);
-  if (a.rt) {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((newton_kernel<NB, TMAX, 2>), dim3(blocks), dim3(T), lds, stream, a);
-  } else if (a.mpb) {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((newton_kernel<NB, TMAX, 1>), dim3(blocks), dim3(T), lds, stream, a);
+  // row-per-thread kernel: small shapes the other two do not take, and (up to N = 6) the forced cross-check of the tests;
+  // for N >= 7 it is not built (it only spilled there, and its instances dominated the compile time)
+  if constexpr (NB >= 8) {
+    if (a.work) return launch_team<NB>(a, blocks, stream);
+    return hipErrorInvalidValue;
   } else {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((newton_kernel<NB, TMAX, 0>), dim3(blocks), dim3(T), lds, stream, a);
+    const int T = newton_threads(NB, a.nx);
+    const size_t lds = a.work ? 0 : newton_exchange_doubles(NB, a.nx) * sizeof(double);
+    if (a.rt) {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((newton_kernel<NB, TMAX, 2>), dim3(blocks), dim3(T), lds, stream, a);
+    } else if (a.mpb) {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((newton_kernel<NB, TMAX, 1>), dim3(blocks), dim3(T), lds, stream, a);
+    } else {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)newton_kernel<NB, TMAX, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((newton_kernel<NB, TMAX, 0>), dim3(blocks), dim3(T), lds, stream, a);
+    }
+    return hipGetLastError();
   }
-  return hipGetLastError();
 }
 
 hipError_t launch_newton(const NewtonArgs& a, int blocks, hipStream_t stream) {
