@@ -1056,6 +1056,10 @@ struct TeamLayout {
   static constexpr int TPW = 64 / NB;              // teams per wave (+1 dummy team of the leftover lanes)
   static constexpr int SV = NB;                    // strip: NB scalars (reductions / pivot search) ...
   static constexpr int SL = ((NB + NB + NC) + 1) / 2 * 2;   // ... + pivot row (NB of M/D + NC of X)
+  // Staging neighbour block rows in an LDS tile turns ~2 NB dependent memory round trips per row operation into 2, but the
+  // tile costs occupancy: measured +15 % at N = 8 and N = 3, -15 % at N = 6 -> only where it pays
+  static constexpr bool STAGE = NB >= 8 || NB <= 5;
+  static constexpr int SLT = SL + (STAGE ? ((NB * NC) + 1) / 2 * 2 : 0);  // strip (+ tile for one neighbour block row)
 };
 
 // Gauss-Jordan across a team on rows Dr (NB) | Xr (NC):  X <- D^-1 X.  PIVOT: the lane with the largest |D[.][k]| among the
@@ -1124,7 +1128,8 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A
   const bool real_team = tw < TPW;
   const int team = wave * TPW + (real_team ? tw : 0);
   const int nteams = nwaves * TPW;
-  double* strip = newton_lds + (size_t)(wave * (TPW + 1) + tw) * TL::SL;
+  double* strip = newton_lds + (size_t)(wave * (TPW + 1) + tw) * TL::SLT;
+  double* tile = strip + TL::SL;                  // NB x NC doubles: one neighbour block row
   const int nx = A.nx, ldx = A.ldx;
   double* rowbuf = A.work + (size_t)blockIdx.x * A.work_stride;
   auto REC = [&](int row, int rr) { return rowbuf + ((size_t)row * NB + rr) * NCP; };
@@ -1334,30 +1339,66 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A
               Xr[NB + j] = 0.0;
             }
             Xr[2 * NB] = own[2 * NB];
-            if (hm) {
+            if constexpr (!TL::STAGE) {
+              if (hm) {
 #pragma unroll
-              for (int q = 0; q < NB; ++q) {
-                const double* nb_ = REC(row - s, q);
-                const double lq = Lt[q];
+                for (int q = 0; q < NB; ++q) {
+                  const double* nb_ = REC(row - s, q);
+                  const double lq = Lt[q];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                  Dr[j] = __builtin_fma(-lq, nb_[NB + j], Dr[j]);       // - Lt Ut[-s]
-                  Xr[j] = __builtin_fma(-lq, nb_[j], Xr[j]);            // - Lt Lt[-s]
+                  for (int j = 0; j < NB; ++j) {
+                    Dr[j] = __builtin_fma(-lq, nb_[NB + j], Dr[j]);       // - Lt Ut[-s]
+                    Xr[j] = __builtin_fma(-lq, nb_[j], Xr[j]);            // - Lt Lt[-s]
+                  }
+                  Xr[2 * NB] = __builtin_fma(-lq, nb_[2 * NB], Xr[2 * NB]);
                 }
-                Xr[2 * NB] = __builtin_fma(-lq, nb_[2 * NB], Xr[2 * NB]);
               }
-            }
-            if (hp) {
+              if (hp) {
 #pragma unroll
-              for (int q = 0; q < NB; ++q) {
-                const double* nb_ = REC(row + s, q);
-                const double uq = Ut[q];
+                for (int q = 0; q < NB; ++q) {
+                  const double* nb_ = REC(row + s, q);
+                  const double uq = Ut[q];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                  Dr[j] = __builtin_fma(-uq, nb_[j], Dr[j]);            // - Ut Lt[+s]
-                  Xr[NB + j] = __builtin_fma(-uq, nb_[NB + j], Xr[NB + j]);   // - Ut Ut[+s]
+                  for (int j = 0; j < NB; ++j) {
+                    Dr[j] = __builtin_fma(-uq, nb_[j], Dr[j]);            // - Ut Lt[+s]
+                    Xr[NB + j] = __builtin_fma(-uq, nb_[NB + j], Xr[NB + j]);   // - Ut Ut[+s]
+                  }
+                  Xr[2 * NB] = __builtin_fma(-uq, nb_[2 * NB], Xr[2 * NB]);
                 }
-                Xr[2 * NB] = __builtin_fma(-uq, nb_[2 * NB], Xr[2 * NB]);
+              }
+            } else {
+              // neighbour block rows travel through the team's LDS tile: every lane fetches ITS row of the neighbour in one batch
+              // of wide loads (one memory round trip per side instead of one per row), then the products read the tile
+              // (broadcast within the team)
+  #pragma unroll
+              for (int side = 0; side < 2; ++side) {
+                const bool have = side == 0 ? hm : hp;
+                const double* src = REC(have ? (side == 0 ? row - s : row + s) : row, r);
+                double tmp[NC];
+  #pragma unroll
+                for (int j = 0; j < NC; ++j) tmp[j] = src[j];
+  #pragma unroll
+                for (int j = 0; j < NC; ++j) tile[r * NC + j] = tmp[j];
+                team_sync();
+                if (have) {
+  #pragma unroll
+                  for (int q = 0; q < NB; ++q) {
+                    const double* nb_ = tile + q * NC;
+                    const double f = side == 0 ? Lt[q] : Ut[q];
+  #pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                      if (side == 0) {
+                        Dr[j] = __builtin_fma(-f, nb_[NB + j], Dr[j]);             // - Lt Ut[-s]
+                        Xr[j] = __builtin_fma(-f, nb_[j], Xr[j]);                  // - Lt Lt[-s]
+                      } else {
+                        Dr[j] = __builtin_fma(-f, nb_[j], Dr[j]);                  // - Ut Lt[+s]
+                        Xr[NB + j] = __builtin_fma(-f, nb_[NB + j], Xr[NB + j]);   // - Ut Ut[+s]
+                      }
+                    }
+                    Xr[2 * NB] = __builtin_fma(-f, nb_[2 * NB], Xr[2 * NB]);
+                  }
+                }
+                team_sync();
               }
             }
             int myk;
@@ -1550,7 +1591,16 @@ static hipError_t launch_team(const NewtonArgs& a, int blocks, hipStream_t strea
     const int v = atoi(e);
     if (v == 256 || v == 512 || v == 1024) T = v;
   }
-  const size_t lds = (size_t)(T / 64) * (TL::TPW + 1) * TL::SL * sizeof(double);
+  size_t lds = (size_t)(T / 64) * (TL::TPW + 1) * TL::SLT * sizeof(double);
+  while (lds > kLdsBudget && T > 64) {
+    T /= 2;
+    lds /= 2;
+  }
+  if (lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)newton_team_kernel<NB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)newton_team_kernel<NB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)newton_team_kernel<NB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (a.rt) hipLaunchKernelGGL((newton_team_kernel<NB, 2>), dim3(blocks), dim3(T), lds, stream, a);
   else if (a.mpb) hipLaunchKernelGGL((newton_team_kernel<NB, 1>), dim3(blocks), dim3(T), lds, stream, a);
   else hipLaunchKernelGGL((newton_team_kernel<NB, 0>), dim3(blocks), dim3(T), lds, stream, a);
