@@ -1,0 +1,129 @@
+"""Host logic of the physical mode (no GPU): continuation path, surface-kinetics plumbing, graded mesh, units."""
+import collections
+
+import numpy as np
+import pytest
+
+from catint_amd.calculator import Calculator, CalculatorError
+from catint_amd.host import graded_mesh
+from catint_amd.transport import Transport
+
+
+class FakeSolver(object):
+    """Records what Calculator.solve_physical asks of the C-ABI wrapper; 'converges' unless told otherwise."""
+
+    def __init__(self, fail_direct=False):
+        self.calls = []
+        self.fail_direct = fail_direct
+        self.B = 0
+
+    def set_batch(self, c0, pb, vz, flux):
+        self.B = len(pb)
+        self.calls.append(('set_batch', pb[:, 0].copy(), np.array(flux, float).copy()))
+
+    def set_pb(self, pb, vz):
+        self.calls.append(('set_pb', pb[:, 0].copy()))
+
+    def set_flux(self, flux):
+        self.calls.append(('set_flux', np.array(flux, float).copy()))
+
+    def set_wall_kinetics(self, species, nu, k):
+        self.calls.append(('kinetics', list(species), np.array(nu, float).copy(), np.array(k, float).copy()))
+
+    def solve_stationary(self):
+        n = sum(1 for c in self.calls if c[0] == 'solve')
+        self.calls.append(('solve',))
+        if self.fail_direct and n == 0:
+            return np.ones(self.B, np.int32)
+        return np.zeros(self.B, np.int32)
+
+    def step(self, n):
+        self.calls.append(('step', n))
+
+    def get_status(self):
+        return np.zeros(self.B, np.int32)
+
+
+def make_tp(phis, **system):
+    species = collections.OrderedDict([('K+', {'bulk_concentration': 100.0, 'MPB_radius': 4.1e-10}),
+                                       ('HCO3-', {'bulk_concentration': 100.0}), ('CO2', {'bulk_concentration': 34.0})])
+    sysd = {'phiM': phis[0], 'boundary thickness': 4e-8, 'Stern capacitance': 20.0, 'phiPZC': 0.16}
+    sysd.update(system)
+    return Transport(species=species, system=sysd, nx=64, descriptors={'phiM': list(phis)})
+
+
+def test_small_potentials_are_solved_directly():
+    phis = np.array([0.0, 0.3, 0.5])
+    tp = make_tp(phis)
+    calc = Calculator(transport=tp, calc='comsol')
+    s = FakeSolver()
+    st = calc.solve_physical(s, np.zeros((3, 3 * tp.nx)), phis, np.zeros((3, 3)))
+    assert np.all(st == 0)
+    assert [c[0] for c in s.calls] == ['set_batch', 'solve'] and np.allclose(s.calls[0][1], phis)
+
+
+def test_failed_direct_solve_restarts_on_the_continuation_path():
+    phis = np.array([0.0, 0.3, 0.5])
+    tp = make_tp(phis)
+    calc = Calculator(transport=tp, calc='comsol')
+    s = FakeSolver(fail_direct=True)
+    flux = np.array([[0.0, 0.0, -1e-4]] * 3)
+    calc.solve_physical(s, np.zeros((3, 3 * tp.nx)), phis, flux)
+    stages = calc.continuation_stages
+    assert stages == 8                                  # nramp: span 0.34 V / 0.1 V = 4 stages < 8
+    batches = [c for c in s.calls if c[0] == 'set_batch']
+    assert len(batches) == 2                            # direct attempt, then the restart from the bulk state
+    assert np.allclose(batches[1][1], 0.16 + (phis - 0.16) / stages) and np.allclose(batches[1][2], flux / stages)
+    pbs = [c[1] for c in s.calls if c[0] == 'set_pb']
+    assert len(pbs) == stages - 1 and np.allclose(pbs[-1], phis)          # ends exactly at phiM with the full flux
+    assert np.allclose([c for c in s.calls if c[0] == 'set_flux'][-1][1], flux)
+
+
+def test_far_potentials_and_kinetics_walk_from_phi_pzc_in_100mV_stages():
+    phis = np.linspace(-0.5, -2.0, 4)
+    tp = make_tp(phis)
+    calc = Calculator(transport=tp, calc='comsol')
+    rate = lambda phiM: 1e-3 * np.exp(-10.0 * phiM)
+    calc.set_surface_kinetics([{'species': 'CO2', 'rate': rate, 'stoichiometry': {'CO2': -1.0, 'HCO3-': 0.5}}])
+    s = FakeSolver()
+    calc.solve_physical(s, np.zeros((4, 3 * tp.nx)), phis, np.zeros((4, 3)))
+    assert calc.continuation_stages == int(np.ceil(2.16 / 0.1))
+    assert [c[0] for c in s.calls].count('solve') == calc.continuation_stages
+    kin = [c for c in s.calls if c[0] == 'kinetics']
+    assert len(kin) == calc.continuation_stages and kin[0][1] == [2]
+    assert np.allclose(kin[0][2], [[0.0, 0.5, -1.0]])
+    w = 1.0 / calc.continuation_stages
+    assert np.allclose(kin[0][3][:, 0], rate(0.16 + (phis - 0.16) * w))           # rate constants at the STAGE potential
+    assert np.allclose(kin[-1][3][:, 0], rate(phis))
+    cs = np.array([[100.0, 100.0, 2.0]] * 4)
+    f = calc.surface_kinetic_fluxes(cs, phis)
+    assert np.allclose(f[:, 2], -rate(phis) * 2.0) and np.allclose(f[:, 1], 0.5 * rate(phis) * 2.0) and np.all(f[:, 0] == 0)
+
+
+def test_warm_and_time_dependent_paths():
+    phis = np.array([-1.0, -1.2])
+    tp = make_tp(phis)
+    calc = Calculator(transport=tp, calc='comsol')
+    s = FakeSolver(); s.B = 2
+    calc.solve_physical(s, None, phis, np.ones((2, 3)), warm=True)
+    assert [c[0] for c in s.calls] == ['set_flux', 'solve']
+    tp2 = make_tp(phis)
+    calc2 = Calculator(transport=tp2, calc='comsol', mode='time-dependent', dt=1e-6, tmax=1e-5)
+    s2 = FakeSolver()
+    calc2.solve_physical(s2, np.zeros((2, 3 * tp2.nx)), phis, np.zeros((2, 3)))
+    assert [c[0] for c in s2.calls] == ['set_batch', 'step'] and s2.calls[1][1] == tp2.nt - 1
+
+
+def test_graded_mesh_and_guards():
+    x = graded_mesh(8e-5, 5e-11, 384)
+    h = np.diff(x)
+    assert len(x) == 384 and x[0] == 0.0 and x[-1] == 8e-5 and np.isclose(h[0], 5e-11)
+    assert np.all(h > 0) and np.allclose(h[1:-1] / h[:-2], h[1] / h[0], rtol=1e-6)      # constant growth ratio
+    assert np.allclose(graded_mesh(1.0, 0.5, 3), [0.0, 0.5, 1.0])                        # degenerate: uniform
+    tp = make_tp([0.0])
+    tp.set_graded_mesh(tp.debye_length / 10)
+    assert not tp.mesh_uniform and np.isclose(tp.dx, tp.debye_length / 10) and len(tp.xmesh) == tp.nx
+    with pytest.raises(CalculatorError):
+        Calculator(transport=tp, calc='Crank-Nicolson', dt=1e-10, tmax=1e-9)           # FD integrators need a uniform mesh
+    with pytest.raises(CalculatorError):
+        Calculator(transport=make_tp([0.0]), calc='FTCS', dt=1e-10, tmax=1e-9).set_surface_kinetics([])
