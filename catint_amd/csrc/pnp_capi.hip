@@ -445,6 +445,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.maxit = maxit > 0 ? maxit : h->np.maxit;
   a.wall_bc = h->np.wall_bc;
   a.mpb = h->mpb ? 1 : 0;
+  a.estimate = h->np.error_estimate ? 1 : 0;
   a.RS = (nx + 15) / 16 * 16;
   a.B = h->B;
   a.work = h->work;

@@ -99,6 +99,7 @@ hipError_t launch_surface(const DevArgs& a, double* csurf, hipStream_t stream);
 struct NewtonArgs {
   int32_t N, nx, ldx, nsteps;
   int32_t maxit, wall_bc, mpb, RS;       // RS: row stride of the element-major PCR buffers
+  int32_t estimate, pad_;                // accept on the quadratic error estimate (pnp_newton_params.error_estimate)
   int64_t B;
   int64_t work_stride;                   // doubles per workgroup in `work`
   double tol, dphi_max;

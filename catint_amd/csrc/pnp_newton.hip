@@ -574,6 +574,7 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
       for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
+      double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
         for (int row = tid; row < nx; row += T) {
@@ -662,9 +663,17 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
           phi[row] = __builtin_fma(lam, du[N], phi[row]);
         }
         __syncthreads();
-        if (upd < A.tol && lam == 1.0) {
-          conv = true;
-          break;
+        if (lam == 1.0) {
+          // strict: the update itself is below tol.  With A.estimate the state is accepted as soon as the quadratic error
+          // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
+          // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
+          if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol)) {
+            conv = true;
+            break;
+          }
+          upd_prev = upd;
+        } else {
+          upd_prev = INFINITY;
         }
       }
       total_it += conv ? it : A.maxit + 1;
@@ -762,6 +771,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
       for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
+      double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
         // ---- rows a and b (the edge between them is evaluated once); a normalised
@@ -1002,9 +1012,17 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs A) {
           }
         }
         __syncthreads();
-        if (upd < A.tol && lam == 1.0) {
-          conv = true;
-          break;
+        if (lam == 1.0) {
+          // strict: the update itself is below tol.  With A.estimate the state is accepted as soon as the quadratic error
+          // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
+          // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
+          if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol)) {
+            conv = true;
+            break;
+          }
+          upd_prev = upd;
+        } else {
+          upd_prev = INFINITY;
         }
       }
       total_it += conv ? it : A.maxit + 1;
@@ -1161,6 +1179,7 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A
       for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
+      double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
         // ---- assembly + normalisation, one block row per team -------------------------------------------------
@@ -1491,9 +1510,17 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A
           phi[row] = __builtin_fma(lam, REC(row, N)[2 * NB], phi[row]);
         }
         __syncthreads();
-        if (upd < A.tol && lam == 1.0) {
-          conv = true;
-          break;
+        if (lam == 1.0) {
+          // strict: the update itself is below tol.  With A.estimate the state is accepted as soon as the quadratic error
+          // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
+          // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
+          if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol)) {
+            conv = true;
+            break;
+          }
+          upd_prev = upd;
+        } else {
+          upd_prev = INFINITY;
         }
       }
       total_it += conv ? it : A.maxit + 1;

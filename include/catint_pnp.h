@@ -141,7 +141,9 @@ typedef struct pnp_newton_params {
   int32_t wall_bc;           /* 0: phi(0) = phiM (Dirichlet);  1: Stern layer, eps dphi/dx = -C_S (phiM - phiPZC - phi(0))
                               *    (comsol_model.py:613, :982; tp.system['Stern capacitance'], ['phiPZC']) */
   int32_t maxit;             /* Newton iterations per solve (COMSOL maxiter 50, comsol_model.py:465-516) */
-  int32_t reserved;
+  int32_t error_estimate;    /* 0: converged when the scaled update < tol (default).  1: also when two consecutive undamped
+                              *    iterations contract (upd_k < 0.1 upd_{k-1}) and the quadratic estimate upd_k^2/upd_{k-1} of the
+                              *    error of the state just computed is < tol -- saves the iteration that only confirms convergence */
   double stern_capacitance;  /* F/m^2 */
   double phi_pzc;            /* V */
   double tol;                /* scaled update max(|dc|/(c + c_bulk), |dphi| beta max|q|) < tol on an undamped step */

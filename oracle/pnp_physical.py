@@ -276,7 +276,7 @@ def solve_block_pcr(L, M, U, rhs):
 
 
 def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver=solve_block_tridiagonal,
-                verbose=False):
+                verbose=False, estimate=False):
     """Solve one backward-Euler step (or, with dt=inf, the stationary problem) by damped Newton.
     Damping (identical on the device): the whole update is scaled so that |d phi| <= dphi_max, a concentration
     never drops below 10 % of its previous iterate, and neither does the free volume fraction 1-phi0 (MPB).
@@ -286,6 +286,7 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
     N = p.N
     vt = 1.0 / (p.beta * max(np.abs(p.q).max(), 1.0))            # thermal voltage of the highest valence
     hist = []
+    upd_prev = np.inf
     for it in range(1, maxit + 1):
         F, L, M, U = residual_and_jacobian(p, c, phi, c_old, dt)
         du = solver(L, M, U, -F)
@@ -312,8 +313,14 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
         hist.append(upd)
         if verbose:
             print(it, lam, upd)
-        if upd < tol and lam == 1.0:
-            return c, phi, it, hist
+        if lam == 1.0:
+            # estimate=True: also accept when two consecutive undamped iterations contract and the quadratic estimate
+            # upd^2/upd_prev of the error of the state just computed is below tol
+            if upd < tol or (estimate and np.isfinite(upd_prev) and upd < 0.1 * upd_prev and upd * (upd / upd_prev) < tol):
+                return c, phi, it, hist
+            upd_prev = upd
+        else:
+            upd_prev = np.inf
     return c, phi, maxit + 1, hist
 
 

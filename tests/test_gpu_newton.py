@@ -70,7 +70,8 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
     c, phi, _, _ = s.get_state()
     its = s.newton_iterations()
     s.close()
-    okw = dict(tol=newton_kw.get('tol', 1e-10), maxit=newton_kw.get('maxit', 50), dphi_max=newton_kw.get('dphi_max', 0.05))
+    okw = dict(tol=newton_kw.get('tol', 1e-10), maxit=newton_kw.get('maxit', 50), dphi_max=newton_kw.get('dphi_max', 0.05),
+               estimate=bool(newton_kw.get('error_estimate', False)))
     if okw['dphi_max'] <= 0:
         okw['dphi_max'] = None
     ref_c = np.zeros_like(c); ref_phi = np.zeros_like(phi); ref_it = np.zeros(B, int)
@@ -264,6 +265,19 @@ def test_config5_shape_size_modified_eight_species_4096_points():
     got, ref = run_both(8, 4096, B=2, seed=4096, points_per_debye=40.0, phi_lo=-0.9, phi_hi=-0.5, cref=50.0,
                         newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=a, maxit=60))
     assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx", [(3, 200), (6, 90), (3, 1100)])
+def test_error_estimate_termination(N, nx):
+    """pnp_newton_params.error_estimate: same acceptance rule on both sides -> same iteration counts, fewer than strict."""
+    D, q, cb, dx, phiM = make_lanes(N, nx, 4, 77)
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    strict, _ = run_both(N, nx, B=4, seed=77, dt=dt, nsteps=8, stationary=False, newton_kw=dict(tol=1e-8))
+    got, ref = run_both(N, nx, B=4, seed=77, dt=dt, nsteps=8, stationary=False, newton_kw=dict(tol=1e-8, error_estimate=True))
+    assert np.array_equal(got[2], ref[2]) and np.all(got[3] == 0)
+    assert got[2].sum() <= strict[2].sum()
+    assert np.abs(got[0] - ref[0]).max() <= 1e-7 * np.abs(ref[0]).max()
+    assert np.abs(got[0] - strict[0]).max() <= 1e-6 * np.abs(strict[0]).max()
 
 
 def test_not_converged_is_reported():
