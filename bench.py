@@ -207,6 +207,10 @@ def main():
             wall, ev_ms = float(t[0]), float(t[1])
         return wall, ev_ms
 
+    # clock spin-up (untimed, not part of W): a cold GPU needs a few milliseconds of load before it holds its clocks, and a
+    # short --warmup would leave that ramp inside the timed region
+    solver.step(512, args.steps_per_launch)
+    solver.set_batch(c0, pb, vz, fl)
     # warmup, then restart from the initial state so the timed steps see a finite state
     solver.step(args.warmup, args.steps_per_launch)
     solver.set_batch(c0, pb, vz, fl)
@@ -297,8 +301,10 @@ def main():
         # (profiles/, MI355X_MICROARCH.md HBM section: FETCH_SIZE doubled on gfx950); null when absent
         try:
             tj = json.load(open(args.traffic_json))
+            # only for the launch shape the counters were collected on (same lanes, same fused launch length)
             if (tj.get('batch'), tj.get('nspecies'), tj.get('nx'), tj.get('steps_per_launch')) == \
-                    (B, N, nx, args.steps_per_launch) and tj.get('method') == args.method:
+                    (B, N, nx, args.steps_per_launch) and tj.get('method') == args.method and \
+                    args.steps == n_launch * args.steps_per_launch and world == 1:
                 out['roofline']['traffic'] = tj['hbm_bytes_per_launch']
                 out['roofline']['traffic_source'] = tj.get('source')
         except Exception:
