@@ -182,7 +182,7 @@ def main():
     from catint_amd.synthetic import make_batch
     from catint_amd.host import solver_from_problem
     B, N, nx = args.batch, args.nspecies, args.nx
-    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=1000 + rank, phi_max=0.025, dt_factor=1e-4)
+    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=1000 + rank, phi_max=0.025, dt_factor=1e-5)
     solver = solver_from_problem(prob, args.method, batch_capacity=B, device=device)
     solver.set_batch(c0, pb, vz, fl)
 
@@ -248,7 +248,7 @@ def main():
     large = None
     if world == 1 and args.large_batch > 0:
         LB = args.large_batch
-        lp, lc0, lpb, lvz, lfl = make_batch(LB, N, nx, seed=77, phi_max=0.025, dt_factor=1e-4)
+        lp, lc0, lpb, lvz, lfl = make_batch(LB, N, nx, seed=77, phi_max=0.025, dt_factor=1e-5)
         s2 = solver_from_problem(lp, args.method, batch_capacity=LB, device=device)
         s2.set_batch(lc0, lpb, lvz, lfl)
         s2.step(5, 1)
