@@ -259,6 +259,37 @@ def test_integrate_entry_point_writes_outputs_at_itout():
                 k += 1
 
 
+def test_config2_batch_physical_mode_full_size_properties():
+    """BASELINE configs[1] sizes (batch 1024 x 3 species x 512 points) in the physical mode: every lane converges, sampled
+    lanes equal the oracle, and a lane's result does not depend on where in the batch (or in which batch) it is solved."""
+    from catint_amd.synthetic import make_batch
+    B, N, nx = 1024, 3, 512
+    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=5, phi_max=0.2, dt_factor=0.1)
+    pb = np.nan_to_num(pb)
+
+    def solve(idx, steps):
+        with _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=len(idx)) as s:
+            s.set_newton(tol=1e-9)
+            s.set_batch(c0[idx], pb[idx], vz[idx], fl[idx])
+            s.step(steps)
+            c, phi, _, _ = s.get_state()
+            return c, phi, s.newton_iterations(), s.get_status()
+    c, phi, its, st = solve(np.arange(B), 4)
+    assert np.all(st == 0) and np.all(np.isfinite(c)) and c.min() > 0 and its.min() >= 8
+    perm = np.random.default_rng(0).permutation(B)
+    c2, phi2, its2, _ = solve(perm, 4)
+    assert np.array_equal(c2, c[perm]) and np.array_equal(phi2, phi[perm]) and np.array_equal(its2, its[perm])
+    sub = np.array([3, 500, 1023])
+    c3, phi3, its3, _ = solve(sub, 4)
+    assert np.array_equal(c3, c[sub]) and np.array_equal(its3, its[sub])
+    for b in sub:
+        p = PH.PhysicalProblem(D=prob.D, charges=prob.charges, beta=prob.beta, eps=prob.eps, dx=prob.dx, nx=nx,
+                               c_bulk=c0[b].reshape(N, nx)[:, -1], phiM=pb[b, 0])
+        rc, rphi, rit = PH.integrate(p, c0[b].reshape(N, nx), np.zeros(nx), prob.dt, 4, tol=1e-9)
+        assert sum(rit) == its[b]
+        assert np.abs(c[b] - rc).max() <= 2e-9 * np.abs(rc).max() and np.abs(phi[b] - rphi).max() <= 2e-9 * 0.2
+
+
 def test_config5_shape_size_modified_eight_species_4096_points():
     """BASELINE configs[4]: 8-species size-modified PNP on 4096 grid points (lane-team kernel), two lanes against the oracle."""
     a = [4.1e-10, 3.0e-10, 3.3e-10, 3.6e-10, 0.0, 3.5e-10, 3.2e-10, 0.0]
