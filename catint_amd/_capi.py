@@ -33,7 +33,7 @@ SYMBOLS = [
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
-    'pnp_set_potential', 'pnp_set_wall_kinetics', 'pnp_set_grid',
+    'pnp_set_potential', 'pnp_set_wall_kinetics', 'pnp_set_grid', 'pnp_solve_surface',
 ]
 
 
@@ -109,6 +109,8 @@ def load_library():
     lib.pnp_set_wall_kinetics.restype = C.c_int
     lib.pnp_set_grid.argtypes = [vp, dp]
     lib.pnp_set_grid.restype = C.c_int
+    lib.pnp_solve_surface.argtypes = [vp, dp, C.c_int32, dp, dp, dp, ip]
+    lib.pnp_solve_surface.restype = C.c_int
     for name in ('pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations', 'pnp_set_potential'):
         getattr(lib, name).restype = C.c_int
     for name in ('pnp_set_species', 'pnp_set_reactions', 'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step',
@@ -245,6 +247,14 @@ class PnpSolver(object):
         st = np.zeros(self.B, np.int32)
         self._check(self._lib.pnp_solve_stationary(self._h, float(tol), int(maxit), _iptr(st)))
         return st
+
+    def solve_surface(self, flux=None, nsteps=0):
+        """New wall fluxes in, surface state out, one synchronisation: (csurf [B][N], vsurf [B], esurf [B], status [B]);
+        nsteps = 0 solves the stationary problem, otherwise nsteps backward-Euler steps."""
+        cs = np.zeros((self.B, self.N)); vs = np.zeros(self.B); es = np.zeros(self.B); st = np.zeros(self.B, np.int32)
+        f = None if flux is None else _f64(flux, (self.B, self.N))
+        self._check(self._lib.pnp_solve_surface(self._h, _dptr(f), int(nsteps), _dptr(cs), _dptr(vs), _dptr(es), _iptr(st)))
+        return cs, vs, es, st
 
     def newton_iterations(self):
         it = np.zeros(self.B, np.int32)

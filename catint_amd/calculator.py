@@ -457,8 +457,11 @@ class Calculator(object):
                 elif self.physical:
                     # warm start from the previous SCF iterate (restart=True of comsol.run, calculator.py:523)
                     warm = istep > 1 and self.mode == 'stationary' and not restart
-                    status = self.solve_physical(solver, c0, phiM, flux, nramp=1 if istep > 1 else 8, warm=warm)
-                    cs, vs, es = solver.get_surface()
+                    if warm:      # fluxes in, surface state out, one device synchronisation (pnp_solve_surface)
+                        cs, vs, es, status = solver.solve_surface(flux)
+                    else:
+                        status = self.solve_physical(solver, c0, phiM, flux, nramp=1 if istep > 1 else 8, warm=False)
+                        cs, vs, es = solver.get_surface()
                     # Wall fluxes that would drive a concentration negative have no solution inside the positive cone the
                     # damped Newton stays in: COMSOL hands the SCF loop a negative surface concentration there
                     # (calculator.py:328-344 falls back to the previous iterate); a lane that did not converge is reported

@@ -569,6 +569,38 @@ int pnp_solve_stationary(pnp_handle* h, double tol, int32_t maxit, int32_t* stat
   return PNP_OK;
 }
 
+int pnp_solve_surface(pnp_handle* h, const double* flux, int32_t nsteps, double* csurf, double* vsurf, double* esurf,
+                      int32_t* status) {
+  if (!h) return PNP_EINVAL;
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_solve_surface: the handle was not created with PNP_METHOD_NEWTON");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_solve_surface: call pnp_set_batch first");
+  if (nsteps < 0) return fail(h, PNP_EINVAL, "pnp_solve_surface: nsteps < 0");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int64_t B = h->B;
+  const int N = h->a.N, ldx = h->a.ldx;
+  // everything below is queued on the handle's stream; one synchronisation at the end
+  if (flux) HIP_TRY(h, hipMemcpyAsync(h->flux, flux, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const int rc = run_newton(h, nsteps == 0 ? 1 : nsteps, nsteps == 0, 0.0, 0);
+  if (rc != PNP_OK) return rc;
+  std::vector<double> p01;
+  if (csurf) {
+    HIP_TRY(h, launch_surface(h->a, h->csurf, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(csurf, h->csurf, (size_t)B * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  if (vsurf || esurf) {
+    p01.resize((size_t)B * 2);
+    HIP_TRY(h, hipMemcpy2DAsync(p01.data(), 2 * sizeof(double), h->v, (size_t)ldx * sizeof(double), 2 * sizeof(double), (size_t)B,
+                                hipMemcpyDeviceToHost, h->stream));
+  }
+  if (status) HIP_TRY(h, hipMemcpyAsync(status, h->status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int64_t b = 0; b < B; ++b) {
+    if (vsurf) vsurf[b] = p01[2 * b];
+    if (esurf) esurf[b] = -(p01[2 * b + 1] - p01[2 * b]) / (h->xgrid[1] - h->xgrid[0]);
+  }
+  return PNP_OK;
+}
+
 int pnp_get_newton_iterations(pnp_handle* h, int32_t* iters) {
   if (!h || !iters) return fail(h, PNP_EINVAL, "pnp_get_newton_iterations: null argument");
   if (!h->newton) return fail(h, PNP_EINVAL, "pnp_get_newton_iterations: the handle was not created with PNP_METHOD_NEWTON");

@@ -166,6 +166,11 @@ int pnp_set_wall_kinetics(pnp_handle* h, int32_t n, const int32_t* species, cons
 /* Stationary solve of every lane from the current state as the initial guess (studies=['stat'], transport.py:811-812).
  * tol/maxit <= 0 keep the values of pnp_set_newton.  status[B] nullable. */
 int pnp_solve_stationary(pnp_handle* h, double tol, int32_t maxit, int32_t* status);
+/* One transport solve as the SCF loop needs it (calculator.py:373-400: new fluxes in, surface state out) in a single call with a
+ * single synchronisation: optional pnp_set_flux(flux), then pnp_solve_stationary (nsteps = 0) or pnp_step(nsteps), then
+ * pnp_get_surface + pnp_get_status.  Any output pointer may be NULL. */
+int pnp_solve_surface(pnp_handle* h, const double* flux, int32_t nsteps, double* csurf, double* vsurf, double* esurf,
+                      int32_t* status);
 /* Newton iterations each lane spent in the most recent pnp_step / pnp_solve_stationary call, summed over its
  * timesteps; a solve that hit maxit counts maxit+1. */
 int pnp_get_newton_iterations(pnp_handle* h, int32_t* iters /* [B] */);
