@@ -366,6 +366,27 @@ class Calculator(object):
                     d['system']['pH'] = ph - np.log10(gamma)
                     d['system']['surface_pH'] = float(ph[0] - np.log10(gamma[0]))
                 d['system']['activity_coefficient'] = gamma.copy()
+                # derived electrolyte quantities of the COMSOL model (comsol_model.py:1010-1040), on the cell edges
+                x = np.asarray(tp.xmesh, float)
+                h = np.diff(x)
+                z = tp.charges / unit_F
+                cmid = 0.5 * (cfin[:, 1:] + cfin[:, :-1])
+                um = tp.D * tp.beta                                            # mobility D/(RT)
+                kappa = unit_F ** 2 * ((z ** 2 * um)[:, None] * cmid).sum(axis=0)              # rho_c, S/m
+                w = -np.log(1.0 / gamma)                                                       # -ln(1-phi0)
+                u = (tp.charges * tp.beta)[:, None] * np.diff(v[i])[None, :] + np.diff(w)[None, :]
+                with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+                    Bu = np.where(np.abs(u) < 1e-8, 1.0 - 0.5 * u, u / np.expm1(u))
+                jtot = -(tp.D[:, None] / h[None, :]) * ((Bu + u) * cfin[:, 1:] - Bu * cfin[:, :-1])   # Scharfetter-Gummel flux
+                jdif = -(tp.D[:, None] / h[None, :]) * np.diff(cfin, axis=1)
+                i_el = unit_F * (z[:, None] * jtot).sum(axis=0)                                # A/m^2
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    dphi_iR = np.concatenate([[0.0], np.cumsum(np.where(kappa > 0, -i_el / kappa, 0.0) * h)])
+                    dphi_diff = np.concatenate([[0.0], np.cumsum(np.where(kappa > 0, unit_F * (z[:, None] * jdif).sum(axis=0) / kappa, 0.0) * h)])
+                d['system'].update({'conductivity': kappa, 'electrolyte_current_density': i_el, 'delta_phi_iR': dphi_iR,
+                                    'delta_phi_diff': dphi_diff, 'delta_phi_iR_inf': float(dphi_iR[-1]),
+                                    'delta_phi_diff_inf': float(dphi_diff[-1]), 'delta_phi_inf': float(v[i, -1] - v[i, 0]),
+                                    'delta_phi_inf_min_iR': float(v[i, -1] - v[i, 0] - dphi_iR[-1])})
                 es = tp.system.get('Stern epsilon', None)
                 if isinstance(es, (int, float)) and es:
                     d['system']['Stern_efield'] = float(-g[i, 0]) * tp.system['epsilon'] / es

@@ -200,6 +200,11 @@ def test_comsol_calculator_is_the_implicit_gpu_solve_and_matches_the_oracle():
     g0 = 1.0 / (1.0 - 6.022140857e23 * 4.1e-10 ** 3 * np.array(d0['species']['K+']['concentration']))
     assert np.allclose(d0['species']['CO2']['activity_coefficient'], g0) and d0['species']['K+']['surface_activity_coefficient'] == g0[0]
     assert np.allclose(d0['system']['efield'][1:-1], -(np.array(d0['system']['potential'])[2:] - np.array(d0['system']['potential'])[:-2]) / (2 * tp.dx))
+    # derived electrolyte outputs (comsol_model.py:1010-1040): no wall flux -> no current, no ohmic drop; bulk conductivity
+    kb = 96485.33289 ** 2 * tp.beta * (tp.D[0] * 100.0 + tp.D[1] * 100.0)
+    assert np.isclose(d0['system']['conductivity'][-1], kb, rtol=1e-6)
+    assert np.abs(d0['system']['electrolyte_current_density']).max() < 1e-2 and abs(d0['system']['delta_phi_iR_inf']) < 1e-9
+    assert np.isclose(d0['system']['delta_phi_inf'], -d0['system']['surface_potential'])
     cK = [tp.alldata[i]['species']['K+']['surface_concentration'] for i in range(len(phis))]
     assert cK[0] > cK[1] > cK[2] > cK[3]                   # cations pile up at negative potentials ...
     assert cK[0] < 1.0 / (6.022140857e23 * 4.1e-10 ** 3)   # ... but never beyond close packing
