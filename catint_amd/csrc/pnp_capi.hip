@@ -27,6 +27,7 @@ struct pnp_handle {
   double *c = nullptr, *lapl[2] = {nullptr, nullptr}, *v = nullptr, *gradv = nullptr, *rates = nullptr;
   double *pb = nullptr, *vzeta = nullptr, *flux = nullptr, *cbulk = nullptr, *csurf = nullptr;
   double *ytmp = nullptr, *ftmp = nullptr;   // method-of-lines scratch: state in, derivative out
+  double* mol_lapl = nullptr;                // ... and its charge row for grids beyond one wave
   SpecConst* spec = nullptr;
   int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
   int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
@@ -91,7 +92,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -694,7 +695,6 @@ static int ensure_potential_buffers(pnp_handle* h) {
 int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
   if (!h || !c || !dcdt) return fail(h, PNP_EINVAL, "pnp_mol_rhs: null argument");
   if (h->newton) return fail(h, PNP_EINVAL, "pnp_mol_rhs: not part of the physical mode");
-  if (waves_per_system(h->a.nx) > 1) return fail(h, PNP_EINVAL, "pnp_mol_rhs: nx > 1026 is not supported by the method-of-lines RHS");
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_mol_rhs: call pnp_set_batch first");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
@@ -712,7 +712,21 @@ int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
     a.c = h->ytmp;   // get_rates(C) of the state being differentiated (calculator_old.py:872-873)
     HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
   }
-  HIP_TRY(h, launch_mol_rhs(a, h->ytmp, h->ftmp, h->stream));
+  if (waves_per_system(a.nx) > 1) {
+    // grids beyond one wave: charge row of the state -> Poisson (multi-wave scans) -> point-wise right-hand side
+    const int rc = ensure_potential_buffers(h);
+    if (rc != PNP_OK) return rc;
+    if (!h->mol_lapl) HIP_TRY(h, dev_alloc(h, &h->mol_lapl, (size_t)h->cfg.batch_capacity * ldx));
+    DevArgs ay = a;
+    ay.c = h->ytmp;
+    if (a.use_mig) {
+      HIP_TRY(h, launch_charge_row(ay, h->mol_lapl, h->stream));
+      HIP_TRY(h, launch_poisson(a, h->mol_lapl, h->v, h->gradv, h->stream));
+    }
+    HIP_TRY(h, launch_mol_rhs_pointwise(a, h->ytmp, h->gradv, h->ftmp, h->stream));
+  } else {
+    HIP_TRY(h, launch_mol_rhs(a, h->ytmp, h->ftmp, h->stream));
+  }
   HIP_TRY(h, hipMemcpy2DAsync(dcdt, w, h->ftmp, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return PNP_OK;

@@ -92,6 +92,8 @@ hipError_t launch_poisson(const DevArgs& a, const double* lapl, double* v, doubl
 hipError_t launch_rates(const DevArgs& a, const ReactionTable& rt, double* rates, hipStream_t stream);
 // method-of-lines RHS (ode_func, calculator_old.py:827-935): dydt[b][k][i] from y[b][k][i]
 hipError_t launch_mol_rhs(const DevArgs& a, const double* y, double* dydt, hipStream_t stream);
+// the same for grids spanning several waves: point-wise from a gradient row computed by launch_poisson
+hipError_t launch_mol_rhs_pointwise(const DevArgs& a, const double* y, const double* gradv, double* dydt, hipStream_t stream);
 // surface gather: csurf[B][N] = c[b][k][0]
 hipError_t launch_surface(const DevArgs& a, double* csurf, hipStream_t stream);
 

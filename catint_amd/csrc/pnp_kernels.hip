@@ -1714,6 +1714,39 @@ __global__ __launch_bounds__(64) void mol_rhs_kernel(const DevArgs A, const doub
   (void)m;
 }
 
+// ode_func for grids beyond one wave (nx > 1026): the same right-hand side evaluated point by point from a gradient row that
+// launch_poisson produced (any grid length, any Poisson branch).  One thread per (lane, species, grid point).
+__global__ void mol_rhs_pointwise_kernel(const DevArgs A, const double* __restrict__ y, const double* __restrict__ gradv,
+                                         double* __restrict__ dydt) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = A.B * A.N * (int64_t)A.ldx;
+  if (idx >= total) return;
+  const int ldx = A.ldx, nx = A.nx, N = A.N;
+  const int i = (int)(idx % ldx);
+  const int64_t bk = idx / ldx;
+  const int k = (int)(bk % N);
+  const int64_t b = bk / N;
+  const double* c = y + bk * (int64_t)ldx;
+  const double* g = gradv + b * (int64_t)ldx;
+  const double dx = A.dx, dt = A.dt;
+  const SpecConst& S = A.spec[k];
+  const double bq = A.beta * S.q;
+  double out = 0.0;                      // bulk point (:886) and the pitch tail
+  if (i == 0) {                          // wall cell :897-915 (no rate term)
+    const double g1 = A.use_mig ? g[1] : 0.0;
+    const double corr0 = A.lf ? (c[1] - c[0]) / dt : 0.0;
+    out = corr0 + (S.D * ((c[2] - c[0]) / (2. * dx) + bq * c[1] * g1) - A.flux[b * N + k]) / dx;
+  } else if (i < nx - 1) {               // :916-927
+    const double gp = A.use_mig ? g[i + 1] : 0.0, gm = A.use_mig ? g[i - 1] : 0.0;
+    const double d2c = (c[i + 1] - 2 * c[i] + c[i - 1]) / (dx * dx);
+    const double dcg = (c[i + 1] * gp - c[i - 1] * gm) / (2. * dx);
+    const double corr = A.lf ? d2c * (dx * dx) / dt / 2. : 0.0;
+    out = corr + S.D * (d2c + bq * dcg);
+    if (A.has_rates) out += A.rates[bk * (int64_t)ldx + i];
+  }
+  dydt[idx] = out;
+}
+
 // lapl[b][i] = -sum_k q_k c[b][k][i]/eps  (:767-771), thread per grid point
 __global__ void charge_row_kernel(const DevArgs A, double* __restrict__ lapl) {
   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1924,6 +1957,13 @@ hipError_t launch_poisson(const DevArgs& a, const double* lapl, double* v, doubl
     case 16: hipLaunchKernelGGL(poisson_kernel<16>, grid, block, lds_bytes_for<16>(2), stream, a, lapl, v, gradv); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_mol_rhs_pointwise(const DevArgs& a, const double* y, const double* gradv, double* dydt, hipStream_t stream) {
+  const int64_t total = a.B * a.N * (int64_t)a.ldx;
+  const int threads = 256;
+  hipLaunchKernelGGL(mol_rhs_pointwise_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, stream, a, y, gradv, dydt);
   return hipGetLastError();
 }
 

@@ -139,3 +139,23 @@ def test_config5_shape_lanes_all_poisson_branches():
         ref, (rv, rg, rl) = oracle_steps(p, 'Crank-Nicolson', c0, pbm, vz, fl, 5)
         assert relerr(c, ref) < RTOL, name
         assert relerr(v, rv) < RTOL and relerr(g, rg) < RTOL and relerr(l, rl) < RTOL, name
+
+
+@pytest.mark.parametrize("nx,pbv,lf", [(2050, [0.02, 0.0, np.nan, np.nan], False), (4096, [0.02, np.nan, np.nan, 1e4], True)])
+def test_method_of_lines_rhs_on_grids_beyond_one_wave(nx, pbv, lf):
+    """ode_func (calculator_old.py:827-935) for nx > 1026: charge row -> multi-wave Poisson -> point-wise RHS, against the oracle."""
+    from oracle import pnp_ref as R
+    from catint_amd.host import solver_from_problem
+    rng = np.random.default_rng(nx)
+    N = 3
+    p = R.Problem(D=np.array([1.957e-9, 2.032e-9, 1.185e-9]), charges=np.array([1, -1, -1]) * 96485.33289, beta=1 / (8.3144598 * 298.14),
+                  eps=78.36 * 8.854187817e-12, dx=2e-11, nx=nx, dt=1e-12, pb=np.array(pbv), vzeta=0.01,
+                  flux_bound=np.array([1e-5, 0.0, -2e-5]), lax_friedrich=lf)
+    y = rng.uniform(5.0, 15.0, (2, N * nx))
+    y[:, :nx] = y[:, nx:2 * nx] + y[:, 2 * nx:]                     # neutral states: the potential stays moderate
+    with solver_from_problem(p, 'FTCS', batch_capacity=2) as s:
+        s.set_batch(y, np.stack([p.pb] * 2), [p.vzeta] * 2, np.stack([p.flux_bound] * 2))
+        f = s.mol_rhs(y)
+    for b in range(2):
+        ref = R.mol_rhs(y[b], p, solver='banded')
+        assert np.abs(f[b] - ref).max() <= 1e-9 * np.abs(ref).max()
