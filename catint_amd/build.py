@@ -12,8 +12,11 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-unused-function']
 
 
+PARTIAL = os.path.join(LIB_DIR, '.partial')      # left by tools/devbuild.sh: the library holds only one block size
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or os.path.exists(PARTIAL):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
@@ -31,4 +34,6 @@ def build_library(force=False, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed:\n' + r.stdout + r.stderr)
+    if os.path.exists(PARTIAL):
+        os.remove(PARTIAL)
     return LIB
