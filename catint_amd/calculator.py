@@ -391,6 +391,9 @@ class Calculator(object):
                 if isinstance(es, (int, float)) and es:
                     d['system']['Stern_efield'] = float(-g[i, 0]) * tp.system['epsilon'] / es
                     d['system']['Stern_epsilon_func'] = es
+                elif es == 'Booth':           # field-dependent Stern permittivity, comsol_reader.py:102-119, :262-273
+                    from .host import booth_stern_field
+                    d['system']['Stern_efield'], d['system']['Stern_epsilon_func'] = booth_stern_field(-g[i, 0], tp.system['epsilon'])
         return cout
 
     # ------------------------------------------------------------------------------------------

@@ -57,3 +57,35 @@ def graded_mesh(length, h0, nx):
     x = np.concatenate([[0.0], np.cumsum(h0 * r ** np.arange(n))])
     x[-1] = length
     return x
+
+
+def booth_permittivity(E, eps_r, n=1.33, beta=1.41e-8):
+    """Field-dependent relative permittivity of water (Booth), as the reference's reader uses it for the Stern layer
+    (comsol_reader.py:102-114): n^2 + (eps_r - n^2) * 3/(beta E) * (coth(beta E) - 1/(beta E)) for |E| >= 1e7 V/m, eps_r below."""
+    import numpy as np
+    E = abs(float(E))
+    if E < 1e7:
+        return float(eps_r)
+    x = beta * E
+    return n ** 2 + (eps_r - n ** 2) * 3.0 / x * (1.0 / np.tanh(x) - 1.0 / x)
+
+
+def booth_stern_field(E_out, eps_r):
+    """Field inside the Stern layer from the field at its outer plane: the root of E = E_out * eps_r / eps_Booth(|E|)
+    (comsol_reader.py:115-119, :262-273; the reference minimises the squared mismatch by basin hopping).  The right-hand side
+    grows with |E| (the permittivity drops), bounded by eps_r/n^2: bisection on a bracket that always contains the root."""
+    E_out = float(E_out)
+    if E_out == 0.0:
+        return 0.0, float(eps_r)
+    sgn = 1.0 if E_out > 0 else -1.0
+    a = abs(E_out)
+    f = lambda E: E - a * eps_r / booth_permittivity(E, eps_r)
+    lo, hi = a, a * eps_r / 1.33 ** 2 * 1.0000001
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if f(mid) > 0:
+            hi = mid
+        else:
+            lo = mid
+    E = 0.5 * (lo + hi)
+    return sgn * E, booth_permittivity(E, eps_r)

@@ -127,3 +127,15 @@ def test_graded_mesh_and_guards():
         Calculator(transport=tp, calc='Crank-Nicolson', dt=1e-10, tmax=1e-9)           # FD integrators need a uniform mesh
     with pytest.raises(CalculatorError):
         Calculator(transport=make_tp([0.0]), calc='FTCS', dt=1e-10, tmax=1e-9).set_surface_kinetics([])
+
+
+def test_booth_stern_field():
+    from catint_amd.host import booth_permittivity, booth_stern_field
+    assert booth_permittivity(5e6, 78.36) == 78.36
+    assert 1.33 ** 2 < booth_permittivity(5e9, 78.36) < booth_permittivity(5e8, 78.36) < 78.36
+    for e_out in (1e5, -3e8, 2e9):
+        E, eps = booth_stern_field(e_out, 78.36)
+        assert np.sign(E) == np.sign(e_out) and abs(E) >= abs(e_out)
+        assert abs(E - e_out * 78.36 / booth_permittivity(E, 78.36)) <= 1e-9 * abs(E)       # displacement continuity
+        assert np.isclose(eps, booth_permittivity(E, 78.36))
+    assert booth_stern_field(0.0, 78.36) == (0.0, 78.36)
