@@ -259,7 +259,7 @@ class Calculator(object):
         Stationary mode: Newton from the current state (warm) or from the bulk state.  If lanes do not converge from the
         bulk state -- or the potentials are far from phiPZC, or surface kinetics are coupled in, where that is the rule --
         every lane walks a continuation path instead: the wall potential goes from phiPZC (uncharged interface) to its phiM
-        in stages of at most tp.newton['dphi_stage'] (0.1 V), the prescribed fluxes grow proportionally and the surface
+        in stages of at most tp.newton['dphi_stage'] (0.2 V; 0.1 ... 0.5 V give the same answer on the CO2R example), the prescribed fluxes grow proportionally and the surface
         rate constants are evaluated at the stage potential, each stage warm-started from the previous one (the reference's
         parametric sweeps: flux_factor / PZC / CS ramps, transport.py:877-893, comsol_model.py:1147-1167).
         Time-dependent mode: tp.nt-1 backward-Euler steps.  Returns status [B]."""
@@ -289,7 +289,7 @@ class Calculator(object):
             st = solver.solve_stationary()
             if not (st != 0).any() or nramp <= 1:
                 return st
-        nst = max(int(nramp), int(np.ceil(span / nk.get('dphi_stage', 0.1))))
+        nst = max(int(nramp), int(np.ceil(span / nk.get('dphi_stage', 0.2))))
         self.continuation_stages = nst
         for j in range(1, nst + 1):
             w = j / float(nst)
@@ -326,8 +326,11 @@ class Calculator(object):
         flux = np.repeat(tp.flux_bound[None, :, 0], B, axis=0)
         if self.physical:
             phiM = np.array([dict(tp.system, **{keys[0]: v1, keys[1]: v2})['phiM'] for (v1, v2) in lanes], float)
+            import time as _time
             with self._physical_solver(B) as s:
+                _t0 = _time.perf_counter()
                 status = self.solve_physical(s, c0, phiM, flux)
+                self.solve_seconds = _time.perf_counter() - _t0        # transport solves only (incl. their host<->device traffic)
                 cfin, v, g, l = s.get_state()
                 self.newton_iterations = s.newton_iterations()
                 if getattr(self, 'surface_kinetics', None):

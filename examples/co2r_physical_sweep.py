@@ -79,8 +79,10 @@ def main():
     j = calc.kinetic_flux[:, names.index('CO')] * 2 * unit_F / 10.0            # mA/cm^2 (nel = 2), comsol_reader.py:241-246
     ok = calc.status == 0
     jlim = tp.D[names.index('CO2')] * 33.429 / tp.xmesh[-1] * 2 * unit_F / 10.0
-    print('%d lanes x %d species x %d points (graded, h0 = %.2e m ... %.2e m): %d converged, %.1f Newton iterations/lane, %.2f s'
-          % (a.lanes, tp.nspecies, tp.nx, tp.xmesh[1], tp.xmesh[-1] - tp.xmesh[-2], ok.sum(), calc.newton_iterations.mean(), t1 - t0))
+    print('%d lanes x %d species x %d points (graded, h0 = %.2e m ... %.2e m): %d converged, %d continuation stages, '
+          '%.2f s in the transport solves, %.2f s in total (incl. the per-lane result dictionaries)'
+          % (a.lanes, tp.nspecies, tp.nx, tp.xmesh[1], tp.xmesh[-1] - tp.xmesh[-2], ok.sum(), calc.continuation_stages,
+             calc.solve_seconds, t1 - t0))
     print('phiM [V]   j_CO [mA/cm2]   c_CO2(0)   pH(0)   phi(0) [V]   c_K+(0)')
     for i in np.linspace(0, a.lanes - 1, min(a.lanes, 9)).astype(int):
         d = tp.alldata[i]

@@ -79,7 +79,7 @@ def test_failed_direct_solve_restarts_on_the_continuation_path():
     assert np.allclose([c for c in s.calls if c[0] == 'set_flux'][-1][1], flux)
 
 
-def test_far_potentials_and_kinetics_walk_from_phi_pzc_in_100mV_stages():
+def test_far_potentials_and_kinetics_walk_from_phi_pzc_in_200mV_stages():
     phis = np.linspace(-0.5, -2.0, 4)
     tp = make_tp(phis)
     calc = Calculator(transport=tp, calc='comsol')
@@ -87,7 +87,7 @@ def test_far_potentials_and_kinetics_walk_from_phi_pzc_in_100mV_stages():
     calc.set_surface_kinetics([{'species': 'CO2', 'rate': rate, 'stoichiometry': {'CO2': -1.0, 'HCO3-': 0.5}}])
     s = FakeSolver()
     calc.solve_physical(s, np.zeros((4, 3 * tp.nx)), phis, np.zeros((4, 3)))
-    assert calc.continuation_stages == int(np.ceil(2.16 / 0.1))
+    assert calc.continuation_stages == int(np.ceil(2.16 / 0.2))
     assert [c[0] for c in s.calls].count('solve') == calc.continuation_stages
     kin = [c for c in s.calls if c[0] == 'kinetics']
     assert len(kin) == calc.continuation_stages and kin[0][1] == [2]
