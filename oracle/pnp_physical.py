@@ -289,6 +289,10 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
     upd_prev = np.inf
     for it in range(1, maxit + 1):
         F, L, M, U = residual_and_jacobian(p, c, phi, c_old, dt)
+        if not (np.all(np.isfinite(F)) and np.all(np.isfinite(M))):      # diverged: the device keeps iterating on NaNs and reports
+            c = np.full_like(c, np.nan)                                   # maxit+1 iterations and the NaN status
+            phi = np.full_like(phi, np.nan)
+            break
         du = solver(L, M, U, -F)
         lam = 1.0
         if dphi_max is not None:

@@ -5,6 +5,8 @@ parity with the reference's COMSOL path itself is unpinned (no fixtures exist, S
 Tolerance: both sides iterate Newton to a scaled update < 1e-10 with the same damping rules, so the converged states agree
 to ~1e-9 relative whatever the linear solver (LAPACK banded LU on the CPU, block cyclic reduction on the GPU).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -330,3 +332,15 @@ def test_surface_observables():
     assert np.allclose(cs, c[:, :, 0]) and np.allclose(vs, phiM) and np.allclose(es, -(phi[:, 1] - phi[:, 0]) / dx)
     assert np.allclose(l, -(q[None, :, None] * c).sum(axis=1) / EPS)
     assert np.allclose(g[:, 1:-1], (phi[:, 2:] - phi[:, :-2]) / (2 * dx))
+
+
+def test_randomised_configurations_follow_the_oracle():
+    """tools/probe/fuzz_newton.py at test size: random species counts, grids, boundary models, reactions, kinetics, fluxes,
+    stationary or transient -- converged lanes equal the oracle, every lane takes the oracle's number of Newton iterations."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FUZZ_SEED='3', FUZZ_CASES='30')
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), '..', 'tools', 'probe', 'fuzz_newton.py')], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert '30 cases, 0 bad' in r.stdout, r.stdout[-3000:]

@@ -1,0 +1,53 @@
+"""dev probe: randomised physical-mode configurations, GPU vs oracle (states and Newton iteration counts)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+import numpy as np
+import tests.test_gpu_newton as T
+from catint_amd.host import graded_mesh
+
+rng = np.random.default_rng(int(os.environ.get('FUZZ_SEED', '1')))
+ncase = int(os.environ.get('FUZZ_CASES', '60'))
+bad = 0
+t0 = time.time()
+for case in range(ncase):
+    N = int(rng.integers(1, 9))
+    nx = int(rng.choice([8, 17, 33, 64, 65, 100, 129, 200, 257, 400, 513, 700]))
+    B = int(rng.integers(1, 4))
+    kw = {}
+    if rng.random() < 0.5:
+        kw.update(wall_bc='stern', stern_capacitance=float(rng.uniform(0.05, 0.4)), phi_pzc=float(rng.uniform(-0.1, 0.1)))
+    mpb = rng.random() < 0.5
+    if mpb:
+        kw['mpb_radius'] = [float(a) for a in rng.uniform(0, 4.2e-10, N) * (rng.random(N) < 0.7)]
+    rx = None
+    if N >= 2 and rng.random() < 0.5:
+        rx = []
+        for _ in range(int(rng.integers(1, 4))):
+            nl, nr = int(rng.integers(0, 3)), int(rng.integers(1, 3))
+            rx.append({'lhs': [int(k) for k in rng.integers(0, N, nl)], 'rhs': [int(k) for k in rng.integers(0, N, nr)],
+                       'kf': float(10 ** rng.uniform(0, 4)), 'kr': float(10 ** rng.uniform(0, 4))})
+    wk = None
+    if rng.random() < 0.4:
+        nu = [float(v) for v in rng.choice([-1.0, 0.0, 1.0, 0.5], N)]
+        wk = [{'species': int(rng.integers(-1, N)), 'k': rng.uniform(1e-4, 1e-1, B) * (1e-4 if rng.random() < 0.3 else 1.0), 'nu': nu}]
+    flux = rng.uniform(-1e-4, 1e-4, (B, N)) if rng.random() < 0.5 else None
+    x = graded_mesh(float(rng.uniform(3, 30)) * nx, 1.0, nx) if rng.random() < 0.4 else None
+    stationary = rng.random() < 0.6
+    try:
+        got, ref = T.run_both(N, nx, B=B, seed=1000 + case, newton_kw=dict(kw, maxit=60), reactions=rx, wall_kinetics=wk, flux=flux, x=x,
+                              stationary=stationary, dt=float(10 ** rng.uniform(-9, -6)), nsteps=int(rng.integers(1, 4)),
+                              phi_lo=-0.3, phi_hi=0.3, points_per_debye=float(rng.uniform(2, 10)))
+        c, phi, its, st = got
+        rc, rphi, rit = ref
+        good = st == 0                       # lanes whose every solve converged; the others only have to agree on that
+        dc = max([np.abs(c[b] - rc[b]).max() / np.abs(rc[b]).max() for b in range(B) if good[b]] + [0.0])
+        dp = max([np.abs(phi[b] - rphi[b]).max() for b in range(B) if good[b]] + [0.0])
+        ok = np.array_equal(its, rit) and dc < 1e-7 and dp < 1e-7
+        tag = 'ok ' if ok else 'BAD'
+    except Exception as e:
+        ok, tag, dc, dp, its, rit, st = False, 'EXC', -1, -1, str(e)[:80], '', ''
+    bad += 0 if ok else 1
+    if not ok or case % 10 == 0:
+        print('%s case %2d N=%d nx=%d B=%d stern=%d mpb=%d rx=%s wk=%d flux=%d grid=%d stat=%d  dc=%.1e dphi=%.1e its=%s ref=%s st=%s' % (
+            tag, case, N, nx, B, 'wall_bc' in kw, mpb, len(rx) if rx else 0, wk is not None, flux is not None, x is not None, stationary, dc, dp, its, rit, st), flush=True)
+print('%d cases, %d bad, %.1f s' % (ncase, bad, time.time() - t0))
