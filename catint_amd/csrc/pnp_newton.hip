@@ -1141,7 +1141,11 @@ __device__ __forceinline__ void team_solve(double (&Dr)[NB], double (&Xr)[2 * NB
 }
 
 template <int NB, int MODE>
-__global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A) {
+__global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G) {
+  __shared__ NewtonArgs sA;        // scalar parameters in LDS, pointers stay kernel arguments (see newton_pair_kernel)
+  if (threadIdx.x == 0) sA = G;
+  __syncthreads();
+  const NewtonArgs& A = sA;
   using TL = TeamLayout<NB>;
   constexpr int N = NB - 1, NC = TL::NC, NCP = TL::NCP, TPW = TL::TPW;
   constexpr bool MPB = MODE >= 1, REACT = MODE == 2;
@@ -1157,7 +1161,7 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A
   double* strip = newton_lds + (size_t)(wave * (TPW + 1) + tw) * TL::SLT;
   double* tile = strip + TL::SL;                  // NB x NC doubles: one neighbour block row
   const int nx = A.nx, ldx = A.ldx;
-  double* rowbuf = A.work + (size_t)blockIdx.x * A.work_stride;
+  double* rowbuf = G.work + (size_t)blockIdx.x * G.work_stride;
   auto REC = [&](int row, int rr) { return rowbuf + ((size_t)row * NB + rr) * NCP; };
   // per-lane species constants (lane N: Poisson row, constants unused)
   double qb_r = 0.0, sig_r = 0.0, fl_r = 0.0, peq_r = 0.0, vol_r = 0.0, rs_r = 0.0;
@@ -1173,15 +1177,15 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A
     }
   const bool spec = r < N;
   const int rs_ = spec ? r : 0;                   // clamped species index for loads
-  for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
-    double* c = A.c + (size_t)b * N * ldx;
-    double* co = A.c_old + (size_t)b * N * ldx;
-    double* phi = A.phi + (size_t)b * ldx;
-    const double* cb = A.cbulk + (size_t)b * N;
-    const double* wk = A.wk_k + (size_t)b * PNP_MAX_WALL_REACTIONS;
-    const double flux_r = A.flux[(size_t)b * N + rs_];
+  for (int64_t b = blockIdx.x; b < G.B; b += gridDim.x) {
+    double* c = G.c + (size_t)b * N * ldx;
+    double* co = G.c_old + (size_t)b * N * ldx;
+    double* phi = G.phi + (size_t)b * ldx;
+    const double* cb = G.cbulk + (size_t)b * N;
+    const double* wk = G.wk_k + (size_t)b * PNP_MAX_WALL_REACTIONS;
+    const double flux_r = G.flux[(size_t)b * N + rs_];
     const double cb_r = cb[rs_];
-    const double phiM = A.pb[b * 4 + 0], phiB = A.pb[b * 4 + 1];
+    const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
     int total_it = 0, st = PNP_STATUS_OK;
     for (int step = 0; step < A.nsteps; ++step) {
       for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
@@ -1224,7 +1228,7 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A
             inv0 = 1.0 / (1.0 - f0);
             invp = 1.0 / (1.0 - fp);
           }
-          const double wem = A.gw[im], wep = A.gw[i < nx - 1 ? i : nx - 2], vi = A.gv[i];
+          const double wem = G.gw[im], wep = G.gw[i < nx - 1 ? i : nx - 2], vi = G.gv[i];
           double Dr[NB], Xr[NC];
 #pragma unroll
           for (int j = 0; j < NB; ++j) Dr[j] = 0.0;
@@ -1256,7 +1260,7 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A
               }
             }
             if constexpr (REACT) {       // mass action in activities, see fill_row
-              const ReactionTable* rt = A.rt;
+              const ReactionTable* rt = G.rt;
               double call[N];
 #pragma unroll
               for (int k = 0; k < N; ++k) call[k] = c[k * ldx + i];
@@ -1546,8 +1550,8 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs A
     __syncthreads();
     if (tid == 0) {
       for (int w = 0; w < nwaves; ++w) bad = fmax(bad, red[0][w]);
-      A.status[b] = bad > 0.0 ? PNP_STATUS_NAN : st;
-      A.iters[b] = total_it;
+      G.status[b] = bad > 0.0 ? PNP_STATUS_NAN : st;
+      G.iters[b] = total_it;
     }
     __syncthreads();
   }
