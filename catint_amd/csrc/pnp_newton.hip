@@ -764,7 +764,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
   double* xch = newton_lds;
   const int tid = threadIdx.x, T = blockDim.x;
   const int nx = A.nx, ldx = A.ldx;
-  const int ra = 2 * tid, rb = 2 * tid + 1;
+  // (row indices ra, rb are re-derived from an opaque copy of tid inside the Newton loop, see there)
   double* stash = G.stash + (size_t)blockIdx.x * G.stash_stride;
   for (int64_t b = blockIdx.x; b < G.B; b += gridDim.x) {
     double* c = G.c + (size_t)b * N * ldx;
@@ -782,6 +782,12 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
       double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
+        // The thread index is made opaque once per iteration: the compiler then recomputes the ~100 global addresses that
+        // depend on it (state rows at four points, parked row) where they are used, instead of precomputing all of them
+        // before the loop and reloading them from spill slots -- scratch memory that misses L2 -- every iteration.
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int ra = 2 * tv, rb = 2 * tv + 1;
         // ---- rows a and b (the edge between them is evaluated once); a normalised
         double Ma[NB][NB], Xa[NB][NC];     // Xa = [Lt_a | Ut_a | rt_a] after the solve
         double Mb[NB][NB], Xb[NB][NC];
@@ -798,7 +804,6 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
           Edge e0[N], e1[N], e2[N];
           edge_fluxes<N, MODE>(A, P0, P1, w0, e0);
           edge_fluxes<N, MODE>(A, P1, P2, w1, e1);
-          edge_fluxes<N, MODE>(A, P2, P3, w2, e2);
           if (ra < nx) {
             fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, ra, P0, P1, P2, e0, e1, w0, w1, G.gv[i1], Ma, Xa);
             block_solve<NB, NC, true>(Ma, Xa);
@@ -809,6 +814,8 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
               for (int cc = 0; cc < NC; ++cc) Xa[r][cc] = 0.0;
           }
           lds_store_row<NB, TS>(xch, tid, Xa);
+          __builtin_amdgcn_sched_barrier(0);          // row a is complete before the work on row b starts (register pressure)
+          edge_fluxes<N, MODE>(A, P2, P3, w2, e2);
           if (rb < nx) {
             fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, rb, P1, P2, P3, e1, e2, w1, w2, G.gv[i2], Mb, Xb);
           } else {
@@ -823,31 +830,41 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
         }
         __syncthreads();
         {
-          // eliminate x_a (own) and x_a' (thread t+1) from row b:  L_b x_a + M_b x_b + U_b x_a' = r_b
-          double Lb[NB][NB], Ub[NB][NB], Q[NB][NB], qv[NB];
+          // eliminate x_a (own) and x_a' (thread t+1) from row b:  L_b x_a + M_b x_b + U_b x_a' = r_b.
+          // Ordered for a small live set: the own a-row is used first and parked right away, the coupling blocks are
+          // consumed row by row (no copies of L_b), then the neighbour's blocks stream through one register block.
+          double Ub[NB][NB], Q[NB][NB], qv[NB];
 #pragma unroll
-          for (int r = 0; r < NB; ++r)
+          for (int r = 0; r < NB; ++r) {
+            double lrow[NB];
 #pragma unroll
-            for (int cc = 0; cc < NB; ++cc) {
-              Lb[r][cc] = Xb[r][cc];
-              Ub[r][cc] = Xb[r][NB + cc];
-              Xb[r][cc] = 0.0;
-              Xb[r][NB + cc] = 0.0;
+            for (int j = 0; j < NB; ++j) {
+              lrow[j] = Xb[r][j];
+              Ub[r][j] = Xb[r][NB + j];
+              Xb[r][j] = 0.0;
+              Xb[r][NB + j] = 0.0;
             }
-          // own a-row: M_b -= L_b Ut_a ; L' = -L_b Lt_a ; r' -= L_b rt_a
+            // own a-row: M_b -= L_b Ut_a ; L' = -L_b Lt_a ; r' -= L_b rt_a
 #pragma unroll
-          for (int r = 0; r < NB; ++r)
+            for (int j = 0; j < NB; ++j) {
 #pragma unroll
-            for (int cc = 0; cc < NB; ++cc)
-#pragma unroll
-              for (int j = 0; j < NB; ++j) {
-                Mb[r][cc] = __builtin_fma(-Lb[r][j], Xa[j][NB + cc], Mb[r][cc]);
-                Xb[r][cc] = __builtin_fma(-Lb[r][j], Xa[j][cc], Xb[r][cc]);
+              for (int cc = 0; cc < NB; ++cc) {
+                Mb[r][cc] = __builtin_fma(-lrow[j], Xa[j][NB + cc], Mb[r][cc]);
+                Xb[r][cc] = __builtin_fma(-lrow[j], Xa[j][cc], Xb[r][cc]);
               }
+              Xb[r][2 * NB] = __builtin_fma(-lrow[j], Xa[j][2 * NB], Xb[r][2 * NB]);
+            }
+          }
+          // park the normalised a-row in device memory (coalesced) until the back-substitution: it would otherwise cost
+          // 2 NB^2 + NB registers through the rest of this phase and every PCR level
+          {
+            double* sp = stash + tv;
 #pragma unroll
-          for (int r = 0; r < NB; ++r)
+            for (int r = 0; r < NB; ++r)
 #pragma unroll
-            for (int j = 0; j < NB; ++j) Xb[r][2 * NB] = __builtin_fma(-Lb[r][j], Xa[j][2 * NB], Xb[r][2 * NB]);
+              for (int cc = 0; cc < NC; ++cc) sp[(size_t)(r * NC + cc) * TS] = Xa[r][cc];
+          }
+          __builtin_amdgcn_sched_barrier(0);
           if (tid + 1 < T) {   // a-row of the next thread: M_b -= U_b Lt_a' ; U' = -U_b Ut_a' ; r' -= U_b rt_a'
             lds_load_block<NB, TS>(xch, tid + 1, 0, Q);
 #pragma unroll
@@ -865,19 +882,6 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
               for (int j = 0; j < NB; ++j) Xb[r][2 * NB] = __builtin_fma(-Ub[r][j], qv[j], Xb[r][2 * NB]);
           }
           block_solve<NB, NC, true>(Mb, Xb);
-        }
-        // park the normalised a-row in device memory (coalesced, L2 resident) until the back-substitution: it
-        // would otherwise cost 2 NB^2 + NB registers through every PCR level
-        {
-          double* sp = stash + tid;
-#pragma unroll
-          for (int r = 0; r < NB; ++r)
-#pragma unroll
-            for (int cc = NB; cc < NC; ++cc) sp[(size_t)(r * NC + cc) * TS] = Xa[r][cc];
-#pragma unroll
-          for (int r = 0; r < NB; ++r)
-#pragma unroll
-            for (int cc = 0; cc < NB; ++cc) sp[(size_t)(r * NC + cc) * TS] = Xa[r][cc];
         }
         // ---- PCR over the T reduced rows, own row in registers
         for (int s = 1; s < T; s <<= 1) {
@@ -938,7 +942,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
         for (int r = 0; r < NB; ++r) xch[r * TS + tid] = dub[r];
         __syncthreads();
         {
-          const double* sp = stash + tid;
+          const double* sp = stash + tv;
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
             double acc = sp[(size_t)(r * NC + 2 * NB) * TS];
