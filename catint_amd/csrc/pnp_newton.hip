@@ -1158,37 +1158,23 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
   const int tid = threadIdx.x, T = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
   const int tw = lane / NB;                       // team inside the wave; tw == TPW: dummy team
-  const int r = lane - tw * NB;                   // row of the block = equation this lane owns
+  const int r0_ = lane - tw * NB;                 // row of the block = equation this lane owns
   const bool real_team = tw < TPW;
-  const int team = wave * TPW + (real_team ? tw : 0);
+  const int team0_ = wave * TPW + (real_team ? tw : 0);
   const int nteams = nwaves * TPW;
   double* strip = newton_lds + (size_t)(wave * (TPW + 1) + tw) * TL::SLT;
   double* tile = strip + TL::SL;                  // NB x NC doubles: one neighbour block row
   const int nx = A.nx, ldx = A.ldx;
   double* rowbuf = G.work + (size_t)blockIdx.x * G.work_stride;
   auto REC = [&](int row, int rr) { return rowbuf + ((size_t)row * NB + rr) * NCP; };
-  // per-lane species constants (lane N: Poisson row, constants unused)
-  double qb_r = 0.0, sig_r = 0.0, fl_r = 0.0, peq_r = 0.0, vol_r = 0.0, rs_r = 0.0;
-#pragma unroll
-  for (int k = 0; k < N; ++k)
-    if (k == r) {
-      qb_r = A.qb[k];
-      sig_r = A.sig[k];
-      fl_r = A.fl[k];
-      peq_r = A.peq[k];
-      vol_r = A.vol[k];
-      rs_r = A.rs[k];
-    }
-  const bool spec = r < N;
-  const int rs_ = spec ? r : 0;                   // clamped species index for loads
+  const bool spec = r0_ < N;
+  const int rs0_ = spec ? r0_ : 0;                // clamped species index for loads
   for (int64_t b = blockIdx.x; b < G.B; b += gridDim.x) {
     double* c = G.c + (size_t)b * N * ldx;
     double* co = G.c_old + (size_t)b * N * ldx;
     double* phi = G.phi + (size_t)b * ldx;
     const double* cb = G.cbulk + (size_t)b * N;
     const double* wk = G.wk_k + (size_t)b * PNP_MAX_WALL_REACTIONS;
-    const double flux_r = G.flux[(size_t)b * N + rs_];
-    const double cb_r = cb[rs_];
     const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
     int total_it = 0, st = PNP_STATUS_OK;
     for (int step = 0; step < A.nsteps; ++step) {
@@ -1198,8 +1184,18 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
       double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
+        // lane coordinates made opaque once per iteration: addresses derived from them are recomputed where they are used
+        // instead of being precomputed before the loop and reloaded from spill slots (see newton_pair_kernel)
         // ---- assembly + normalisation, one block row per team -------------------------------------------------
         for (int row0 = 0; row0 < nx; row0 += nteams) {
+          // lane coordinates made opaque once per pass: everything derived from them (addresses, the lane's species constants,
+          // which are read from the parameter copy in LDS) is recomputed per pass instead of being kept in -- spilled --
+          // registers across the whole Newton loop (see newton_pair_kernel)
+          int r = r0_, team = team0_;
+          asm volatile("" : "+v"(r), "+v"(team));
+          const int rs_ = spec ? r : 0;
+          const double qb_r = A.qb[rs_], sig_r = A.sig[rs_], fl_r = A.fl[rs_], peq_r = A.peq[rs_], vol_r = A.vol[rs_], rs_r = A.rs[rs_];
+          const double flux_r = G.flux[(size_t)b * N + rs_], cb_r = cb[rs_];
           const int i = min(row0 + team, nx - 1);
           const bool valid = real_team && row0 + team < nx;
           const int im = i > 0 ? i - 1 : 0, ip = i < nx - 1 ? i + 1 : nx - 1;
@@ -1359,6 +1355,8 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
         for (; s < nx; s <<= 1) {
           const int nact = (nx - (2 * s - 1) + 2 * s - 1) / (2 * s);      // rows 2s-1 + t*2s < nx
           for (int t0 = 0; t0 < nact; t0 += nteams) {
+            int r = r0_, team = team0_;
+            asm volatile("" : "+v"(r), "+v"(team));
             const int t = t0 + team;
             const bool valid = real_team && t < nact;
             const int row = valid ? 2 * s - 1 + t * 2 * s : 2 * s - 1;
@@ -1449,6 +1447,7 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
         for (s >>= 1; s >= 1; s >>= 1) {
           const int nact = (nx - (s - 1) + 2 * s - 1) / (2 * s);          // rows s-1 + t*2s < nx
           for (int t0 = 0; t0 < nact; t0 += nteams) {
+            const int r = r0_, team = team0_;
             const int t = t0 + team;
             if (real_team && t < nact) {
               const int row = s - 1 + t * 2 * s;
