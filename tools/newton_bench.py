@@ -24,6 +24,8 @@ def main():
     ap.add_argument('--phi-max', type=float, default=0.2)
     ap.add_argument('--dt-factor', type=float, default=0.1)
     ap.add_argument('--stern', action='store_true')
+    ap.add_argument('--mpb', action='store_true', help='steric ions (MPB radii 3-4.5 Angstrom)')
+    ap.add_argument('--reactions', action='store_true', help='one buffer-like homogeneous reaction')
     ap.add_argument('--tol', type=float, default=1e-8)
     a = ap.parse_args()
     from catint_amd import _capi
@@ -32,10 +34,13 @@ def main():
     pb = np.nan_to_num(pb)
     s = _capi.PnpSolver(prob.N, prob.nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton',
                         batch_capacity=a.batch)
+    radii = [4.1e-10, 3.6e-10, 3.3e-10, 3e-10, 3e-10, 3e-10, 4.5e-10, 3.5e-10][:a.nspecies] if a.mpb else None
     if a.stern:
-        s.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=a.tol)
+        s.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=a.tol, mpb_radius=radii)
     else:
-        s.set_newton(tol=a.tol)
+        s.set_newton(tol=a.tol, mpb_radius=radii)
+    if a.reactions and a.nspecies >= 3:
+        s.set_reactions([([1], [2], 5.0e3, 5.0e3)])
     s.set_batch(c0, pb, vz, fl)
     s.step(a.warmup)
     s.synchronize()
