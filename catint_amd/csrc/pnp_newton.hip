@@ -535,6 +535,14 @@ __device__ __forceinline__ void assemble_row(const NewtonArgs& A, const double* 
   fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, i, Pm, P0, Pp, em, ep, wem, wep, A.gv[i], M, X);
 }
 
+// Workgroup barrier that orders LDS traffic only: it does not wait for outstanding global stores (the parked row) the way
+// __syncthreads() does.  For hand-offs that go through LDS alone.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -828,7 +836,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
             }
           }
         }
-        __syncthreads();
+        lds_barrier();  
         {
           // eliminate x_a (own) and x_a' (thread t+1) from row b:  L_b x_a + M_b x_b + U_b x_a' = r_b.
           // Ordered for a small live set: the own a-row is used first and parked right away, the coupling blocks are
@@ -885,9 +893,9 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
         }
         // ---- PCR over the T reduced rows, own row in registers
         for (int s = 1; s < T; s <<= 1) {
-          __syncthreads();                       // everyone has finished reading the previous contents of xch
+          lds_barrier();                         // everyone has finished reading the previous contents of xch
           lds_store_row<NB, TS>(xch, tid, Xb);
-          __syncthreads();
+          lds_barrier();  
           double D[NB][NB], Y[NB][NC], Lt[NB][NB], Ut[NB][NB], Q[NB][NB], qv[NB];
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
@@ -937,10 +945,10 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
         double dub[NB], dua[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) dub[r] = Xb[r][2 * NB];
-        __syncthreads();
+        lds_barrier();  
 #pragma unroll
         for (int r = 0; r < NB; ++r) xch[r * TS + tid] = dub[r];
-        __syncthreads();
+        lds_barrier();  
         {
           const double* sp = stash + tv;
 #pragma unroll
