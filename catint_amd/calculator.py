@@ -304,6 +304,32 @@ class Calculator(object):
         return st
 
     # ------------------------------------------------------------------------------------------
+    def run_single_step(self, label=''):
+        """One transport solve at the CURRENT operating point tp.system / tp.species[*]['flux'] (reference
+        Calculator.run_single_step, calculator.py:408-535: comsol.run + check_error + reader) -- a batch of one lane.  The
+        results go where the reference's reader puts them with update_last (comsol_reader.py:196-279): tp.species[sp]
+        ['concentration','surface_concentration', ...] and tp.system['potential','efield','surface_potential','surface_pH', ...].
+        Returns True when the solve converged (the reference's check_error + NaN test, :409-414, :457)."""
+        tp = self.tp
+        saved = (tp.descriptors, tp.alldata_names, tp.alldata)
+        keys = list(tp.descriptors.keys())
+        try:
+            import collections
+            tp.descriptors = collections.OrderedDict((k, [tp.system[k]]) for k in keys)
+            tp.alldata_names = [[tp.system[keys[0]], tp.system[keys[1]]]]
+            tp.alldata = [{'species': {}, 'system': {}}]
+            tp.flux_bound[:, 0] = [float(tp.species[sp].get('flux', 0.0)) for sp in tp.species]
+            self.run()
+            d = tp.alldata[0]
+        finally:
+            tp.descriptors, tp.alldata_names, tp.alldata = saved
+        for sp in tp.species:
+            tp.species[sp].update(d['species'][sp])
+        tp.system.update({k: v for k, v in d['system'].items() if k not in keys and k != 'status'})
+        self.last_label = label
+        return int(np.atleast_1d(self.status)[0]) == 0
+
+    # ------------------------------------------------------------------------------------------
     def run(self):
         """Descriptor sweep (calculator.py:196-240) with every descriptor point as one GPU lane.
         Fills tp.alldata[i]['species'|'system'] with the field contract of comsol_reader.py:196-326

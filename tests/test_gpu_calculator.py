@@ -318,3 +318,17 @@ def test_co2r_physical_example_matches_the_oracle_along_the_polarization_curve()
         assert np.abs(np.array(d['system']['potential']) - phi).max() < 1e-7
     j = calc.kinetic_flux[:, names.index('CO')]
     assert j[0] > 0 and j[1] > 5 * j[0]           # Tafel region, then the CO2-transport plateau
+
+
+def test_run_single_step_updates_tp_like_the_comsol_reader():
+    tp = _physical_transport([-0.4, -0.8], mpb=False)
+    tp.system['phiM'] = -0.7
+    tp.species['CO2']['flux'] = -2e-5
+    tp.species['CO']['flux'] = 2e-5
+    calc = Calculator(transport=tp, calc='comsol')
+    assert calc.run_single_step(label='it1')
+    L = (tp.nx - 1) * tp.dx
+    assert np.isclose(tp.species['CO']['surface_concentration'], 2e-5 * L / tp.D[3], rtol=1e-6)       # neutral product: linear profile
+    assert len(tp.species['K+']['concentration']) == tp.nx and tp.species['K+']['surface_concentration'] > 100.0
+    assert tp.system['surface_potential'] < 0 and len(tp.system['potential']) == tp.nx and 'activity_coefficient' in tp.system
+    assert list(tp.descriptors['phiM']) == [-0.4, -0.8] and len(tp.alldata) == 2                          # the sweep set-up is untouched
