@@ -1662,7 +1662,7 @@ static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t 
   const char* force = getenv("CATINT_NEWTON_KERNEL");     // "generic" forces the row-per-thread kernel (tests)
   const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
   if constexpr (NB >= 3) {     // lane teams: every large block, and the N = 2..4 grids too long for the pair kernel
-    if (a.work && !(force && force[0] == 'g') && (NB >= 6 || tp == 0)) return launch_team<NB>(a, blocks, stream);
+    if (a.work && !(force && force[0] == 'g') && (NB >= 6 || tp == 0 || (force && force[0] == 't'))) return launch_team<NB>(a, blocks, stream);
   }
   if constexpr (NB <= 5) {
     if (tp > 0) {
