@@ -309,6 +309,38 @@ __device__ __forceinline__ void cr_backsub_row(double* buf, int RS, int row, int
   for (int r = 0; r < NB; ++r) p[(size_t)r * RS] = x[r];
 }
 
+// exp(u) - 1 for |u| >= 0.05 (smaller arguments take the Taylor branch of the caller), all constants in scalar registers.
+// The library expm1 keeps its ~10 polynomial coefficients in vector registers hoisted out of the Newton loop; in the
+// 128-register kernels they were spilled and re-read from scratch -- one dependent memory round trip per Horner step.
+// u = k ln2 + r, |r| <= ln2/2;  e^r - 1 by a degree-13 Taylor polynomial (remainder < 4e-18);  e^u - 1 = 2^k (e^r - 1) + (2^k - 1).
+__device__ __forceinline__ double expm1_sc(double u) {
+  double l2e = 1.4426950408889634, ln2h = 6.93147180369123816490e-01, ln2l = 1.90821492927058770002e-10;
+  double c2 = 1.0 / 2, c3 = 1.0 / 6, c4 = 1.0 / 24, c5 = 1.0 / 120, c6 = 1.0 / 720, c7 = 1.0 / 5040, c8 = 1.0 / 40320,
+         c9 = 1.0 / 362880, c10 = 1.0 / 3628800, c11 = 1.0 / 39916800, c12 = 1.0 / 479001600, c13 = 1.0 / 6227020800.0;
+  asm volatile("" : "+s"(l2e), "+s"(ln2h), "+s"(ln2l), "+s"(c2), "+s"(c3), "+s"(c4), "+s"(c5), "+s"(c6), "+s"(c7), "+s"(c8),
+               "+s"(c9), "+s"(c10), "+s"(c11), "+s"(c12), "+s"(c13));
+  const double uc = fmin(fmax(u, -60.0), 709.0);           // e^-60 - 1 == -1 in double; beyond 709 the result is inf anyway
+  const double kf = __builtin_rint(uc * l2e);
+  const double r = __builtin_fma(-kf, ln2l, __builtin_fma(-kf, ln2h, uc));
+  double p = c13;
+  p = __builtin_fma(p, r, c12);
+  p = __builtin_fma(p, r, c11);
+  p = __builtin_fma(p, r, c10);
+  p = __builtin_fma(p, r, c9);
+  p = __builtin_fma(p, r, c8);
+  p = __builtin_fma(p, r, c7);
+  p = __builtin_fma(p, r, c6);
+  p = __builtin_fma(p, r, c5);
+  p = __builtin_fma(p, r, c4);
+  p = __builtin_fma(p, r, c3);
+  p = __builtin_fma(p, r, c2);
+  p = __builtin_fma(p * r, r, r);                             // e^r - 1
+  const int k = (int)kf;
+  const double t = __builtin_ldexp(1.0, k);
+  const double res = __builtin_fma(t, p, t - 1.0);
+  return u > 709.0 ? INFINITY : res;
+}
+
 // Scharfetter-Gummel flux of one species across one edge (left point l, right point r), scaled by dx/D:
 //   J = -(B(-u) c_r - B(u) c_l),  u = psi_r - psi_l;   Ju = dJ/du;   dJ/dc_l = Bp, dJ/dc_r = -Bm
 struct Edge {
@@ -318,11 +350,15 @@ struct Edge {
 __device__ __forceinline__ Edge edge_flux(double u, double cl, double cr, double w) {   // w = dx/h_e (1 on a uniform grid)
   double B, dB;
   if (fabs(u) < 0.05) {   // oracle/pnp_physical.py: bernoulli, SERIES_U
+    // the six series coefficients are materialised in scalar registers right here: left to the compiler they are hoisted out
+    // of the Newton loop as vector registers and -- in the 128-register kernels -- spilled to scratch and reloaded per call
+    double k12 = 1.0 / 12.0, k720 = -1.0 / 720.0, k30240 = 1.0 / 30240.0, k6 = 1.0 / 6.0, k180 = -1.0 / 180.0, k5040 = 1.0 / 5040.0;
+    asm volatile("" : "+s"(k12), "+s"(k720), "+s"(k30240), "+s"(k6), "+s"(k180), "+s"(k5040));
     const double u2 = u * u;
-    B = 1.0 - 0.5 * u + u2 * (1.0 / 12.0 + u2 * (-1.0 / 720.0 + u2 * (1.0 / 30240.0)));
-    dB = -0.5 + u * (1.0 / 6.0 + u2 * (-1.0 / 180.0 + u2 * (1.0 / 5040.0)));
+    B = 1.0 - 0.5 * u + u2 * (k12 + u2 * (k720 + u2 * k30240));
+    dB = -0.5 + u * (k6 + u2 * (k180 + u2 * k5040));
   } else {
-    const double rE = nrcp(expm1(u));
+    const double rE = nrcp(expm1_sc(u));
     B = u * rE;
     dB = (1.0 - B - u) * rE;
   }
@@ -1200,7 +1236,9 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
           // which are read from the parameter copy in LDS) is recomputed per pass instead of being kept in -- spilled --
           // registers across the whole Newton loop (see newton_pair_kernel)
           int r = r0_, team = team0_;
-          asm volatile("" : "+v"(r), "+v"(team));
+          const NewtonArgs* Ap = &sA;            // ... and so is the pointer to the parameter copy: its loads stay inside the pass
+          asm volatile("" : "+v"(r), "+v"(team), "+v"(Ap));
+          const NewtonArgs& A = *Ap;
           const int rs_ = spec ? r : 0;
           const double qb_r = A.qb[rs_], sig_r = A.sig[rs_], fl_r = A.fl[rs_], peq_r = A.peq[rs_], vol_r = A.vol[rs_], rs_r = A.rs[rs_];
           const double flux_r = G.flux[(size_t)b * N + rs_], cb_r = cb[rs_];
