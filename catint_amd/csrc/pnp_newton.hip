@@ -20,16 +20,9 @@
 #include <cstdlib>
 
 #include "pnp_internal.h"
+#include "pnp_math.h"
 
 namespace pnp {
-
-__device__ __forceinline__ double nrcp(double x) {   // v_rcp_f64 + two Newton steps (1.1e-16 relative)
-  double r = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-x, r, 1.0);
-  return __builtin_fma(r, e, r);
-}
 
 // X <- M^-1 X for a dense NB x NB block M and NC right-hand-side columns, Gauss-Jordan in registers.
 // PIVOT: partial (row) pivoting, used for the raw Jacobian blocks; the PCR levels work on I - (small products)
@@ -309,38 +302,6 @@ __device__ __forceinline__ void cr_backsub_row(double* buf, int RS, int row, int
   for (int r = 0; r < NB; ++r) p[(size_t)r * RS] = x[r];
 }
 
-// exp(u) - 1 for |u| >= 0.05 (smaller arguments take the Taylor branch of the caller), all constants in scalar registers.
-// The library expm1 keeps its ~10 polynomial coefficients in vector registers hoisted out of the Newton loop; in the
-// 128-register kernels they were spilled and re-read from scratch -- one dependent memory round trip per Horner step.
-// u = k ln2 + r, |r| <= ln2/2;  e^r - 1 by a degree-13 Taylor polynomial (remainder < 4e-18);  e^u - 1 = 2^k (e^r - 1) + (2^k - 1).
-__device__ __forceinline__ double expm1_sc(double u) {
-  double l2e = 1.4426950408889634, ln2h = 6.93147180369123816490e-01, ln2l = 1.90821492927058770002e-10;
-  double c2 = 1.0 / 2, c3 = 1.0 / 6, c4 = 1.0 / 24, c5 = 1.0 / 120, c6 = 1.0 / 720, c7 = 1.0 / 5040, c8 = 1.0 / 40320,
-         c9 = 1.0 / 362880, c10 = 1.0 / 3628800, c11 = 1.0 / 39916800, c12 = 1.0 / 479001600, c13 = 1.0 / 6227020800.0;
-  asm volatile("" : "+s"(l2e), "+s"(ln2h), "+s"(ln2l), "+s"(c2), "+s"(c3), "+s"(c4), "+s"(c5), "+s"(c6), "+s"(c7), "+s"(c8),
-               "+s"(c9), "+s"(c10), "+s"(c11), "+s"(c12), "+s"(c13));
-  const double uc = fmin(fmax(u, -60.0), 709.0);           // e^-60 - 1 == -1 in double; beyond 709 the result is inf anyway
-  const double kf = __builtin_rint(uc * l2e);
-  const double r = __builtin_fma(-kf, ln2l, __builtin_fma(-kf, ln2h, uc));
-  double p = c13;
-  p = __builtin_fma(p, r, c12);
-  p = __builtin_fma(p, r, c11);
-  p = __builtin_fma(p, r, c10);
-  p = __builtin_fma(p, r, c9);
-  p = __builtin_fma(p, r, c8);
-  p = __builtin_fma(p, r, c7);
-  p = __builtin_fma(p, r, c6);
-  p = __builtin_fma(p, r, c5);
-  p = __builtin_fma(p, r, c4);
-  p = __builtin_fma(p, r, c3);
-  p = __builtin_fma(p, r, c2);
-  p = __builtin_fma(p * r, r, r);                             // e^r - 1
-  const int k = (int)kf;
-  const double t = __builtin_ldexp(1.0, k);
-  const double res = __builtin_fma(t, p, t - 1.0);
-  return u > 709.0 ? INFINITY : res;
-}
-
 // Scharfetter-Gummel flux of one species across one edge (left point l, right point r), scaled by dx/D:
 //   J = -(B(-u) c_r - B(u) c_l),  u = psi_r - psi_l;   Ju = dJ/du;   dJ/dc_l = Bp, dJ/dc_r = -Bm
 struct Edge {
@@ -390,7 +351,7 @@ __device__ __forceinline__ Point<N, MODE> load_point(const NewtonArgs& A, const 
     double f = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) f = __builtin_fma(A.vol[k], P.c[k], f);
-    P.w = -log1p(-f);
+    P.w = -log1p_sc(-f);
     const double inv = 1.0 / (1.0 - f);
     P.gam = inv;
 #pragma unroll
@@ -1267,9 +1228,9 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
           const double rho = team_sum(spec ? peq_r * c0 : 0.0);
           double wm_ = 0.0, w0_ = 0.0, wp_ = 0.0, invm = 1.0, inv0 = 1.0, invp = 1.0;
           if constexpr (MPB) {
-            wm_ = -log1p(-fm);
-            w0_ = -log1p(-f0);
-            wp_ = -log1p(-fp);
+            wm_ = -log1p_sc(-fm);
+            w0_ = -log1p_sc(-f0);
+            wp_ = -log1p_sc(-fp);
             invm = 1.0 / (1.0 - fm);
             inv0 = 1.0 / (1.0 - f0);
             invp = 1.0 / (1.0 - fp);
