@@ -25,8 +25,11 @@
 namespace pnp {
 
 // X <- M^-1 X for a dense NB x NB block M and NC right-hand-side columns, Gauss-Jordan in registers.
-// PIVOT: partial (row) pivoting, used for the raw Jacobian blocks; the PCR levels work on I - (small products)
-// and run without.
+// PIVOT: partial (row) pivoting, used for the raw Jacobian blocks when steric coupling or reactions fill the species block;
+// the PCR levels work on I - (small products) and run without.  Point ions without reactions need none either: a species
+// row has a positive diagonal (sigma + B(u) + B(-u') > 0) and couples only to the potential column, so eliminating the
+// species columns first only makes the Poisson pivot more negative (-2 - sum_k (dx^2/eps) q_k^2 beta |dJ/du| / M_kk) --
+// no cancellation, no growth; the pair-reduced row is a Schur complement of the same structure.
 template <int NB, int NC, bool PIVOT>
 __device__ __forceinline__ void block_solve(double (&M)[NB][NB], double (&X)[NB][NC]) {
 #pragma unroll
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
         for (int row = tid; row < nx; row += T) {
           double M[NB][NB], X[NB][2 * NB + 1];
           assemble_row<NB, MODE>(A, c, co, phi, flux, wk, cb, phiM, phiB, row, M, X);
-          block_solve<NB, 2 * NB + 1, true>(M, X);
+          block_solve<NB, 2 * NB + 1, (MODE != 0)>(M, X);      // point ions without reactions: pivot-free, see block_solve
           store_row<NB>(buf0, RS, row, X);
         }
         __syncthreads();
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
           edge_fluxes<N, MODE>(A, P1, P2, w1, e1);
           if (ra < nx) {
             fill_row<NB, MODE>(A, c, co, flux, wk, cb, phiM, phiB, ra, P0, P1, P2, e0, e1, w0, w1, G.gv[i1], Ma, Xa);
-            block_solve<NB, NC, true>(Ma, Xa);
+            block_solve<NB, NC, (MODE != 0)>(Ma, Xa);
           } else {
 #pragma unroll
             for (int r = 0; r < NB; ++r)
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
 #pragma unroll
               for (int j = 0; j < NB; ++j) Xb[r][2 * NB] = __builtin_fma(-Ub[r][j], qv[j], Xb[r][2 * NB]);
           }
-          block_solve<NB, NC, true>(Mb, Xb);
+          block_solve<NB, NC, (MODE != 0)>(Mb, Xb);
         }
         // ---- PCR over the T reduced rows, own row in registers
         for (int s = 1; s < T; s <<= 1) {
@@ -1348,7 +1351,7 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
             }
           }
           int myk;
-          team_solve<NB, true>(Dr, Xr, strip, r, myk);
+          team_solve<NB, (MODE != 0)>(Dr, Xr, strip, r, myk);
           if (valid) {
             double* o = REC(i, myk);
 #pragma unroll
