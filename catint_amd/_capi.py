@@ -33,7 +33,7 @@ SYMBOLS = [
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
-    'pnp_set_potential', 'pnp_set_wall_kinetics', 'pnp_set_grid', 'pnp_solve_surface',
+    'pnp_set_potential', 'pnp_set_wall_kinetics', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
 ]
 
 
@@ -61,6 +61,20 @@ class PnpNewtonParams(C.Structure):
         ('struct_size', C.c_int32), ('wall_bc', C.c_int32), ('maxit', C.c_int32), ('error_estimate', C.c_int32),
         ('stern_capacitance', C.c_double), ('phi_pzc', C.c_double), ('tol', C.c_double), ('dphi_max', C.c_double),
     ]
+
+
+class PnpScfParams(C.Structure):
+    _fields_ = [
+        ('struct_size', C.c_int32), ('istep', C.c_int32), ('max_iter', C.c_int32), ('check_every', C.c_int32),
+        ('species_H', C.c_int32), ('species_OH', C.c_int32), ('tau_scf', C.c_double), ('faraday', C.c_double),
+    ]
+
+
+class PnpScfState(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in (
+        'surface_concentration', 'surface_concentration_old', 'flux', 'current_density_old', 'mix', 'accuracy',
+        'surface_pH', 'surface_potential', 'surface_efield')] + [(n, C.POINTER(C.c_int32)) for n in (
+            'step_to_check', 'active', 'failed')]
 
 
 _lib = None
@@ -111,6 +125,8 @@ def load_library():
     lib.pnp_set_grid.restype = C.c_int
     lib.pnp_solve_surface.argtypes = [vp, dp, C.c_int32, dp, dp, dp, ip]
     lib.pnp_solve_surface.restype = C.c_int
+    lib.pnp_scf_cycle.argtypes = [vp, C.POINTER(PnpScfParams), dp, dp, C.POINTER(PnpScfState), ip]
+    lib.pnp_scf_cycle.restype = C.c_int
     for name in ('pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations', 'pnp_set_potential'):
         getattr(lib, name).restype = C.c_int
     for name in ('pnp_set_species', 'pnp_set_reactions', 'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step',
@@ -255,6 +271,31 @@ class PnpSolver(object):
         f = None if flux is None else _f64(flux, (self.B, self.N))
         self._check(self._lib.pnp_solve_surface(self._h, _dptr(f), int(nsteps), _dptr(cs), _dptr(vs), _dptr(es), _iptr(st)))
         return cs, vs, es, st
+
+    def scf_cycle(self, state, istep, max_iter, tau_scf, faraday, nel=None, nprod=None, species_H=-1, species_OH=-1,
+                  check_every=8):
+        """Device SCF loop (pnp_scf_cycle) from iteration istep+1 on.  `state`: dict of the loop arrays
+        ('surface_concentration', 'surface_concentration_old', 'flux', 'current_density_old' [B][N]; 'mix', 'accuracy',
+        'surface_pH', 'surface_potential', 'surface_efield' [B]; 'step_to_check', 'active', 'failed' [B] int) -- updated in
+        place (fresh contiguous arrays are put back into the dict).  Returns the last iteration number that had active lanes."""
+        B, N = self.B, self.N
+        st = PnpScfState()
+        for name, ctype in PnpScfState._fields_:
+            if ctype == C.POINTER(C.c_double):
+                shape = (B, N) if name in ('surface_concentration', 'surface_concentration_old', 'flux', 'current_density_old') else (B,)
+                arr = np.array(_f64(state[name], shape))
+                setattr(st, name, _dptr(arr))
+            else:
+                arr = np.ascontiguousarray(np.asarray(state[name]).reshape(B), dtype=np.int32).copy()
+                setattr(st, name, _iptr(arr))
+            state[name] = arr
+        p = PnpScfParams(struct_size=C.sizeof(PnpScfParams), istep=int(istep), max_iter=int(max_iter), check_every=int(check_every),
+                         species_H=int(species_H), species_OH=int(species_OH), tau_scf=float(tau_scf), faraday=float(faraday))
+        nel = None if nel is None else _f64(nel, (N,))
+        nprod = None if nprod is None else _f64(nprod, (N,))
+        it = C.c_int32(0)
+        self._check(self._lib.pnp_scf_cycle(self._h, C.byref(p), _dptr(nel), _dptr(nprod), C.byref(st), C.byref(it)))
+        return int(it.value)
 
     def newton_iterations(self):
         it = np.zeros(self.B, np.int32)

@@ -243,13 +243,16 @@ class Calculator(object):
                       for r in rx], axis=1)
         solver.set_wall_kinetics(species, nu, k)
 
-    def surface_kinetic_fluxes(self, csurf, phiM):
-        """Flux [B][N] into the electrolyte implied by set_surface_kinetics at the surface state csurf [B][N]."""
+    def surface_kinetic_fluxes(self, csurf, phiM, clip=False, reactions=None):
+        """Flux [B][N] into the electrolyte implied by set_surface_kinetics at the surface state csurf [B][N]
+        (clip: negative surface concentrations count as zero, as in the explicit SCF loop)."""
         names = list(self.tp.species.keys())
         out = np.zeros_like(csurf)
-        for r in getattr(self, 'surface_kinetics', []):
+        for r in (reactions if reactions is not None else getattr(self, 'surface_kinetics', None)) or []:
             K = np.broadcast_to(np.asarray(r['rate'](phiM) if callable(r['rate']) else r['rate'], float), phiM.shape)
             cs = csurf[:, names.index(r['species'])] if r.get('species') is not None else 1.0
+            if clip and r.get('species') is not None:
+                cs = np.maximum(cs, 0.0)
             for sp, v in r['stoichiometry'].items():
                 out[:, names.index(sp)] += v * K * cs
         return out
@@ -444,7 +447,7 @@ class Calculator(object):
             phiM[i] = system['phiM']
         return pb, vz, phiM
 
-    def run_scf_cycle(self, flux_callback, nel=None, nprod=None, max_iter=1000, transport_fn=None):
+    def run_scf_cycle(self, flux_callback=None, nel=None, nprod=None, max_iter=1000, transport_fn=None):
         """Batched counterpart of the reference's SCF outer loop (catint/calculator.py:294-406): kinetics
         (`flux_callback`, the seam where CatMAP sat, catmap_wrapper.py:106) <-> transport, once per iteration, for
         every descriptor point at the same time.  Each lane carries its own mixing factor, iteration bookkeeping
@@ -455,8 +458,21 @@ class Calculator(object):
         state = {'surface_concentration' [B][N], 'surface_pH' [B], 'phiM' [B], 'surface_potential' [B],
                  'surface_efield' [B], 'istep'}.
         transport_fn(flux) -> (csurf [B][N], vsurf [B], esurf [B]) replaces the GPU solve (host-logic tests).
+        flux_callback=None (physical mode, stationary): the kinetic model is the analytic table of set_surface_kinetics,
+        evaluated EXPLICITLY from the mixed surface concentrations, and the loop runs on the device from its second
+        iteration on (pnp_scf_cycle: no host round trip per iteration, converged lanes leave the batch).
+        Same iterates as this host loop with surface_kinetic_fluxes(clip=True) as the callback; the hand-over happens after the
+        first iteration (>= 2) in which every transport solve converged, and a lane whose solve fails later goes back to the
+        state of its last converged solve instead of triggering a whole-batch restart from the bulk state.
         Returns a dict with the per-lane results and bookkeeping."""
         tp = self.tp
+        device_loop = flux_callback is None
+        kinetics = getattr(self, 'surface_kinetics', None)
+        if device_loop:
+            if not (self.physical and self.mode == 'stationary' and kinetics and transport_fn is None):
+                raise CalculatorError('run_scf_cycle without a callback needs the physical mode (stationary) and set_surface_kinetics')
+            flux_callback = lambda state: self.surface_kinetic_fluxes(state['surface_concentration'], state['phiM'], clip=True,  # noqa: E731
+                                                                      reactions=kinetics)
         names = list(tp.species.keys())
         N = tp.nspecies
         pb, vz, phiM = self._lane_inputs()
@@ -483,6 +499,8 @@ class Calculator(object):
         history = []
         restart = False
         try:
+            if device_loop:
+                self.surface_kinetics = None      # explicit coupling: the transport solves see prescribed fluxes only
             while active.any() and istep < max_iter:       # :316
                 istep += 1
                 dec = active & (istep - step_to_check > 40)                                  # :319-323
@@ -542,7 +560,27 @@ class Calculator(object):
                 bad = active & (~np.isfinite(cs).all(axis=1) | (status == 2))
                 failed |= bad
                 active = active & ~bad & ((acc > self.tau_scf) | (sc < 0.0).any(axis=1))
+                if device_loop and active.any() and istep < max_iter and istep >= 2 and not restart:
+                    # hand the loop state over; the table with the rate constants at the full potentials is the kinetic model
+                    self.surface_kinetics = kinetics
+                    self._apply_surface_kinetics(solver, phiM)
+                    st = {'surface_concentration': sc, 'surface_concentration_old': sc_old, 'flux': flux,
+                          'current_density_old': cd_old, 'mix': mix, 'accuracy': acc, 'surface_pH': surface_pH,
+                          'surface_potential': vsurf, 'surface_efield': esurf, 'step_to_check': step_to_check,
+                          'active': active.astype(np.int32), 'failed': failed.astype(np.int32)}
+                    istep = solver.scf_cycle(st, istep, max_iter, self.tau_scf, unit_F, nel, nprod,
+                                             species_H=-1 if iH is None else iH, species_OH=-1 if iOH is None else iOH)
+                    sc, sc_old, flux, cd_old = (st[k] for k in ('surface_concentration', 'surface_concentration_old', 'flux',
+                                                                'current_density_old'))
+                    mix, acc, surface_pH, vsurf, esurf = (st[k] for k in ('mix', 'accuracy', 'surface_pH', 'surface_potential',
+                                                                          'surface_efield'))
+                    step_to_check = st['step_to_check']
+                    active = st['active'] != 0
+                    failed = st['failed'] != 0
+                    break
         finally:
+            if device_loop:
+                self.surface_kinetics = kinetics
             if solver is not None:
                 solver.close()
         for i in range(B):

@@ -52,6 +52,13 @@ struct pnp_handle {
   int64_t work_stride = 0;
   int32_t* iters = nullptr;
   int nw_blocks = 0;
+  // device SCF loop (pnp_scf_cycle): per-lane bookkeeping, allocated on first use; the two switches below are set around
+  // its transport solves
+  double* scf_d = nullptr;               // (4N + 5) B doubles
+  double* scf_snap = nullptr;            // (N + 1) ldx B doubles: per-lane state of the last converged transport solve
+  int32_t* scf_i = nullptr;              // 3 B flags + 65 counters
+  const int32_t* newton_mask = nullptr;  // lanes to solve (null: all)
+  bool newton_explicit_kinetics = false; // the wall-kinetics table feeds the prescribed fluxes instead of the Jacobian
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
   int64_t dev_bytes = 0;
   std::string err;
@@ -92,7 +99,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -469,7 +476,8 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   }
   a.vt_inv = beta * qmax;
   a.rt = (h->rt_dev && h->rt.n > 0) ? h->rt_dev : nullptr;
-  a.n_wk = h->n_wk;
+  a.n_wk = h->newton_explicit_kinetics ? 0 : h->n_wk;
+  a.lane_mask = h->newton_mask;
   memcpy(a.wk_species, h->wk_species, sizeof(a.wk_species));
   memcpy(a.wk_nu, h->wk_nu, sizeof(a.wk_nu));
   a.wk_k = h->wk_k;
@@ -599,6 +607,129 @@ int pnp_solve_surface(pnp_handle* h, const double* flux, int32_t nsteps, double*
     if (vsurf) vsurf[b] = p01[2 * b];
     if (esurf) esurf[b] = -(p01[2 * b + 1] - p01[2 * b]) / (h->xgrid[1] - h->xgrid[0]);
   }
+  return PNP_OK;
+}
+
+int pnp_scf_cycle(pnp_handle* h, const pnp_scf_params* p, const double* nel, const double* nprod, pnp_scf_state* s,
+                  int32_t* iterations) {
+  if (!h || !p || !s) return fail(h, PNP_EINVAL, "pnp_scf_cycle: null argument");
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_scf_cycle: the handle was not created with PNP_METHOD_NEWTON");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_scf_cycle: call pnp_set_batch first");
+  if (p->struct_size != (int32_t)sizeof(pnp_scf_params)) return fail(h, PNP_EINVAL, "pnp_scf_cycle: struct_size mismatch (ABI)");
+  if (h->n_wk < 1) return fail(h, PNP_ESTATE, "pnp_scf_cycle: no kinetic model (pnp_set_wall_kinetics)");
+  if (p->istep < 1) return fail(h, PNP_EINVAL, "pnp_scf_cycle: the first iteration (transport solve from the bulk state) is the caller's");
+  const int N = h->a.N;
+  if (p->species_H >= N || p->species_OH >= N) return fail(h, PNP_EINVAL, "pnp_scf_cycle: pH species index out of range");
+  if (!s->surface_concentration || !s->surface_concentration_old || !s->flux || !s->current_density_old || !s->mix ||
+      !s->accuracy || !s->surface_pH || !s->surface_potential || !s->surface_efield || !s->step_to_check || !s->active || !s->failed)
+    return fail(h, PNP_EINVAL, "pnp_scf_cycle: null array in pnp_scf_state");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int64_t B = h->B, cap = h->cfg.batch_capacity;
+  if (!h->scf_d) {
+    HIP_TRY(h, dev_alloc(h, &h->scf_d, (size_t)cap * (4 * N + 5)));
+    HIP_TRY(h, dev_alloc(h, &h->scf_i, (size_t)cap * 3 + 65));
+    HIP_TRY(h, dev_alloc(h, &h->scf_snap, (size_t)cap * (N + 1) * h->a.ldx));
+  }
+  ScfArgs a;
+  memset(&a, 0, sizeof(a));
+  a.N = N;
+  a.n_wk = h->n_wk;
+  a.iH = p->species_H;
+  a.iOH = p->species_OH;
+  a.ldx = h->a.ldx;
+  a.B = B;
+  a.tau = p->tau_scf;
+  a.h0 = h->xgrid[1] - h->xgrid[0];
+  a.faraday = p->faraday;
+  memcpy(a.wk_species, h->wk_species, sizeof(a.wk_species));
+  memcpy(a.wk_nu, h->wk_nu, sizeof(a.wk_nu));
+  for (int k = 0; k < N; ++k) {
+    a.nel[k] = nel ? nel[k] : 1.0;
+    a.nprod[k] = nprod ? nprod[k] : 1.0;
+  }
+  a.wk_k = h->wk_k;
+  double* d = h->scf_d;
+  a.sc = d;
+  a.sc_old = d + (size_t)cap * N;
+  a.flux = h->flux;                       // the transport solve reads its wall fluxes here
+  a.cd_old = d + (size_t)cap * 2 * N;
+  double* scal = d + (size_t)cap * 3 * N;  // (one [B][N] block spare)
+  scal += (size_t)cap * N;
+  a.mix = scal;
+  a.acc = scal + cap;
+  a.surface_pH = scal + 2 * cap;
+  a.vsurf = scal + 3 * cap;
+  a.esurf = scal + 4 * cap;
+  a.step_to_check = h->scf_i;
+  a.active = h->scf_i + cap;
+  a.failed = h->scf_i + 2 * cap;
+  a.counters = h->scf_i + 3 * cap;
+  a.c = h->c;
+  a.phi = h->v;
+  a.snap_c = h->scf_snap;
+  a.snap_phi = h->scf_snap + (size_t)cap * N * h->a.ldx;
+  a.status = h->status;
+  const size_t bn = (size_t)B * N * sizeof(double), bd = (size_t)B * sizeof(double), bi = (size_t)B * sizeof(int32_t);
+  hipStream_t st = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(a.sc, s->surface_concentration, bn, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.sc_old, s->surface_concentration_old, bn, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.flux, s->flux, bn, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.cd_old, s->current_density_old, bn, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.mix, s->mix, bd, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.acc, s->accuracy, bd, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.surface_pH, s->surface_pH, bd, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.vsurf, s->surface_potential, bd, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.esurf, s->surface_efield, bd, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.step_to_check, s->step_to_check, bi, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.active, s->active, bi, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.failed, s->failed, bi, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemsetAsync(a.counters, 0, 65 * sizeof(int32_t), st));
+  HIP_TRY(h, hipMemcpyAsync(a.snap_c, a.c, (size_t)B * N * h->a.ldx * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(a.snap_phi, a.phi, (size_t)B * h->a.ldx * sizeof(double), hipMemcpyDeviceToDevice, st));
+  const int every = p->check_every > 0 ? (p->check_every < 32 ? p->check_every : 32) : 8;
+  int rc = PNP_OK;
+  int32_t left = 1;
+  h->newton_mask = a.active;
+  h->newton_explicit_kinetics = true;
+  for (int istep = p->istep + 1; istep <= p->max_iter && rc == PNP_OK; ++istep) {
+    a.istep = istep;
+    a.slot = istep & 63;
+    hipError_t e = hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st);
+    if (e == hipSuccess) e = launch_scf_pre(a, st);
+    if (e != hipSuccess) {
+      rc = fail(h, PNP_EDEVICE, std::string("pnp_scf_cycle: ") + hipGetErrorString(e));
+      break;
+    }
+    rc = run_newton(h, 1, true, 0.0, 0);       // stationary, warm: the state of the previous iteration (restart=True, calculator.py:523)
+    if (rc != PNP_OK) break;
+    e = launch_scf_keep(a, st);
+    if (e == hipSuccess) e = launch_scf_post(a, st);
+    if (e == hipSuccess && ((istep - p->istep) % every == 0 || istep == p->max_iter)) {
+      e = hipMemcpyAsync(&left, a.counters + a.slot, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e == hipSuccess && left == 0) break;
+    }
+    if (e != hipSuccess) rc = fail(h, PNP_EDEVICE, std::string("pnp_scf_cycle: ") + hipGetErrorString(e));
+  }
+  h->newton_mask = nullptr;
+  h->newton_explicit_kinetics = false;
+  if (rc != PNP_OK) return rc;
+  int32_t last = 0;
+  HIP_TRY(h, hipMemcpyAsync(s->surface_concentration, a.sc, bn, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->surface_concentration_old, a.sc_old, bn, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->flux, a.flux, bn, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->current_density_old, a.cd_old, bn, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->mix, a.mix, bd, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->accuracy, a.acc, bd, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->surface_pH, a.surface_pH, bd, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->surface_potential, a.vsurf, bd, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->surface_efield, a.esurf, bd, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->step_to_check, a.step_to_check, bi, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->active, a.active, bi, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(s->failed, a.failed, bi, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(&last, a.counters + 64, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));
+  if (iterations) *iterations = last > p->istep ? last : p->istep;
   return PNP_OK;
 }
 

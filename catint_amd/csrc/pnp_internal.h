@@ -132,6 +132,7 @@ struct NewtonArgs {
   int64_t stash_stride;
   int32_t* status;                       // [B]
   int32_t* iters;                        // [B] Newton iterations spent by this call (maxit+1 for a failed solve)
+  const int32_t* lane_mask;              // [B] or null: lanes with a zero are left untouched (frozen lanes of the SCF loop)
 };
 int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);
@@ -140,5 +141,29 @@ bool newton_exchange_in_lds(int nb, int nx);
 int newton_pair_threads(int nb, int nx);   // threads of the pair kernel, 0 if the shape does not fit it
 int newton_pair_stride(int nb, int nx);    // its compile-time row stride (256 or 512)
 hipError_t launch_newton(const NewtonArgs& a, int blocks, hipStream_t stream);
+
+// ---- kinetics <-> transport SCF loop on the device (pnp_scf.hip; Calculator.run_scf_cycle, calculator.py:294-406) ----
+struct ScfArgs {
+  int32_t N, n_wk, iH, iOH;
+  int32_t istep, ldx, slot, pad_;
+  int64_t B;
+  double tau, h0, faraday;               // convergence threshold tau_scf; first cell x[1]-x[0]; unit_F of the caller
+  int32_t wk_species[PNP_MAX_WALL_REACTIONS];
+  double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES];
+  double nel[PNP_NEWTON_MAX_SPECIES], nprod[PNP_NEWTON_MAX_SPECIES];
+  const double* wk_k;                    // [B][PNP_MAX_WALL_REACTIONS]
+  double *sc, *sc_old, *flux, *cd_old;   // [B][N]
+  double *mix, *acc, *surface_pH, *vsurf, *esurf;      // [B]
+  int32_t *step_to_check, *active, *failed;            // [B]
+  double* c;                             // [B][N][ldx] transport state
+  double* phi;                           // [B][ldx]
+  double* snap_c;                        // the state each lane's last CONVERGED transport solve left behind ...
+  double* snap_phi;                      // ... restored when a solve fails
+  const int32_t* status;                 // [B] of the transport solve
+  int32_t* counters;                     // [0..63] active lanes after iteration (slot = istep & 63), [64] last iteration with work
+};
+hipError_t launch_scf_pre(const ScfArgs& a, hipStream_t stream);     // mixing, fallback, pH, new wall fluxes
+hipError_t launch_scf_keep(const ScfArgs& a, hipStream_t stream);    // converged lanes: state -> snapshot; failed lanes: snapshot -> state
+hipError_t launch_scf_post(const ScfArgs& a, hipStream_t stream);    // surface state, accuracy, convergence flags
 
 }  // namespace pnp

@@ -570,6 +570,7 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
   if constexpr (NB >= 5) buf0 = A.work + (size_t)blockIdx.x * A.work_stride;
   else buf0 = A.work ? A.work + (size_t)blockIdx.x * A.work_stride : newton_lds;
   for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+    if (A.lane_mask && !A.lane_mask[b]) continue;       // frozen lane (block-uniform: no thread reaches a barrier)
     double* c = A.c + (size_t)b * N * ldx;
     double* co = A.c_old + (size_t)b * N * ldx;
     double* phi = A.phi + (size_t)b * ldx;
@@ -775,6 +776,7 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
   // (row indices ra, rb are re-derived from an opaque copy of tid inside the Newton loop, see there)
   double* stash = G.stash + (size_t)blockIdx.x * G.stash_stride;
   for (int64_t b = blockIdx.x; b < G.B; b += gridDim.x) {
+    if (G.lane_mask && !G.lane_mask[b]) continue;       // frozen lane (block-uniform: no thread reaches a barrier)
     double* c = G.c + (size_t)b * N * ldx;
     double* co = G.c_old + (size_t)b * N * ldx;
     double* phi = G.phi + (size_t)b * ldx;
@@ -1178,6 +1180,7 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
   const bool spec = r0_ < N;
   const int rs0_ = spec ? r0_ : 0;                // clamped species index for loads
   for (int64_t b = blockIdx.x; b < G.B; b += gridDim.x) {
+    if (G.lane_mask && !G.lane_mask[b]) continue;       // frozen lane (block-uniform: no thread reaches a barrier)
     double* c = G.c + (size_t)b * N * ldx;
     double* co = G.c_old + (size_t)b * N * ldx;
     double* phi = G.phi + (size_t)b * ldx;

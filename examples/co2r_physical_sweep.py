@@ -64,7 +64,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--lanes', type=int, default=256)
     ap.add_argument('--nx', type=int, default=384)
-    ap.add_argument('--scf', action='store_true', help='also run the SCF outer loop (kinetics callback) for comparison')
+    ap.add_argument('--scf', action='store_true', help='also run the SCF outer loop (kinetics callback on the host) for comparison')
+    ap.add_argument('--scf-device', action='store_true', help='also run the SCF outer loop on the device (pnp_scf_cycle)')
     a = ap.parse_args()
     tp, phis = build(a.lanes, a.nx)
     rate = tafel_rate(tp)
@@ -90,6 +91,17 @@ def main():
         print('%7.3f   %12.5f   %8.4f   %5.2f   %9.4f   %8.1f' % (phis[i], j[i], d['species']['CO2']['surface_concentration'], ph,
                                                                 d['system']['surface_potential'], d['species']['K+']['surface_concentration']))
     print('diffusion-limited CO2 current without buffer regeneration: %.3f mA/cm2' % jlim)
+    if a.scf_device:
+        tp3, _ = build(a.lanes, a.nx)
+        tp3.newton = tp.newton
+        scf = Calculator(transport=tp3, calc='comsol', tau_scf=0.008, mix_scf=0.02)         # run.py:95
+        scf.set_surface_kinetics(kin)
+        t0 = time.time()
+        out = scf.run_scf_cycle(nel=[1, 2, 1, 2, 1, 1, 1], max_iter=3000)
+        print('SCF loop on the device: %d iterations, %d/%d lanes converged, %.2f s; max |j_scf - j_implicit| / j = %.2e'
+              % (out['iterations'], out['converged'].sum(), a.lanes, time.time() - t0,
+                 np.abs(out['flux'][out['converged'], names.index('CO')] * 2 * unit_F / 10.0 - j[out['converged']]).max()
+                 / max(np.abs(j).max(), 1e-300)))
     if a.scf:
         tp2, _ = build(a.lanes, a.nx)
         tp2.newton = tp.newton

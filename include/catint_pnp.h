@@ -171,6 +171,47 @@ int pnp_solve_stationary(pnp_handle* h, double tol, int32_t maxit, int32_t* stat
  * pnp_get_surface + pnp_get_status.  Any output pointer may be NULL. */
 int pnp_solve_surface(pnp_handle* h, const double* flux, int32_t nsteps, double* csurf, double* vsurf, double* esurf,
                       int32_t* status);
+/* Kinetics <-> transport self-consistency loop of every lane ON THE DEVICE -- the reference's Calculator.run_scf_cycle
+ * (catint/calculator.py:294-406) with the analytic kinetic model of pnp_set_wall_kinetics where CatMAP sat (explicitly:
+ * flux_k = sum_r nu_rk K_r[lane] max(c_s(r)(x=0), 0) from the MIXED surface concentrations, not inside the Jacobian).
+ * Per iteration and lane: mixing factor decay every 40 iterations (:319-323), mixing with the previous iterate and the
+ * negative-concentration fallback (:328-344), surface pH (:346-359), new fluxes (:373), one warm-started stationary
+ * transport solve of the lanes still active (:385, restart=True :523), current densities flux*nel*F/nprod/10 and the signed
+ * relative change evaluate_accuracy (:260-283, :389-402); a lane leaves the loop when accuracy <= tau_scf and no surface
+ * concentration is negative, a lane whose solve did not converge reports -1 (COMSOL's unreachable-flux answer).  No host
+ * round trip per iteration: the host reads one counter every `check_every` iterations.
+ * The caller runs the first iteration(s) (first transport solve, with whatever continuation it needs) and hands over the
+ * loop state together with a CONVERGED transport state on the device: a lane whose later solve fails is put back to the
+ * state of its last converged solve.  All arrays of pnp_scf_state are host arrays, read at entry, written back at exit. */
+typedef struct pnp_scf_params {
+  int32_t struct_size;   /* = sizeof(pnp_scf_params) */
+  int32_t istep;         /* iterations already done (>= 1) */
+  int32_t max_iter;      /* the loop ends after this iteration number at the latest */
+  int32_t check_every;   /* host look-ups of the active-lane counter (1..32, <= 0: 8) */
+  int32_t species_H;     /* index of H+ (surface pH = -log10(c/1000)), or -1 */
+  int32_t species_OH;    /* index of OH- (used when there is no H+: 14 + log10(c/1000)), or -1 */
+  double tau_scf;        /* convergence threshold on the relative current-density change */
+  double faraday;        /* unit_F of the caller (catint/units.py) */
+} pnp_scf_params;
+
+typedef struct pnp_scf_state {
+  double* surface_concentration;       /* [B][N] sc */
+  double* surface_concentration_old;   /* [B][N] sc_old */
+  double* flux;                        /* [B][N] wall fluxes of the last iteration */
+  double* current_density_old;         /* [B][N] mA/cm^2 of the last iteration */
+  double* mix;                         /* [B] mixing factor */
+  double* accuracy;                    /* [B] */
+  double* surface_pH;                  /* [B] */
+  double* surface_potential;           /* [B] */
+  double* surface_efield;              /* [B] */
+  int32_t* step_to_check;              /* [B] iteration of the last mixing-factor decay */
+  int32_t* active;                     /* [B] 1: still iterating */
+  int32_t* failed;                     /* [B] 1: NaN in the transport solve (nan_in_surface, calculator.py:409-414) */
+} pnp_scf_state;
+
+int pnp_scf_cycle(pnp_handle* h, const pnp_scf_params* p, const double* nel /* [N] or NULL */, const double* nprod /* [N] or NULL */,
+                  pnp_scf_state* s, int32_t* iterations /* last iteration number that had active lanes, nullable */);
+
 /* Newton iterations each lane spent in the most recent pnp_step / pnp_solve_stationary call, summed over its
  * timesteps; a solve that hit maxit counts maxit+1. */
 int pnp_get_newton_iterations(pnp_handle* h, int32_t* iters /* [B] */);

@@ -279,6 +279,82 @@ def test_implicit_surface_kinetics_give_the_scf_fixed_point_in_one_solve():
     assert np.allclose(out['surface_concentration'][:, 2], cs[:9], rtol=2e-4)
 
 
+def test_device_scf_loop_walks_the_same_iterates_as_the_host_loop():
+    """pnp_scf_cycle: mixing, fallback, accuracy and mix decay per lane on the device, against the batched
+    host loop with the same analytic kinetics as a Python callback -- same iteration count, same per-lane bookkeeping."""
+    phis = list(np.linspace(-0.6, -1.4, 9))
+    rate = lambda phiM: 1e-4 * np.exp(-12.0 * (phiM + 0.6))
+    kin = [{'species': 'CO2', 'rate': rate, 'stoichiometry': {'CO2': -1.0, 'CO': 1.0}}]
+    outs = []
+    for device in (False, True):
+        tp = _physical_transport(phis, mpb=False)
+        calc = Calculator(transport=tp, calc='comsol', tau_scf=1e-6, mix_scf=0.02)
+        if device:
+            calc.set_surface_kinetics(kin)
+            outs.append(calc.run_scf_cycle(nel=[1, 1, 2, 2], max_iter=3000))
+            assert calc.surface_kinetics == kin
+        else:
+            def cb(state):
+                f = np.zeros((len(phis), 4))
+                f[:, 2] = -rate(state['phiM']) * np.maximum(state['surface_concentration'][:, 2], 0.0)
+                f[:, 3] = -f[:, 2]
+                return f
+            outs.append(calc.run_scf_cycle(cb, nel=[1, 1, 2, 2], max_iter=3000))
+    host, dev = outs
+    assert host['converged'].all() and dev['converged'].all() and not dev['failed'].any()
+    assert dev['iterations'] == host['iterations'] and host['iterations'] > 100
+    assert np.array_equal(dev['mix'], host['mix'])                              # the same number of decays per lane
+    assert np.allclose(dev['surface_concentration'], host['surface_concentration'], rtol=1e-9, atol=1e-12)
+    assert np.allclose(dev['flux'], host['flux'], rtol=1e-9, atol=1e-18)
+    assert np.allclose(dev['accuracy'], host['accuracy'], rtol=1e-3, atol=1e-12)
+    assert np.allclose(dev['current_density'], host['current_density'], rtol=1e-9)
+    # and both sit on the fixed point the implicit solve finds directly
+    L = (tp.nx - 1) * tp.dx
+    kap = rate(np.array(phis)) * L / tp.D[2]
+    assert np.allclose(dev['surface_concentration'][:, 2], 34.0 / (1.0 + kap), rtol=2e-4)
+
+
+def test_device_scf_loop_freezes_converged_lanes_and_puts_failed_ones_back():
+    """pnp_scf_cycle through the C-ABI with a hand-made loop state: lane 2 asks for a flux far beyond the diffusion limit (no
+    solution in the positive cone) -> its solve fails, the lane reports -1 (the reference's negative-concentration answer),
+    keeps the state of its last converged solve and never converges; lanes 0 and 1 converge and leave the batch."""
+    from catint_amd.units import unit_F
+    phis = np.array([-0.6, -0.7, -1.4])
+    tp = _physical_transport(list(phis), mpb=False)
+    tp.newton = {'maxit': 30}
+    calc = Calculator(transport=tp, calc='comsol', tau_scf=1e-5, mix_scf=0.5)
+    B, N = 3, 4
+    solver = calc._physical_solver(B)
+    try:
+        st = calc.solve_physical(solver, np.repeat(tp.c0[None, :], B, axis=0), phis, np.zeros((B, N)), nramp=8)
+        assert (st == 0).all()
+        c_start, phi_start = solver.get_state()[:2]
+        calc.set_surface_kinetics([{'species': 'CO2', 'rate': lambda phiM: 1e-4 * np.exp(-12.0 * (phiM + 0.6)),
+                                    'stoichiometry': {'CO2': -1.0, 'CO': 1.0}}])
+        calc._apply_surface_kinetics(solver, phis)
+        cs, vs, es = solver.get_surface()
+        state = {'surface_concentration': cs.copy(), 'surface_concentration_old': cs.copy(), 'flux': np.zeros((B, N)),
+                 'current_density_old': np.zeros((B, N)), 'mix': np.full(B, 0.5), 'accuracy': np.full(B, np.inf),
+                 'surface_pH': np.full(B, 7.0), 'surface_potential': vs, 'surface_efield': es,
+                 'step_to_check': np.full(B, 5), 'active': np.ones(B, np.int32), 'failed': np.zeros(B, np.int32)}
+        last = solver.scf_cycle(state, istep=5, max_iter=60, tau_scf=1e-5, faraday=unit_F, nel=[1, 1, 2, 2])
+        assert last == 60
+        assert list(state['active']) == [0, 0, 1] and not state['failed'].any()
+        assert (state['surface_concentration'][2] == -1.0).all()
+        assert state['mix'][2] == 0.5 * 0.9 and state['step_to_check'][2] == 46 and (state['mix'][:2] == 0.5).all()
+        c_end, phi_end = solver.get_state()[:2]
+        assert np.array_equal(c_end[2], c_start[2]) and np.array_equal(phi_end[2], phi_start[2])
+        # converged lanes: flux = K c_s(CO2) at the fixed point, state on the device consistent with what was reported
+        K = 1e-4 * np.exp(-12.0 * (phis[:2] + 0.6))
+        L = (tp.nx - 1) * tp.dx
+        assert np.allclose(state['surface_concentration'][:2, 2], 34.0 / (1.0 + K * L / tp.D[2]), rtol=1e-4)
+        assert np.allclose(c_end[:2, 2, 0], state['surface_concentration'][:2, 2], rtol=1e-12)
+        assert np.allclose(state['flux'][:2, 2], -K * state['surface_concentration_old'][:2, 2], rtol=1e-12)
+        assert (state['accuracy'][:2] <= 1e-5).all()
+    finally:
+        solver.close()
+
+
 def test_co2r_physical_example_matches_the_oracle_along_the_polarization_curve():
     """examples/co2r_physical_sweep.py (BASELINE configs[2] in the physical mode: 7 species, 5 stiff buffer reactions, steric K+,
     Stern layer, graded mesh, implicit Tafel kinetics) at test size, against the CPU oracle walking the same continuation."""
