@@ -207,13 +207,21 @@ def main():
             wall, ev_ms = float(t[0]), float(t[1])
         return wall, ev_ms
 
-    # clock spin-up (untimed, not part of W): a cold GPU needs a few milliseconds of load before it holds its clocks, and a
-    # short --warmup would leave that ramp inside the timed region
-    solver.step(512, args.steps_per_launch)
+    # Settling (untimed, not part of W).  Measured (tools/probe/cold_start_probe.py, slow_start_probe*.py): the clocks of a cold
+    # GPU settle over ~0.1 s of load, and the first two or three launches that follow an upload (pnp_set_batch) run 1.5x slower
+    # from start to end however long they are.  The number reported is the sustained rate of a trajectory in flight: 0.3 s of load
+    # on a throw-away trajectory, then the state is uploaded and four 8-step launches take the slow launches; the W warmup steps
+    # and the K timed steps follow on the same trajectory.  (The reference's lagged-potential integrator does not survive
+    # long runs on this workload -- lanes turn NaN after ~3000 steps, tools/probe/long_trajectory_probe.py, in the oracle too --
+    # hence the fresh upload; lanes_ok reports the state the timed steps leave behind.)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.3:
+        solver.step(512, args.steps_per_launch)
+        solver.synchronize()
     solver.set_batch(c0, pb, vz, fl)
-    # warmup, then restart from the initial state so the timed steps see a finite state
+    for _ in range(4):
+        solver.step(8, 8)
     solver.step(args.warmup, args.steps_per_launch)
-    solver.set_batch(c0, pb, vz, fl)
     wall, ev_ms = timed(args.steps, args.steps_per_launch)
     status = solver.get_status()
     n_launch = (args.steps + args.steps_per_launch - 1) // args.steps_per_launch
@@ -223,7 +231,7 @@ def main():
     # one launch per timestep (state read from and written to HBM by every launch) -- reported next to the headline
     fused = None
     if not args.no_fused and args.steps_per_launch != 1:
-        solver.set_batch(c0, pb, vz, fl)
+        solver.step(16, 1)
         fw, fe = timed(args.steps, 1)
         lsec = fe * 1e-3 / args.steps
         fused = {'timesteps_per_s': world * B * args.steps / fw, 'ms_per_step': fw / args.steps * 1e3,
@@ -251,8 +259,7 @@ def main():
         lp, lc0, lpb, lvz, lfl = make_batch(LB, N, nx, seed=77, phi_max=0.025, dt_factor=1e-5)
         s2 = solver_from_problem(lp, args.method, batch_capacity=LB, device=device)
         s2.set_batch(lc0, lpb, lvz, lfl)
-        s2.step(5, 1)
-        s2.set_batch(lc0, lpb, lvz, lfl)
+        s2.step(16, 1)
         ls = max(10, min(args.steps, 50))
         s2.synchronize()
         s2.timer_start()
@@ -267,8 +274,8 @@ def main():
         # the same batch in fused launches (like the headline)
         s3 = solver_from_problem(lp, args.method, batch_capacity=LB, device=device)
         s3.set_batch(lc0, lpb, lvz, lfl)
-        s3.step(8, 8)
-        s3.set_batch(lc0, lpb, lvz, lfl)
+        for _ in range(4):        # past the slow launches that follow an upload (see above)
+            s3.step(8, 8)
         s3.synchronize()
         s3.timer_start()
         s3.step(args.steps, args.steps_per_launch)

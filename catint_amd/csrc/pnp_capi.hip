@@ -382,7 +382,7 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_batch = true;
     h->steps_done = 0;
-    return PNP_OK;
+      return PNP_OK;
   }
   HIP_TRY(h, hipMemsetAsync(h->lapl[1], 0, (size_t)B * ldx * sizeof(double), h->stream));
   h->cur = 0;
@@ -403,18 +403,18 @@ static int run_steps(pnp_handle* h, int nsteps) {
     if (nsteps != 1) return fail(h, PNP_EINVAL, "internal: rate terms need one step per launch");
     HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
   }
-  // Measured on MI355X: while the batch has fewer lanes than ~2 per SIMD the LDS-staged
-  // kernel with three interleaved species per wave has the shortest critical path; once the batch
-  // oversubscribes the chip the register-resident kernel (one wave per lane, 3 waves/SIMD) wins because the
-  // LDS pipe stops being the shared bottleneck.  P = 16 keeps the LDS-staged kernel (twice the occupancy).
+  // Measured on MI355X.  One timestep per launch: while the batch has fewer lanes than ~2 per SIMD
+  // the LDS-staged kernel with three interleaved species per wave has the shortest critical path; once the batch
+  // oversubscribes the chip the register-resident kernel (one wave per lane, 3 waves/SIMD) wins because the LDS pipe
+  // stops being the shared bottleneck.  P = 16 keeps the LDS-staged kernel (twice the occupancy).
   if (waves_per_system(a.nx) > 1) {
     HIP_TRY(h, launch_step_mw(a, h->stream));
     if (nsteps & 1) h->cur = 1 - h->cur;
     h->steps_done += nsteps;
     return PNP_OK;
   }
-  // ... in one-step launches; in fused launches the LDS-staged kernel is at least as fast at every batch size
-  // (0.60-0.64 of the roofline for B = 1024...8192 against 0.52-0.63), measured with CATINT_PNP_KERNEL=2/4
+  // Fused launches: the LDS-staged kernel with one species per wave (choose_step_config) at every batch size
+  // (0.75-0.78 of the roofline for B = 1024...16384 against 0.52-0.63), measured with CATINT_PNP_KERNEL=2/4
   bool rr = step_rr_applicable(a) && a.B >= 2048 && h->P <= 8 && nsteps < 8;
   if (h->kernel_override == 2) rr = false;
   if (h->kernel_override == 4) rr = step_rr_applicable(a);
@@ -424,7 +424,7 @@ static int run_steps(pnp_handle* h, int nsteps) {
     HIP_TRY(h, launch_step_rr(a, w, h->stream));
   } else {
     int W = 1, G = 1;
-    choose_step_config(a.N, a.B, h->P, &W, &G);
+    choose_step_config(a.N, a.B, h->P, nsteps >= 8, &W, &G);
     if (h->waves_override >= 1 || h->species_override >= 1) {
       const int w2 = h->waves_override >= 1 ? h->waves_override : W;
       const int g2 = h->species_override >= 1 ? h->species_override : 1;

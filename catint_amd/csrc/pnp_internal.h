@@ -73,8 +73,9 @@ int points_per_lane(int nx);
 // waves cooperating on one tridiagonal system: 1 up to nx = 1026, 2 up to 2050, 4 up to 4098
 int waves_per_system(int nx);
 hipError_t launch_step_mw(const DevArgs& a, hipStream_t stream);
-// W = waves per operating point, G = species interleaved inside one wave, chosen for a batch of B lanes
-void choose_step_config(int N, int64_t B, int P, int* W, int* G);
+// W = waves per operating point, G = species interleaved inside one wave, chosen for a batch of B lanes and for launches
+// of one timestep or of many (fused)
+void choose_step_config(int N, int64_t B, int P, bool fused, int* W, int* G);
 bool step_config_supported(int W, int G);
 size_t step_lds_bytes(int P, int W, int G);
 

@@ -802,6 +802,14 @@ __global__ __launch_bounds__(64 * W, (step_min_waves<P, G>())) void step_kernel(
     if (neg_mask) st = PNP_STATUS_NEGATIVE;
     if (nan_mask) st = PNP_STATUS_NAN;
     if (st) atomicMax(&A.status[b], st);   // sticky until the next pnp_set_batch
+#ifdef PNP_HWID_PROBE
+    // diagnosis build (tools/probe/hwid_probe.py): which SIMD ran each wave of the workgroup -- HW_ID[5:4] -- and which CU / SE
+    // wave 0 ran on -- HW_ID[11:8], [15:13]
+    const unsigned simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+    unsigned v = 1u << (8 + 4 * wave + simd);
+    if (wave == 0) v |= (__builtin_amdgcn_s_getreg((3 << 11) | (8 << 6) | 4) << 20) | (__builtin_amdgcn_s_getreg((2 << 11) | (13 << 6) | 4) << 24);
+    atomicOr((unsigned*)&A.status[b], v);
+#endif
   }
 }
 
@@ -1848,14 +1856,24 @@ hipError_t launch_poisson_mw(const DevArgs& a, const double* lapl, double* v, do
   return hipGetLastError();
 }
 
-void choose_step_config(int N, int64_t B, int P, int* W, int* G) {
-  // Small batches: every SIMD should own a few independent dependency chains -- species in different
-  // waves (W) and/or interleaved inside a wave (G).  Large batches: one wave per operating point.
+void choose_step_config(int N, int64_t B, int P, bool fused, int* W, int* G) {
   int w = 1, g = 1;
-  if (P <= 8) g = (N % 3 == 0) ? 3 : ((N % 2 == 0) ? 2 : 1);
-  if (g > N) g = N;
-  const int wmax = (g == 3) ? 1 : (g == 2 ? 2 : 4);   // instantiated (W,G) pairs: see launch_step_p
-  while (w < wmax && w * g < N && B * w < 2048) ++w;
+  if (fused) {
+    // Launches that advance many timesteps (measured per shape with tools/probe/step_config_probe.py):
+    // up to 8 points per lane one species per wave and 3 (N <= 4: N) waves per operating point -- 0.75-0.78 of the roofline
+    // on the headline shape against 0.65 for three species interleaved in one wave, at every batch size, because a wave
+    // issues an fp64 instruction only every ~8.5 cycles and the SIMD wants four of them; 16 points per lane: one wave, two
+    // species interleaved when they pair up (the rows no longer fit LDS three waves wide at useful occupancy).
+    if (P >= 16) g = (N % 2 == 0) ? 2 : 1;
+    else if (P >= 4) w = N <= 4 ? N : 3;
+  } else {
+    // One timestep per launch.  Small batches: every SIMD should own a few independent dependency chains -- species in
+    // different waves (W) and/or interleaved inside a wave (G).  Large batches: one wave per operating point.
+    if (P <= 8) g = (N % 3 == 0) ? 3 : ((N % 2 == 0) ? 2 : 1);
+    if (g > N) g = N;
+    const int wmax = (g == 3) ? 1 : (g == 2 ? 2 : 4);   // instantiated (W,G) pairs: see launch_step_p
+    while (w < wmax && w * g < N && B * w < 2048) ++w;
+  }
   *W = w;
   *G = g;
 }
