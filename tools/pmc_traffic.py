@@ -20,7 +20,8 @@ def counter(dirname):
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
             meta = {k: r[k] for k in ('Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'VGPR_Count', 'Accum_VGPR_Count',
                                       'SGPR_Count', 'LDS_Block_Size', 'Scratch_Size')}
-    return {k: sum(v) / len(v) for k, v in agg.items()}, meta, {k: len(v) for k, v in agg.items()}
+    # median: the handful of short settling launches (8 steps) and the slow ones after an upload do not belong to the figure
+    return {k: sorted(v)[len(v) // 2] for k, v in agg.items()}, meta, {k: len(v) for k, v in agg.items()}
 
 
 print('# command: python3 bench.py ' + args)
@@ -33,7 +34,7 @@ sq, _, _ = counter('sq')
 print('## step kernel dispatch:', json.dumps(meta))
 fs, ws = fetch['FETCH_SIZE'], write['WRITE_SIZE']
 hbm = (2.0 * fs + ws) * 1024.0
-print('## HBM counters (mean over %d launches): FETCH_SIZE=%.1f KiB (x2 on gfx950 -> %.3f MB), WRITE_SIZE=%.1f KiB (%.3f MB)'
+print('## HBM counters (median over %d launches): FETCH_SIZE=%.1f KiB (x2 on gfx950 -> %.3f MB), WRITE_SIZE=%.1f KiB (%.3f MB)'
       % (n['FETCH_SIZE'], fs, 2 * fs * 1024 / 1e6, ws, ws * 1024 / 1e6))
 print('## hbm_bytes_per_launch = %.0f' % hbm)
 waves = float(meta['Grid_Size']) / 64
