@@ -314,6 +314,12 @@ def main():
                     args.steps == n_launch * args.steps_per_launch and world == 1:
                 out['roofline']['traffic'] = tj['hbm_bytes_per_launch']
                 out['roofline']['traffic_source'] = tj.get('source')
+                if tj.get('sq_insts_valu_per_wave'):
+                    # fp64 vector utilisation next to the HBM figure.  Every VALU instruction of the kernel counted as
+                    # a 64-lane fp64 operation (upper bound; SQ_INSTS_VALU of the same rocprofv3 run) against 256 CUs x 4 SIMDs x
+                    # 16 fp64 lanes per cycle x 2.4 GHz
+                    lane_ops = tj['sq_insts_valu_per_wave'] / args.steps_per_launch * tj.get('waves_per_lane', 1.0) * 64.0
+                    out['roofline']['fp64_valu_util'] = lane_ops * (B / launch_s * args.steps / n_launch) / (256 * 4 * 16 * 2.4e9)
         except Exception:
             pass
         if fused:

@@ -582,7 +582,12 @@ __global__ __launch_bounds__(64 * W, (step_min_waves<P, G>())) void step_kernel(
         // grad_v[i] is kept in slot i+1 (slot 0 duplicates grad_v[0]) so that every stencil window
         // below is an affine, clamp-free LDS address
         // (the scans use the head of GV as their exchange strip: grad_v of the previous step is dead by now)
-        const double v1w = poisson_wave<P, false, 1>(A, LV, GV, nullptr, GV, vw, vb, gw, gb, lane);
+        // The lane index is made opaque once per step: the scan's lane-dependent weights ((double)(m - r0 - j), ...) are then
+        // recomputed where they are used (one conversion each) instead of being hoisted out of the time loop and -- in the
+        // instances that sit at their register budget -- reloaded from spill slots, four dependent scratch loads per step.
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const double v1w = poisson_wave<P, false, 1>(A, LV, GV, nullptr, GV, vw, vb, gw, gb, lane_o);
         if (lane == 0) {
           GV[V1SLOT] = v1w;
           // CN indexes grad_v with the interior index r <= nx-3 plus, for the bulk boundary term,

@@ -46,5 +46,8 @@ rec = {'batch': opt('--batch', 1024), 'nspecies': opt('--nspecies', 3), 'nx': op
        'steps_per_launch': opt('--steps-per-launch', 256), 'method': 'Crank-Nicolson',
        'hbm_bytes_per_launch': hbm, 'fetch_size_kib': fs, 'write_size_kib': ws,
        'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024',
-       'kernel': meta.get('Kernel_Name')}
+       'kernel': meta.get('Kernel_Name'),
+       # per wave and launch; a lane of the batch is advanced by Grid_Size/64/batch waves
+       'sq_insts_valu_per_wave': sq.get('SQ_INSTS_VALU', 0.0) / waves, 'sq_insts_lds_per_wave': sq.get('SQ_INSTS_LDS', 0.0) / waves,
+       'waves_per_lane': waves / opt('--batch', 1024)}
 json.dump(rec, open(out + '/hbm_traffic.json', 'w'), indent=1)
