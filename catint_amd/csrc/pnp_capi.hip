@@ -28,6 +28,7 @@ struct pnp_handle {
   double *pb = nullptr, *vzeta = nullptr, *flux = nullptr, *cbulk = nullptr, *csurf = nullptr;
   double *ytmp = nullptr, *ftmp = nullptr;   // method-of-lines scratch: state in, derivative out
   double* mol_lapl = nullptr;                // ... and its charge row for grids beyond one wave
+  double* stage = nullptr;                   // upload staging [B][N][nx] (pnp_set_batch)
   SpecConst* spec = nullptr;
   int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
   int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
@@ -99,7 +100,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -361,30 +362,26 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
   h->B = B;
   h->a.B = B;
-  // pads of the pitched rows must be zero (they travel through the kernels untouched)
-  HIP_TRY(h, hipMemsetAsync(h->c, 0, (size_t)B * N * ldx * sizeof(double), h->stream));
-  HIP_TRY(h, hipMemcpy2DAsync(h->c, (size_t)ldx * sizeof(double), c0, (size_t)nx * sizeof(double), (size_t)nx * sizeof(double),
-                              (size_t)B * N, hipMemcpyHostToDevice, h->stream));
+  // One contiguous upload into a staging buffer; unpack_state_kernel writes the pitched rows (zero pads: they travel through
+  // the kernels untouched), the bulk Dirichlet values = last grid point of the initial state (calculator_old.py:540) and the
+  // zeroed second charge row.
+  if (!h->stage) HIP_TRY(h, dev_alloc(h, &h->stage, (size_t)h->cfg.batch_capacity * N * nx));
+  HIP_TRY(h, hipMemcpyAsync(h->stage, c0, (size_t)B * N * nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->pb, pb, (size_t)B * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->vzeta, vzeta, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->flux, flux, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  // bulk Dirichlet values = last grid point of the initial state (calculator_old.py:540)
-  HIP_TRY(h, hipMemcpy2DAsync(h->cbulk, sizeof(double), c0 + (nx - 1), (size_t)nx * sizeof(double), sizeof(double), (size_t)B * N,
-                              hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->status, 0, (size_t)B * sizeof(int32_t), h->stream));
+  HIP_TRY(h, launch_unpack_state(h->a, h->stage, h->cbulk, h->newton ? nullptr : h->lapl[1], h->newton ? h->iters : nullptr, h->stream));
   if (h->newton) {
     // initial guess of the potential: the bulk value everywhere (field-free electrolyte, c = c_bulk; comsol_model.py:744)
     std::vector<double> phi0((size_t)B * ldx, 0.0);
     for (int64_t b = 0; b < B; ++b)
       for (int i = 0; i < nx; ++i) phi0[(size_t)b * ldx + i] = pb[b * 4 + 1];
     HIP_TRY(h, hipMemcpyAsync(h->v, phi0.data(), phi0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->iters, 0, (size_t)B * sizeof(int32_t), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_batch = true;
     h->steps_done = 0;
-      return PNP_OK;
+    return PNP_OK;
   }
-  HIP_TRY(h, hipMemsetAsync(h->lapl[1], 0, (size_t)B * ldx * sizeof(double), h->stream));
   h->cur = 0;
   HIP_TRY(h, launch_charge_row(h->a, h->lapl[0], h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));

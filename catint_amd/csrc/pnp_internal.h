@@ -95,6 +95,10 @@ hipError_t launch_rates(const DevArgs& a, const ReactionTable& rt, double* rates
 hipError_t launch_mol_rhs(const DevArgs& a, const double* y, double* dydt, hipStream_t stream);
 // the same for grids spanning several waves: point-wise from a gradient row computed by launch_poisson
 hipError_t launch_mol_rhs_pointwise(const DevArgs& a, const double* y, const double* gradv, double* dydt, hipStream_t stream);
+// state upload: contiguous staging buffer [B][N][nx] -> pitched rows a.c (pads zero), cbulk[B][N], zeroed charge row (nullable),
+// status[B] = 0, iters[B] = 0 (nullable)
+hipError_t launch_unpack_state(const DevArgs& a, const double* stage, double* cbulk, double* lapl_zero, int32_t* iters_zero,
+                               hipStream_t stream);
 // surface gather: csurf[B][N] = c[b][k][0]
 hipError_t launch_surface(const DevArgs& a, double* csurf, hipStream_t stream);
 

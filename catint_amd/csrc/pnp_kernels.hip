@@ -1774,6 +1774,29 @@ __global__ void charge_row_kernel(const DevArgs A, double* __restrict__ lapl) {
   lapl[idx] = acc;
 }
 
+// Upload path of pnp_set_batch: the host state arrives contiguous ([B][N][nx]) in a staging buffer and THIS kernel writes the
+// pitched state rows (pads zero), the bulk Dirichlet values (last grid point, calculator_old.py:540) and a zeroed second charge row.
+// One contiguous host-to-device copy and one kernel replace two fill blits and two strided 2-D copies.
+__global__ void unpack_state_kernel(const DevArgs A, const double* __restrict__ stage, double* __restrict__ cbulk,
+                                    double* __restrict__ lapl_zero, int32_t* __restrict__ iters_zero) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = A.B * A.N * A.ldx;
+  if (idx >= total) return;
+  const int64_t row = idx / A.ldx;           // b*N + k
+  const int i = (int)(idx - row * A.ldx);
+  double v = 0.0;
+  if (i < A.nx) {
+    v = stage[row * A.nx + i];
+    if (i == A.nx - 1) cbulk[row] = v;
+  }
+  A.c[idx] = v;
+  if (lapl_zero && row % A.N == 0) lapl_zero[(row / A.N) * A.ldx + i] = 0.0;
+  if (i == 0 && row % A.N == 0) {              // per-lane flags start clean
+    A.status[row / A.N] = PNP_STATUS_OK;
+    if (iters_zero) iters_zero[row / A.N] = 0;
+  }
+}
+
 // get_rates (:159-208) with the reference's overwrite order, thread per grid point
 __global__ void rates_kernel(const DevArgs A, const ReactionTable rt, double* __restrict__ rates) {
   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -2009,6 +2032,15 @@ hipError_t launch_charge_row(const DevArgs& a, double* lapl, hipStream_t stream)
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
   hipLaunchKernelGGL(charge_row_kernel, dim3(blocks), dim3(threads), 0, stream, a, lapl);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_state(const DevArgs& a, const double* stage, double* cbulk, double* lapl_zero, int32_t* iters_zero,
+                               hipStream_t stream) {
+  const int64_t total = a.B * a.N * a.ldx;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+  hipLaunchKernelGGL(unpack_state_kernel, dim3(blocks), dim3(threads), 0, stream, a, stage, cbulk, lapl_zero, iters_zero);
   return hipGetLastError();
 }
 
