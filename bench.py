@@ -125,6 +125,25 @@ def physical_mode(args, device, with_cpu):
            'ms_per_step': ms / args.physical_steps, 'lanes_ok': ok, 'bound': 'fp64 VALU issue / LDS exchange (not HBM)'}
     if N == 3 and nx <= 512:
         out['fp64_valu_util'] = 256 * 3716.0 * out['newton_iterations_per_s'] / (256 * 4 * 16 * 2.4e9)
+    # the same steps with the quadratic error estimate as the stopping rule (pnp_newton_params.error_estimate: stop when the
+    # NEXT update is predicted below tol -- the state meets the same tolerance, the last confirming iteration is not spent)
+    try:
+        s = _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=B,
+                            device=device)
+        s.set_newton(tol=1e-8, error_estimate=True)
+        s.set_batch(c0, pb, vz, fl)
+        s.step(5)
+        s.synchronize()
+        s.timer_start()
+        s.step(args.physical_steps)
+        ms_e = s.timer_stop()
+        it_e = s.newton_iterations()
+        ok_e = int((s.get_status() == 0).sum())
+        s.close()
+        out['with_error_estimate'] = {'timesteps_per_s': B * args.physical_steps / (ms_e * 1e-3),
+                                      'mean_newton_iterations_per_step': float(it_e.sum()) / (B * args.physical_steps), 'lanes_ok': ok_e}
+    except Exception as e:
+        out['with_error_estimate'] = {'error': str(e)}
     # BASELINE configs[4] shape in the same mode: 8 species (size-modified, Stern wall), 4096 points -- lane-team kernel
     try:
         LB = max(64, min(1024, B))
