@@ -295,6 +295,7 @@ def main():
         s3.set_batch(lc0, lpb, lvz, lfl)
         for _ in range(4):        # past the slow launches that follow an upload (see above)
             s3.step(8, 8)
+        s3.step(args.steps_per_launch, args.steps_per_launch)
         s3.synchronize()
         s3.timer_start()
         s3.step(args.steps, args.steps_per_launch)

@@ -55,6 +55,8 @@ struct pnp_handle {
   int nw_blocks = 0;
   // device SCF loop (pnp_scf_cycle): per-lane bookkeeping, allocated on first use; the two switches below are set around
   // its transport solves
+  double* sweep = nullptr;               // sweep kernel: records of the resident teams (allocated on first use)
+  int sweep_blocks = 0;
   double* scf_d = nullptr;               // (4N + 5) B doubles
   double* scf_snap = nullptr;            // (N + 1) ldx B doubles: per-lane state of the last converged transport solve
   int32_t* scf_i = nullptr;              // 3 B flags + 65 counters
@@ -100,7 +102,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -475,6 +477,28 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.rt = (h->rt_dev && h->rt.n > 0) ? h->rt_dev : nullptr;
   a.n_wk = h->newton_explicit_kinetics ? 0 : h->n_wk;
   a.lane_mask = h->newton_mask;
+  if (newton_sweep_preferred(N + 1, nx, h->B)) {
+    // one team (N+1 lanes) per operating point, 64/(N+1) per wave; the workspace holds the records of the resident waves: at
+    // most four per SIMD, all of the batch capacity, and 32 GiB
+    const int64_t tpw = 64 / (N + 1);
+    const size_t per_block = newton_sweep_doubles(N + 1, nx) * (size_t)tpw * sizeof(double);
+    if (!h->sweep) {
+      int64_t blocks = (h->cfg.batch_capacity + tpw - 1) / tpw;
+      if (blocks > 4096) blocks = 4096;
+      if (const char* e = getenv("CATINT_NEWTON_SWEEP_BLOCKS")) {      // tests: force several rounds per team
+        const int v = atoi(e);
+        if (v >= 1 && v < blocks) blocks = v;
+      }
+      const int64_t fit = (int64_t)(((size_t)32 << 30) / per_block);
+      if (blocks > fit) blocks = fit;
+      if (blocks < 1) blocks = 1;
+      HIP_TRY(h, dev_alloc(h, &h->sweep, (size_t)blocks * per_block / sizeof(double)));
+      h->sweep_blocks = (int)blocks;
+    }
+    a.sweep = h->sweep;
+    a.sweep_stride = (int64_t)newton_sweep_doubles(N + 1, nx);
+    a.sweep_blocks = h->sweep_blocks;
+  }
   memcpy(a.wk_species, h->wk_species, sizeof(a.wk_species));
   memcpy(a.wk_nu, h->wk_nu, sizeof(a.wk_nu));
   a.wk_k = h->wk_k;

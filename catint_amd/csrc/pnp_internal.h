@@ -138,10 +138,15 @@ struct NewtonArgs {
   int32_t* status;                       // [B]
   int32_t* iters;                        // [B] Newton iterations spent by this call (maxit+1 for a failed solve)
   const int32_t* lane_mask;              // [B] or null: lanes with a zero are left untouched (frozen lanes of the SCF loop)
+  double* sweep;                         // sweep kernel (one team per operating point): records, sweep_stride doubles per team
+  int64_t sweep_stride;
+  int32_t sweep_blocks, pad2_;           // workgroups (= waves) the sweep workspace was sized for; 0: no workspace
 };
 int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);
 size_t newton_team_doubles(int nb, int nx);      // row buffer of the lane-team kernel (N >= 5)
+size_t newton_sweep_doubles(int nb, int nx);     // records of one team of the sweep kernel (block Thomas, large batches)
+bool newton_sweep_preferred(int nb, int nx, int64_t B);   // large blocks and enough lanes to fill the chip with teams
 bool newton_exchange_in_lds(int nb, int nx);
 int newton_pair_threads(int nb, int nx);   // threads of the pair kernel, 0 if the shape does not fit it
 int newton_pair_stride(int nb, int nx);    // its compile-time row stride (256 or 512)

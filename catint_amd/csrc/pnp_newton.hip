@@ -1104,9 +1104,8 @@ struct TeamLayout {
 
 // Gauss-Jordan across a team on rows Dr (NB) | Xr (NC):  X <- D^-1 X.  PIVOT: the lane with the largest |D[.][k]| among the
 // lanes not used yet provides pivot row k; on return `myk` is the unknown whose solution row the lane holds.
-template <int NB, bool PIVOT>
-__device__ __forceinline__ void team_solve(double (&Dr)[NB], double (&Xr)[2 * NB + 1], double* strip, int r, int& myk) {
-  constexpr int NC = 2 * NB + 1;
+template <int NB, int NC, bool PIVOT>
+__device__ __forceinline__ void team_solve_n(double (&Dr)[NB], double (&Xr)[NC], double* strip, int r, int& myk) {
   double* sv = strip;             // [NB] scalars
   double* sp = strip + NB;        // pivot row
   bool used = false;
@@ -1152,6 +1151,168 @@ __device__ __forceinline__ void team_solve(double (&Dr)[NB], double (&Xr)[2 * NB
     }
     if constexpr (!PIVOT) team_sync();      // (with pivoting the next search's sync separates the strip reuse)
   }
+}
+
+template <int NB, bool PIVOT>
+__device__ __forceinline__ void team_solve(double (&Dr)[NB], double (&Xr)[2 * NB + 1], double* strip, int r, int& myk) {
+  team_solve_n<NB, 2 * NB + 1, PIVOT>(Dr, Xr, strip, r, myk);
+}
+
+// One block row of the Newton system, evaluated by a team: lane r returns row r of the diagonal block (Dr) and of [L | U | rhs]
+// (Xr) of grid point i -- the equation of species r (r < N) or the Poisson equation (r = N); see fill_row for the formulas.
+// A: scalar parameters (LDS copy), G: kernel arguments (pointers).  `strip` is the team's LDS strip (team sums).
+template <int NB, int MODE>
+__device__ __forceinline__ void team_assemble_row(const NewtonArgs& A, const NewtonArgs& G, const double* c, const double* co,
+                                                  const double* phi, const double* cb, const double* wk, double phiM, double phiB,
+                                                  int64_t b, int i, int r, bool spec, double* strip, double (&Dr)[NB],
+                                                  double (&Xr)[2 * NB + 1]) {
+  constexpr int N = NB - 1, NC = 2 * NB + 1;
+  constexpr bool MPB = MODE >= 1, REACT = MODE == 2;
+  const int nx = A.nx, ldx = A.ldx;
+    const int rs_ = spec ? r : 0;
+    const double qb_r = A.qb[rs_], sig_r = A.sig[rs_], fl_r = A.fl[rs_], peq_r = A.peq[rs_], vol_r = A.vol[rs_], rs_r = A.rs[rs_];
+    const double flux_r = G.flux[(size_t)b * N + rs_], cb_r = cb[rs_];
+    const int im = i > 0 ? i - 1 : 0, ip = i < nx - 1 ? i + 1 : nx - 1;
+    const bool wall = (i == 0), bulk = (i == nx - 1);
+    const double pm = phi[im], p0 = phi[i], pp = phi[ip];
+    const double cm = c[rs_ * ldx + im], c0 = c[rs_ * ldx + i], cp = c[rs_ * ldx + ip];
+    // team sums: occupied volume fraction at the three points, scaled charge density at i
+    auto team_sum = [&](double v) {
+      strip[r] = v;
+      team_sync();
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc += strip[j];
+      team_sync();
+      return acc;
+    };
+    double fm = 0.0, f0 = 0.0, fp = 0.0;
+    if constexpr (MPB) {
+      fm = team_sum(spec ? vol_r * cm : 0.0);
+      f0 = team_sum(spec ? vol_r * c0 : 0.0);
+      fp = team_sum(spec ? vol_r * cp : 0.0);
+    }
+    const double rho = team_sum(spec ? peq_r * c0 : 0.0);
+    double wm_ = 0.0, w0_ = 0.0, wp_ = 0.0, invm = 1.0, inv0 = 1.0, invp = 1.0;
+    if constexpr (MPB) {
+      wm_ = -log1p_sc(-fm);
+      w0_ = -log1p_sc(-f0);
+      wp_ = -log1p_sc(-fp);
+      invm = 1.0 / (1.0 - fm);
+      inv0 = 1.0 / (1.0 - f0);
+      invp = 1.0 / (1.0 - fp);
+    }
+    const double wem = G.gw[im], wep = G.gw[i < nx - 1 ? i : nx - 2], vi = G.gv[i];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) Dr[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) Xr[j] = 0.0;
+    if (spec) {
+      const double wpp = bulk ? 0.0 : 1.0, wmm = (wall || bulk) ? 0.0 : 1.0, ws = bulk ? 0.0 : vi;
+      const Edge em = edge_flux(qb_r * (p0 - pm) + (w0_ - wm_), cm, c0, wem);
+      const Edge ep = edge_flux(qb_r * (pp - p0) + (wp_ - w0_), c0, cp, wep);
+      const double sg = ws * sig_r;
+      const double Jp = wpp * ep.J, Jup = wpp * ep.Ju, Jm = wmm * em.J, Jum = wmm * em.Ju;
+      double F = sg * (c0 - co[rs_ * ldx + i]) + Jp - Jm - (wall ? flux_r * fl_r : 0.0);
+      if (bulk) F = c0 - cb_r;
+      double rhs = -F;
+      const double diag = sg + wpp * ep.Bp + wmm * em.Bm + (bulk ? 1.0 : 0.0);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const double own = (j == r) ? 1.0 : 0.0, pot = (j == N) ? 1.0 : 0.0;
+        Dr[j] = own * diag - pot * qb_r * (Jup + Jum);
+        Xr[NB + j] = -own * (wpp * ep.Bm) + pot * Jup * qb_r;
+        Xr[j] = -own * (wmm * em.Bp) + pot * Jum * qb_r;
+        if constexpr (MPB) {
+          if (j < N) {
+            const double vj = A.vol[j];
+            Dr[j] += -(Jup + Jum) * vj * inv0;
+            Xr[NB + j] += Jup * vj * invp;
+            Xr[j] += Jum * vj * invm;
+          }
+        }
+      }
+      if constexpr (REACT) {       // mass action in activities, see fill_row
+        const ReactionTable* rt = G.rt;
+        double call[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) call[k] = c[k * ldx + i];
+        auto pick = [&](int idx) {
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) v = (k == idx) ? call[k] : v;
+          return v;
+        };
+        const double wr = ws * rs_r;
+        const int nr = rt->n;
+        for (int q = 0; q < nr; ++q) {
+          const int nl = rt->n_lhs[q], nrh = rt->n_rhs[q];
+          // net stoichiometry of this lane's species in reaction q (products - educts)
+          int mult = 0;
+          for (int a = 0; a < nl; ++a) mult -= (rt->lhs[q][a] == r) ? 1 : 0;
+          for (int a = 0; a < nrh; ++a) mult += (rt->rhs[q][a] == r) ? 1 : 0;
+          for (int side = 0; side < 2; ++side) {
+            const int n = side == 0 ? nl : nrh;
+            const int32_t* idx = side == 0 ? rt->lhs[q] : rt->rhs[q];
+            const double kk = side == 0 ? rt->kf[q] : rt->kr[q];
+            if (kk == 0.0) continue;
+            double pre = kk;
+            for (int a = 0; a < n; ++a) pre *= inv0;
+            double prod = pre;
+            for (int a = 0; a < n; ++a) prod *= pick(idx[a]);
+            const double w = (side == 0 ? 1.0 : -1.0) * mult * wr;      // forward minus backward
+            rhs = __builtin_fma(w, prod, rhs);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              double dp = MPB ? prod * n * A.vol[j] * inv0 : 0.0;
+              for (int a = 0; a < n; ++a) {
+                if (idx[a] != j) continue;
+                double rest = pre;
+                for (int b2 = 0; b2 < n; ++b2)
+                  if (b2 != a) rest *= pick(idx[b2]);
+                dp += rest;
+              }
+              Dr[j] = __builtin_fma(-w, dp, Dr[j]);
+            }
+          }
+        }
+      }
+      if (wall && A.n_wk > 0) {   // implicit first-order surface kinetics, see fill_row
+        for (int q = 0; q < A.n_wk; ++q) {
+          const int sp = A.wk_species[q];
+          double nu = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) nu = (k == r) ? A.wk_nu[q][k] : nu;
+          const double a = nu * wk[q] * fl_r;
+          const double cs = sp >= 0 ? c[sp * ldx] : 1.0;
+          rhs += a * cs;
+#pragma unroll
+          for (int j = 0; j < N; ++j) Dr[j] -= (j == sp) ? a : 0.0;
+        }
+      }
+      Xr[2 * NB] = rhs;
+    } else {
+      if (bulk) {
+        Xr[2 * NB] = -(p0 - phiB);
+        Dr[N] = 1.0;
+      } else if (wall) {
+        if (A.wall_bc == 0) {
+          Xr[2 * NB] = -(p0 - phiM);
+          Dr[N] = 1.0;
+        } else {
+          Xr[2 * NB] = -(wep * (pp - p0) + A.stern * (phiM - A.phi_pzc - p0));
+          Dr[N] = -wep - A.stern;
+          Xr[NB + N] = wep;
+        }
+      } else {
+        Xr[2 * NB] = -(wep * (pp - p0) - wem * (p0 - pm) + vi * rho);
+#pragma unroll
+        for (int k = 0; k < N; ++k) Dr[k] = vi * A.peq[k];
+        Dr[N] = -(wep + wem);
+        Xr[N] = wem;
+        Xr[NB + N] = wep;
+      }
+    }
 }
 
 template <int NB, int MODE>
@@ -1206,153 +1367,10 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
           const NewtonArgs* Ap = &sA;            // ... and so is the pointer to the parameter copy: its loads stay inside the pass
           asm volatile("" : "+v"(r), "+v"(team), "+v"(Ap));
           const NewtonArgs& A = *Ap;
-          const int rs_ = spec ? r : 0;
-          const double qb_r = A.qb[rs_], sig_r = A.sig[rs_], fl_r = A.fl[rs_], peq_r = A.peq[rs_], vol_r = A.vol[rs_], rs_r = A.rs[rs_];
-          const double flux_r = G.flux[(size_t)b * N + rs_], cb_r = cb[rs_];
           const int i = min(row0 + team, nx - 1);
           const bool valid = real_team && row0 + team < nx;
-          const int im = i > 0 ? i - 1 : 0, ip = i < nx - 1 ? i + 1 : nx - 1;
-          const bool wall = (i == 0), bulk = (i == nx - 1);
-          const double pm = phi[im], p0 = phi[i], pp = phi[ip];
-          const double cm = c[rs_ * ldx + im], c0 = c[rs_ * ldx + i], cp = c[rs_ * ldx + ip];
-          // team sums: occupied volume fraction at the three points, scaled charge density at i
-          auto team_sum = [&](double v) {
-            strip[r] = v;
-            team_sync();
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) acc += strip[j];
-            team_sync();
-            return acc;
-          };
-          double fm = 0.0, f0 = 0.0, fp = 0.0;
-          if constexpr (MPB) {
-            fm = team_sum(spec ? vol_r * cm : 0.0);
-            f0 = team_sum(spec ? vol_r * c0 : 0.0);
-            fp = team_sum(spec ? vol_r * cp : 0.0);
-          }
-          const double rho = team_sum(spec ? peq_r * c0 : 0.0);
-          double wm_ = 0.0, w0_ = 0.0, wp_ = 0.0, invm = 1.0, inv0 = 1.0, invp = 1.0;
-          if constexpr (MPB) {
-            wm_ = -log1p_sc(-fm);
-            w0_ = -log1p_sc(-f0);
-            wp_ = -log1p_sc(-fp);
-            invm = 1.0 / (1.0 - fm);
-            inv0 = 1.0 / (1.0 - f0);
-            invp = 1.0 / (1.0 - fp);
-          }
-          const double wem = G.gw[im], wep = G.gw[i < nx - 1 ? i : nx - 2], vi = G.gv[i];
           double Dr[NB], Xr[NC];
-#pragma unroll
-          for (int j = 0; j < NB; ++j) Dr[j] = 0.0;
-#pragma unroll
-          for (int j = 0; j < NC; ++j) Xr[j] = 0.0;
-          if (spec) {
-            const double wpp = bulk ? 0.0 : 1.0, wmm = (wall || bulk) ? 0.0 : 1.0, ws = bulk ? 0.0 : vi;
-            const Edge em = edge_flux(qb_r * (p0 - pm) + (w0_ - wm_), cm, c0, wem);
-            const Edge ep = edge_flux(qb_r * (pp - p0) + (wp_ - w0_), c0, cp, wep);
-            const double sg = ws * sig_r;
-            const double Jp = wpp * ep.J, Jup = wpp * ep.Ju, Jm = wmm * em.J, Jum = wmm * em.Ju;
-            double F = sg * (c0 - co[rs_ * ldx + i]) + Jp - Jm - (wall ? flux_r * fl_r : 0.0);
-            if (bulk) F = c0 - cb_r;
-            double rhs = -F;
-            const double diag = sg + wpp * ep.Bp + wmm * em.Bm + (bulk ? 1.0 : 0.0);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-              const double own = (j == r) ? 1.0 : 0.0, pot = (j == N) ? 1.0 : 0.0;
-              Dr[j] = own * diag - pot * qb_r * (Jup + Jum);
-              Xr[NB + j] = -own * (wpp * ep.Bm) + pot * Jup * qb_r;
-              Xr[j] = -own * (wmm * em.Bp) + pot * Jum * qb_r;
-              if constexpr (MPB) {
-                if (j < N) {
-                  const double vj = A.vol[j];
-                  Dr[j] += -(Jup + Jum) * vj * inv0;
-                  Xr[NB + j] += Jup * vj * invp;
-                  Xr[j] += Jum * vj * invm;
-                }
-              }
-            }
-            if constexpr (REACT) {       // mass action in activities, see fill_row
-              const ReactionTable* rt = G.rt;
-              double call[N];
-#pragma unroll
-              for (int k = 0; k < N; ++k) call[k] = c[k * ldx + i];
-              auto pick = [&](int idx) {
-                double v = 0.0;
-#pragma unroll
-                for (int k = 0; k < N; ++k) v = (k == idx) ? call[k] : v;
-                return v;
-              };
-              const double wr = ws * rs_r;
-              const int nr = rt->n;
-              for (int q = 0; q < nr; ++q) {
-                const int nl = rt->n_lhs[q], nrh = rt->n_rhs[q];
-                // net stoichiometry of this lane's species in reaction q (products - educts)
-                int mult = 0;
-                for (int a = 0; a < nl; ++a) mult -= (rt->lhs[q][a] == r) ? 1 : 0;
-                for (int a = 0; a < nrh; ++a) mult += (rt->rhs[q][a] == r) ? 1 : 0;
-                for (int side = 0; side < 2; ++side) {
-                  const int n = side == 0 ? nl : nrh;
-                  const int32_t* idx = side == 0 ? rt->lhs[q] : rt->rhs[q];
-                  const double kk = side == 0 ? rt->kf[q] : rt->kr[q];
-                  if (kk == 0.0) continue;
-                  double pre = kk;
-                  for (int a = 0; a < n; ++a) pre *= inv0;
-                  double prod = pre;
-                  for (int a = 0; a < n; ++a) prod *= pick(idx[a]);
-                  const double w = (side == 0 ? 1.0 : -1.0) * mult * wr;      // forward minus backward
-                  rhs = __builtin_fma(w, prod, rhs);
-#pragma unroll
-                  for (int j = 0; j < N; ++j) {
-                    double dp = MPB ? prod * n * A.vol[j] * inv0 : 0.0;
-                    for (int a = 0; a < n; ++a) {
-                      if (idx[a] != j) continue;
-                      double rest = pre;
-                      for (int b2 = 0; b2 < n; ++b2)
-                        if (b2 != a) rest *= pick(idx[b2]);
-                      dp += rest;
-                    }
-                    Dr[j] = __builtin_fma(-w, dp, Dr[j]);
-                  }
-                }
-              }
-            }
-            if (wall && A.n_wk > 0) {   // implicit first-order surface kinetics, see fill_row
-              for (int q = 0; q < A.n_wk; ++q) {
-                const int sp = A.wk_species[q];
-                double nu = 0.0;
-#pragma unroll
-                for (int k = 0; k < N; ++k) nu = (k == r) ? A.wk_nu[q][k] : nu;
-                const double a = nu * wk[q] * fl_r;
-                const double cs = sp >= 0 ? c[sp * ldx] : 1.0;
-                rhs += a * cs;
-#pragma unroll
-                for (int j = 0; j < N; ++j) Dr[j] -= (j == sp) ? a : 0.0;
-              }
-            }
-            Xr[2 * NB] = rhs;
-          } else {
-            if (bulk) {
-              Xr[2 * NB] = -(p0 - phiB);
-              Dr[N] = 1.0;
-            } else if (wall) {
-              if (A.wall_bc == 0) {
-                Xr[2 * NB] = -(p0 - phiM);
-                Dr[N] = 1.0;
-              } else {
-                Xr[2 * NB] = -(wep * (pp - p0) + A.stern * (phiM - A.phi_pzc - p0));
-                Dr[N] = -wep - A.stern;
-                Xr[NB + N] = wep;
-              }
-            } else {
-              Xr[2 * NB] = -(wep * (pp - p0) - wem * (p0 - pm) + vi * rho);
-#pragma unroll
-              for (int k = 0; k < N; ++k) Dr[k] = vi * A.peq[k];
-              Dr[N] = -(wep + wem);
-              Xr[N] = wem;
-              Xr[NB + N] = wep;
-            }
-          }
+          team_assemble_row<NB, MODE>(A, G, c, co, phi, cb, wk, phiM, phiB, b, i, r, spec, strip, Dr, Xr);
           int myk;
           team_solve<NB, (MODE != 0)>(Dr, Xr, strip, r, myk);
           if (valid) {
@@ -1574,6 +1592,219 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sweep kernel for LARGE BATCHES of large blocks: ONE TEAM (NB lanes) PER OPERATING POINT, block Thomas along the grid.
+// Cyclic reduction spends a workgroup per operating point and streams every block row ~6 times per Newton iteration through
+// device memory (N = 8, nx = 4096: ~60 MB per operating point and iteration -- with thousands of lanes in flight that traffic,
+// not arithmetic, bounds the lane-team kernel above).  When the batch alone fills the chip the parallelism inside one grid is
+// not needed: a team walks its grid once forward (assemble row i, D'_i = D_i - L_i Ut_{i-1}, [Ut_i | rt_i] = D'_i^-1 [U_i | r_i -
+// L_i rt_{i-1}], one record of NB x (NB+1) doubles per row written to device memory) and once backward (x_i = rt_i - Ut_i
+// x_{i+1}): O(nx) work instead of O(nx log nx), each record written and read once (~6 MB per operating point and iteration
+// for N = 8, nx = 4096), no workgroup barrier anywhere -- the 64/NB teams of a wave do not interact and a wave is the workgroup.
+// Same assembly (team_assemble_row), damping, update and stopping rule as the lane-team kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+struct SweepLayout {
+  static constexpr int NW = (NB + 1 + 1) / 2 * 2;     // record of one block-row lane: Ut row (NB) + rt, padded to even
+  static constexpr int TPW = 64 / NB;
+  static constexpr int SL = ((NB + NB + NB + 1) + 1) / 2 * 2;      // strip: NB scalars + pivot row (NB of D, NB + 1 of X)
+  static constexpr int TILE = NB * (NB + 1) + (NB * (NB + 1)) % 2; // [Ut | rt] of the previous row
+  static constexpr int PER_TEAM = SL + TILE + NB + NB % 2;         // + the solution vector of the row below (back-substitution)
+};
+size_t newton_sweep_doubles(int nb, int nx) { return (size_t)nx * nb * ((nb + 2) / 2 * 2); }
+
+template <int NB, int MODE>
+__global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G) {
+  __shared__ NewtonArgs sA;
+  if (threadIdx.x == 0) sA = G;
+  __syncthreads();
+  using SL_ = SweepLayout<NB>;
+  constexpr int N = NB - 1, NW = SL_::NW, TPW = SL_::TPW, NY = NB + 1;
+  constexpr bool MPB = MODE >= 1;
+  __shared__ double sweep_lds[(TPW + 1) * SL_::PER_TEAM];
+  const int lane = threadIdx.x;
+  const int tw = lane / NB;
+  const int r0_ = lane - tw * NB;
+  const bool real_team = tw < TPW;
+  double* strip = sweep_lds + (size_t)tw * SL_::PER_TEAM;
+  double* tile = strip + SL_::SL;
+  double* xs = tile + SL_::TILE;
+  const int64_t gteam = (int64_t)blockIdx.x * TPW + (real_team ? tw : 0);
+  const int64_t nteams = (int64_t)gridDim.x * TPW;
+  double* W = G.sweep + (size_t)gteam * G.sweep_stride;
+  const bool spec = r0_ < N;
+  // CONTROL FLOW IS WAVE-UNIFORM: a team without a lane (tail of the batch, masked lane, the leftover lanes of the wave) and a
+  // team whose Newton iteration has converged run along on valid data with their state stores switched off, and the loops end
+  // on wave-wide votes.  (Letting teams diverge -- skip rounds, leave the Newton loop early -- produced wild addresses in the
+  // instances that spill registers: values spilled under a partial exec mask came back undefined for the other lanes.)
+  for (int64_t b0 = 0; b0 < G.B; b0 += nteams) {
+    const int64_t bt = b0 + gteam;
+    const bool have = real_team && bt < G.B && !(G.lane_mask && !G.lane_mask[bt < G.B ? bt : 0]);
+    const int64_t b = bt < G.B ? bt : G.B - 1;
+    const NewtonArgs& A = sA;
+    const int nx = A.nx, ldx = A.ldx;
+    double* c = G.c + (size_t)b * N * ldx;
+    double* co = G.c_old + (size_t)b * N * ldx;
+    double* phi = G.phi + (size_t)b * ldx;
+    const double* cb = G.cbulk + (size_t)b * N;
+    const double* wk = G.wk_k + (size_t)b * PNP_MAX_WALL_REACTIONS;
+    const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
+    int total_it = 0, st = PNP_STATUS_OK;
+    for (int step = 0; step < A.nsteps; ++step) {
+      if (have)
+        for (int e = r0_; e < N * ldx; e += NB) co[e] = c[e];
+      team_sync();
+      bool conv = false, done = !have;
+      double upd_prev = INFINITY;
+      int it_used = 0;
+      for (int it = 1; it <= A.maxit; ++it) {
+        // ---- forward: assemble, eliminate the sub-diagonal block with the previous row's record, solve, record ----------
+        for (int i = 0; i < nx; ++i) {
+          int r = r0_;
+          const NewtonArgs* Ap = &sA;
+          asm volatile("" : "+v"(r), "+v"(Ap));      // see newton_team_kernel: keeps per-lane constants out of spill slots
+          const NewtonArgs& A = *Ap;
+          double Dr[NB], Xr[2 * NB + 1];
+          team_assemble_row<NB, MODE>(A, G, c, co, phi, cb, wk, phiM, phiB, b, i, r, spec, strip, Dr, Xr);
+          double Y[NY];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) Y[j] = Xr[NB + j];
+          Y[NB] = Xr[2 * NB];
+          if (i > 0) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+              const double lq = Xr[q];
+              const double* prev = tile + q * NY;
+#pragma unroll
+              for (int j = 0; j < NB; ++j) Dr[j] = __builtin_fma(-lq, prev[j], Dr[j]);
+              Y[NB] = __builtin_fma(-lq, prev[NB], Y[NB]);
+            }
+          }
+          team_sync();
+          int myk;
+          team_solve_n<NB, NY, (MODE != 0)>(Dr, Y, strip, r, myk);
+          myk = myk < 0 ? r : myk;      // (a NaN block leaves a lane without a pivot; the lane's state is flagged below)
+          double* rec = W + ((size_t)i * NB + myk) * NW;
+#pragma unroll
+          for (int j = 0; j < NY; ++j) {
+            tile[myk * NY + j] = Y[j];
+            if (real_team) rec[j] = Y[j];        // (the leftover lanes of the wave have no records of their own)
+          }
+          team_sync();
+        }
+        // ---- backward: x_i = rt_i - Ut_i x_{i+1}; the update norms on the way -----------------------------------------
+        double mphi = 0.0, upd = 0.0;
+        {
+          const int r = r0_;
+          double x = 0.0;
+          for (int i = nx - 1; i >= 0; --i) {
+            double* rec = W + ((size_t)i * NB + r) * NW;
+            x = rec[NB];
+            if (i < nx - 1) {
+#pragma unroll
+              for (int j = 0; j < NB; ++j) x = __builtin_fma(-rec[j], xs[j], x);
+            }
+            team_sync();
+            xs[r] = x;
+            if (real_team) rec[NB] = x;
+            team_sync();
+            const double ck = c[(spec ? r : 0) * ldx + i];
+            const double rel = fabs(x) / (fabs(ck) + fabs(cb[spec ? r : 0]) + 1e-300);
+            const double a = fabs(x);
+            if (spec) {
+              upd = fmax(upd, rel);
+              if (!(x == x)) upd = INFINITY;
+            } else {
+              mphi = fmax(mphi, a);
+              if (!(a == a)) mphi = INFINITY;
+            }
+          }
+        }
+        auto team_max = [&](double v) {
+          strip[r0_] = v;
+          team_sync();
+          double m = 0.0;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) m = fmax(m, strip[j]);
+          team_sync();
+          return m;
+        };
+        mphi = team_max(mphi);
+        upd = team_max(upd);
+        upd = fmax(upd, mphi * A.vt_inv);
+        double lam = 1.0;
+        if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+        // ---- damping, clips, update (oracle/pnp_physical.py: newton_step), row by row ---------------------------------------
+        for (int i = 0; i < nx; ++i) {
+          const int r = r0_;
+          const double du = W[((size_t)i * NB + r) * NW + NB];
+          double cc_ = 0.0, cn = 0.0;
+          if (spec) {
+            cc_ = c[r * ldx + i];
+            const double t_ = __builtin_fma(lam, du, cc_);
+            const double lo = 0.1 * cc_;
+            cn = t_ < lo ? lo : t_;
+          }
+          if constexpr (MPB) {
+            strip[r] = cc_;
+            xs[r] = cn;
+            team_sync();
+            double f_old = 0.0, f_new = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              f_old = __builtin_fma(A.vol[k], strip[k], f_old);
+              f_new = __builtin_fma(A.vol[k], xs[k], f_new);
+            }
+            team_sync();
+            const double free_ = 1.0 - f_old;
+            const double target = fmax(0.1 * free_, 1e-12);
+            if ((1.0 - f_new) < target) {
+              const double theta = (free_ - target) / (f_new - f_old);
+              cn = __builtin_fma(theta, cn - cc_, cc_);
+            }
+          }
+          if (!done) {
+            if (spec) c[r * ldx + i] = cn;
+            else phi[i] = __builtin_fma(lam, du, phi[i]);
+          }
+        }
+        team_sync();
+        if (!done) {
+          if (lam == 1.0) {
+            if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol)) {
+              conv = true;
+              done = true;
+              it_used = it;
+            }
+            upd_prev = upd;
+          } else {
+            upd_prev = INFINITY;
+          }
+        }
+        if (__ballot(!done) == 0ull) break;       // every team of the wave has converged
+      }
+      total_it += conv ? it_used : A.maxit + 1;
+      if (!conv) st = PNP_STATUS_MAXIT;
+    }
+    double bad = 0.0;
+    for (int e = r0_; e < nx; e += NB) {
+      double sacc = phi[e];
+#pragma unroll
+      for (int k = 0; k < N; ++k) sacc += c[k * ldx + e];
+      if (!(fabs(sacc) < INFINITY)) bad = 1.0;
+    }
+    strip[r0_] = bad;
+    team_sync();
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bad = fmax(bad, strip[j]);
+    if (have && r0_ == 0) {
+      G.status[b] = bad > 0.0 ? PNP_STATUS_NAN : st;
+      G.iters[b] = total_it;
+    }
+    team_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static constexpr size_t kLdsBudget = 160 * 1024 - 512;
@@ -1662,10 +1893,32 @@ static hipError_t launch_team(const NewtonArgs& a, int blocks, hipStream_t strea
   return hipGetLastError();
 }
 
+// sweep kernel: one wave per workgroup, 64/NB operating points per wave
+template <int NB>
+static hipError_t launch_sweep(const NewtonArgs& a, hipStream_t stream) {
+  constexpr int TPW = SweepLayout<NB>::TPW;
+  int64_t blocks = (a.B + TPW - 1) / TPW;
+  if (blocks > a.sweep_blocks) blocks = a.sweep_blocks;
+  if (a.rt) hipLaunchKernelGGL((newton_sweep_kernel<NB, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  else if (a.mpb) hipLaunchKernelGGL((newton_sweep_kernel<NB, 1>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((newton_sweep_kernel<NB, 0>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+// Large blocks and a batch that fills the chip with teams on its own (measured): the sweep kernel.
+bool newton_sweep_preferred(int nb, int nx, int64_t B) {
+  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 's' && nb >= 3;
+  (void)nx;
+  return nb >= 6 && B >= 4096;
+}
+
 template <int NB, int TMAX>
 static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t stream) {
   const char* force = getenv("CATINT_NEWTON_KERNEL");     // "generic" forces the row-per-thread kernel (tests)
   const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
+  if constexpr (NB >= 3) {
+    if (a.sweep && a.sweep_blocks > 0 && newton_sweep_preferred(NB, a.nx, a.B)) return launch_sweep<NB>(a, stream);
+  }
   if constexpr (NB >= 3) {     // lane teams: every large block, and the N = 2..4 grids too long for the pair kernel
     if (a.work && !(force && force[0] == 'g') && (NB >= 6 || tp == 0 || (force && force[0] == 't'))) return launch_team<NB>(a, blocks, stream);
   }

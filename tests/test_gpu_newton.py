@@ -132,6 +132,30 @@ def test_row_per_thread_kernel(N, nx, monkeypatch):
     assert_close(got, ref)
 
 
+@pytest.mark.parametrize("N,nx,blocks", [(2, 64, 0), (3, 130, 0), (5, 70, 0), (6, 96, 1), (7, 50, 2), (8, 40, 1)])
+def test_sweep_kernel(N, nx, blocks, monkeypatch):
+    # block Thomas with one lane team per operating point (the large-batch kernel for large blocks), forced onto small batches;
+    # blocks > 0 caps its workgroups so that every team walks several operating points one after the other, with teams of a
+    # wave running out of lanes at different times
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'sweep')
+    if blocks:
+        monkeypatch.setenv('CATINT_NEWTON_SWEEP_BLOCKS', str(blocks))
+    kw = {'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * N} if N >= 6 else {}
+    got, ref = run_both(N, nx, B=23, seed=N * 31 + nx, newton_kw=kw)
+    assert_close(got, ref)
+
+
+def test_sweep_kernel_is_the_default_for_large_batches_of_large_blocks(monkeypatch):
+    # B >= 4096 lanes of N >= 5 species take the sweep kernel: same answers and iteration counts as the lane-team kernel
+    N, nx, B = 5, 24, 4096
+    a = run_gpu_only(N, nx, B, 5)
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'team')
+    b = run_gpu_only(N, nx, B, 5)
+    assert np.abs(a[0] - b[0]).max() <= 1e-9 * np.abs(b[0]).max() and np.abs(a[1] - b[1]).max() <= 1e-10
+    assert np.array_equal(a[2], b[2]) and (a[2] <= 50).all()
+    assert not np.array_equal(a[0], b[0])            # (two different linear solvers: not the same bits)
+
+
 @pytest.mark.parametrize("N,nx", [(3, 513), (2, 1030), (3, 1200)])
 def test_more_rows_than_threads(N, nx):
     got, ref = run_both(N, nx, B=3, seed=nx, points_per_debye=20.0)
