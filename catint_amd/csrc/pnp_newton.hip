@@ -1909,7 +1909,9 @@ static hipError_t launch_sweep(const NewtonArgs& a, hipStream_t stream) {
 bool newton_sweep_preferred(int nb, int nx, int64_t B) {
   if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 's' && nb >= 3;
   (void)nx;
-  return nb >= 6 && B >= 4096;
+  // at least one wave of teams per SIMD (1024 SIMDs): below that the chip is not full and, with uniform control flow, a wave
+  // waits for its slowest lane -- the CO2R example (7 species, 4096 lanes, iteration counts 3...30) took 0.84 s instead of 0.51 s
+  return nb >= 6 && (B + 64 / nb - 1) / (64 / nb) >= 1024;
 }
 
 template <int NB, int TMAX>

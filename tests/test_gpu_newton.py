@@ -146,8 +146,9 @@ def test_sweep_kernel(N, nx, blocks, monkeypatch):
 
 
 def test_sweep_kernel_is_the_default_for_large_batches_of_large_blocks(monkeypatch):
-    # B >= 4096 lanes of N >= 5 species take the sweep kernel: same answers and iteration counts as the lane-team kernel
-    N, nx, B = 5, 24, 4096
+    # N >= 5 species and at least 1024 waves of lane teams (10 operating points per wave at N = 5) take the sweep kernel: same
+    # answers and iteration counts as the lane-team kernel
+    N, nx, B = 5, 24, 10240
     a = run_gpu_only(N, nx, B, 5)
     monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'team')
     b = run_gpu_only(N, nx, B, 5)
