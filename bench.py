@@ -164,6 +164,26 @@ def physical_mode(args, device, with_cpu):
                                 'lanes_ok': ok8}
     except Exception as e:      # never let the extra line break the headline
         out['config4_shape'] = {'error': str(e)}
+    # large batch of large blocks: the sweep kernel (block Thomas, one lane team per operating point)
+    try:
+        SB = 8192
+        p8, c8, pb8, vz8, fl8 = make_batch(SB, 8, 512, seed=4444, phi_max=0.2, dt_factor=0.1)
+        s8 = _capi.PnpSolver(8, 512, p8.dx, p8.dt, p8.beta, p8.eps, p8.D, p8.charges, method='Newton', batch_capacity=SB, device=device)
+        s8.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=1e-8, mpb_radius=[4.1e-10, 3.6e-10, 3.3e-10, 3e-10, 3e-10, 3e-10, 4.5e-10, 3.5e-10])
+        s8.set_batch(c8, np.nan_to_num(pb8), vz8, fl8)
+        s8.step(1)
+        s8.synchronize()
+        s8.timer_start()
+        s8.step(4)
+        ms8 = s8.timer_stop()
+        it8 = s8.newton_iterations()
+        ok8 = int((s8.get_status() == 0).sum())
+        s8.close()
+        out['large_batch_8_species'] = {'workload': 'batch=%d, 8 species size-modified, 512 points, Stern wall (sweep kernel)' % SB,
+                                        'timesteps_per_s': SB * 4 / (ms8 * 1e-3), 'newton_iterations_per_s': float(it8.sum()) / (ms8 * 1e-3),
+                                        'lanes_ok': ok8}
+    except Exception as e:
+        out['large_batch_8_species'] = {'error': str(e)}
     if with_cpu:
         from oracle import pnp_physical as PH
         nl, ns = 2, 2

@@ -1632,175 +1632,201 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
   const int64_t nteams = (int64_t)gridDim.x * TPW;
   double* W = G.sweep + (size_t)gteam * G.sweep_stride;
   const bool spec = r0_ < N;
-  // CONTROL FLOW IS WAVE-UNIFORM: a team without a lane (tail of the batch, masked lane, the leftover lanes of the wave) and a
-  // team whose Newton iteration has converged run along on valid data with their state stores switched off, and the loops end
-  // on wave-wide votes.  (Letting teams diverge -- skip rounds, leave the Newton loop early -- produced wild addresses in the
-  // instances that spill registers: values spilled under a partial exec mask came back undefined for the other lanes.)
-  for (int64_t b0 = 0; b0 < G.B; b0 += nteams) {
-    const int64_t bt = b0 + gteam;
-    const bool have = real_team && bt < G.B && !(G.lane_mask && !G.lane_mask[bt < G.B ? bt : 0]);
-    const int64_t b = bt < G.B ? bt : G.B - 1;
+  // CONTROL FLOW IS WAVE-UNIFORM.  The kernel is an iteration engine: every pass of the loop below is ONE Newton iteration of
+  // whatever operating point each team currently holds; a team that finishes its point (all timesteps converged or out of
+  // iterations) takes its next one (gteam, gteam + nteams, ...) at the top of the next pass, so the teams of a wave never wait
+  // for each other's iteration counts.  A team without work (batch exhausted, masked lane, the leftover lanes of the wave) runs
+  // along on valid data with its state stores switched off, and the loop ends on a wave-wide vote.  (Letting teams diverge --
+  // skip rounds, leave a Newton loop early -- produced wild addresses in the instances that spill registers: values spilled
+  // under a partial exec mask came back undefined for the other lanes.)
+  const int nx = sA.nx, ldx = sA.ldx;
+  int64_t bnext = gteam;          // the team's next operating point
+  int64_t b = 0;                  // ... and its current one (valid memory even while the team has no work)
+  bool have = false, fresh = false;
+  int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
+  double upd_prev = INFINITY;
+  for (;;) {
+    if (!have && real_team && bnext < G.B) {
+      b = bnext;
+      bnext += nteams;
+      have = !(G.lane_mask && !G.lane_mask[b]);
+      fresh = true;
+      step = 0;
+      total_it = 0;
+      st = PNP_STATUS_OK;
+    }
+    if (__ballot(have) == 0ull) {
+      if (__ballot(real_team && bnext < G.B) == 0ull) break;
+      continue;                   // (only masked lanes were drawn: draw again)
+    }
     const NewtonArgs& A = sA;
-    const int nx = A.nx, ldx = A.ldx;
     double* c = G.c + (size_t)b * N * ldx;
     double* co = G.c_old + (size_t)b * N * ldx;
     double* phi = G.phi + (size_t)b * ldx;
     const double* cb = G.cbulk + (size_t)b * N;
     const double* wk = G.wk_k + (size_t)b * PNP_MAX_WALL_REACTIONS;
     const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
-    int total_it = 0, st = PNP_STATUS_OK;
-    for (int step = 0; step < A.nsteps; ++step) {
-      if (have)
-        for (int e = r0_; e < N * ldx; e += NB) co[e] = c[e];
+    // ---- start of a timestep: previous time level ------------------------------------------------------------------------
+    if (__ballot(have && fresh) != 0ull) {
+      for (int e = r0_; e < N * ldx; e += NB) {
+        const double v = c[e];
+        if (have && fresh) co[e] = v;
+      }
       team_sync();
-      bool conv = false, done = !have;
-      double upd_prev = INFINITY;
-      int it_used = 0;
-      for (int it = 1; it <= A.maxit; ++it) {
-        // ---- forward: assemble, eliminate the sub-diagonal block with the previous row's record, solve, record ----------
-        for (int i = 0; i < nx; ++i) {
-          int r = r0_;
-          const NewtonArgs* Ap = &sA;
-          asm volatile("" : "+v"(r), "+v"(Ap));      // see newton_team_kernel: keeps per-lane constants out of spill slots
-          const NewtonArgs& A = *Ap;
-          double Dr[NB], Xr[2 * NB + 1];
-          team_assemble_row<NB, MODE>(A, G, c, co, phi, cb, wk, phiM, phiB, b, i, r, spec, strip, Dr, Xr);
-          double Y[NY];
+    }
+    if (fresh) {
+      it = 0;
+      upd_prev = INFINITY;
+      fresh = false;
+    }
+    it += 1;
+    // ---- forward: assemble, eliminate the sub-diagonal block with the previous row's record, solve, record ------------------
+    for (int i = 0; i < nx; ++i) {
+      int r = r0_;
+      const NewtonArgs* Ap = &sA;
+      asm volatile("" : "+v"(r), "+v"(Ap));      // see newton_team_kernel: keeps per-lane constants out of spill slots
+      const NewtonArgs& A = *Ap;
+      double Dr[NB], Xr[2 * NB + 1];
+      team_assemble_row<NB, MODE>(A, G, c, co, phi, cb, wk, phiM, phiB, b, i, r, spec, strip, Dr, Xr);
+      double Y[NY];
 #pragma unroll
-          for (int j = 0; j < NB; ++j) Y[j] = Xr[NB + j];
-          Y[NB] = Xr[2 * NB];
-          if (i > 0) {
+      for (int j = 0; j < NB; ++j) Y[j] = Xr[NB + j];
+      Y[NB] = Xr[2 * NB];
+      if (i > 0) {
 #pragma unroll
-            for (int q = 0; q < NB; ++q) {
-              const double lq = Xr[q];
-              const double* prev = tile + q * NY;
+        for (int q = 0; q < NB; ++q) {
+          const double lq = Xr[q];
+          const double* prev = tile + q * NY;
 #pragma unroll
-              for (int j = 0; j < NB; ++j) Dr[j] = __builtin_fma(-lq, prev[j], Dr[j]);
-              Y[NB] = __builtin_fma(-lq, prev[NB], Y[NB]);
-            }
-          }
-          team_sync();
-          int myk;
-          team_solve_n<NB, NY, (MODE != 0)>(Dr, Y, strip, r, myk);
-          myk = myk < 0 ? r : myk;      // (a NaN block leaves a lane without a pivot; the lane's state is flagged below)
-          double* rec = W + ((size_t)i * NB + myk) * NW;
-#pragma unroll
-          for (int j = 0; j < NY; ++j) {
-            tile[myk * NY + j] = Y[j];
-            if (real_team) rec[j] = Y[j];        // (the leftover lanes of the wave have no records of their own)
-          }
-          team_sync();
+          for (int j = 0; j < NB; ++j) Dr[j] = __builtin_fma(-lq, prev[j], Dr[j]);
+          Y[NB] = __builtin_fma(-lq, prev[NB], Y[NB]);
         }
-        // ---- backward: x_i = rt_i - Ut_i x_{i+1}; the update norms on the way -----------------------------------------
-        double mphi = 0.0, upd = 0.0;
-        {
-          const int r = r0_;
-          double x = 0.0;
-          for (int i = nx - 1; i >= 0; --i) {
-            double* rec = W + ((size_t)i * NB + r) * NW;
-            x = rec[NB];
-            if (i < nx - 1) {
+      }
+      team_sync();
+      int myk;
+      team_solve_n<NB, NY, (MODE != 0)>(Dr, Y, strip, r, myk);
+      myk = myk < 0 ? r : myk;      // (a NaN block leaves a lane without a pivot; the lane's state is flagged at the end)
+      double* rec = W + ((size_t)i * NB + myk) * NW;
 #pragma unroll
-              for (int j = 0; j < NB; ++j) x = __builtin_fma(-rec[j], xs[j], x);
-            }
-            team_sync();
-            xs[r] = x;
-            if (real_team) rec[NB] = x;
-            team_sync();
-            const double ck = c[(spec ? r : 0) * ldx + i];
-            const double rel = fabs(x) / (fabs(ck) + fabs(cb[spec ? r : 0]) + 1e-300);
-            const double a = fabs(x);
-            if (spec) {
-              upd = fmax(upd, rel);
-              if (!(x == x)) upd = INFINITY;
-            } else {
-              mphi = fmax(mphi, a);
-              if (!(a == a)) mphi = INFINITY;
-            }
-          }
-        }
-        auto team_max = [&](double v) {
-          strip[r0_] = v;
-          team_sync();
-          double m = 0.0;
+      for (int j = 0; j < NY; ++j) {
+        tile[myk * NY + j] = Y[j];
+        if (real_team) rec[j] = Y[j];        // (the leftover lanes of the wave have no records of their own)
+      }
+      team_sync();
+    }
+    // ---- backward: x_i = rt_i - Ut_i x_{i+1}; the update norms on the way -------------------------------------------------
+    double mphi = 0.0, upd = 0.0;
+    {
+      const int r = r0_;
+      for (int i = nx - 1; i >= 0; --i) {
+        double* rec = W + ((size_t)i * NB + r) * NW;
+        double x = rec[NB];
+        if (i < nx - 1) {
 #pragma unroll
-          for (int j = 0; j < NB; ++j) m = fmax(m, strip[j]);
-          team_sync();
-          return m;
-        };
-        mphi = team_max(mphi);
-        upd = team_max(upd);
-        upd = fmax(upd, mphi * A.vt_inv);
-        double lam = 1.0;
-        if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
-        // ---- damping, clips, update (oracle/pnp_physical.py: newton_step), row by row ---------------------------------------
-        for (int i = 0; i < nx; ++i) {
-          const int r = r0_;
-          const double du = W[((size_t)i * NB + r) * NW + NB];
-          double cc_ = 0.0, cn = 0.0;
-          if (spec) {
-            cc_ = c[r * ldx + i];
-            const double t_ = __builtin_fma(lam, du, cc_);
-            const double lo = 0.1 * cc_;
-            cn = t_ < lo ? lo : t_;
-          }
-          if constexpr (MPB) {
-            strip[r] = cc_;
-            xs[r] = cn;
-            team_sync();
-            double f_old = 0.0, f_new = 0.0;
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-              f_old = __builtin_fma(A.vol[k], strip[k], f_old);
-              f_new = __builtin_fma(A.vol[k], xs[k], f_new);
-            }
-            team_sync();
-            const double free_ = 1.0 - f_old;
-            const double target = fmax(0.1 * free_, 1e-12);
-            if ((1.0 - f_new) < target) {
-              const double theta = (free_ - target) / (f_new - f_old);
-              cn = __builtin_fma(theta, cn - cc_, cc_);
-            }
-          }
-          if (!done) {
-            if (spec) c[r * ldx + i] = cn;
-            else phi[i] = __builtin_fma(lam, du, phi[i]);
-          }
+          for (int j = 0; j < NB; ++j) x = __builtin_fma(-rec[j], xs[j], x);
         }
         team_sync();
-        if (!done) {
-          if (lam == 1.0) {
-            if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol)) {
-              conv = true;
-              done = true;
-              it_used = it;
-            }
-            upd_prev = upd;
-          } else {
-            upd_prev = INFINITY;
-          }
+        xs[r] = x;
+        if (real_team) rec[NB] = x;
+        team_sync();
+        const double ck = c[(spec ? r : 0) * ldx + i];
+        const double rel = fabs(x) / (fabs(ck) + fabs(cb[spec ? r : 0]) + 1e-300);
+        const double a = fabs(x);
+        if (spec) {
+          upd = fmax(upd, rel);
+          if (!(x == x)) upd = INFINITY;
+        } else {
+          mphi = fmax(mphi, a);
+          if (!(a == a)) mphi = INFINITY;
         }
-        if (__ballot(!done) == 0ull) break;       // every team of the wave has converged
       }
-      total_it += conv ? it_used : A.maxit + 1;
-      if (!conv) st = PNP_STATUS_MAXIT;
     }
-    double bad = 0.0;
-    for (int e = r0_; e < nx; e += NB) {
-      double sacc = phi[e];
+    auto team_max = [&](double v) {
+      strip[r0_] = v;
+      team_sync();
+      double m = 0.0;
 #pragma unroll
-      for (int k = 0; k < N; ++k) sacc += c[k * ldx + e];
-      if (!(fabs(sacc) < INFINITY)) bad = 1.0;
-    }
-    strip[r0_] = bad;
-    team_sync();
+      for (int j = 0; j < NB; ++j) m = fmax(m, strip[j]);
+      team_sync();
+      return m;
+    };
+    mphi = team_max(mphi);
+    upd = team_max(upd);
+    upd = fmax(upd, mphi * A.vt_inv);
+    double lam = 1.0;
+    if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+    // ---- damping, clips, update (oracle/pnp_physical.py: newton_step), row by row -----------------------------------------
+    for (int i = 0; i < nx; ++i) {
+      const int r = r0_;
+      const double du = W[((size_t)i * NB + r) * NW + NB];
+      double cc_ = 0.0, cn = 0.0;
+      if (spec) {
+        cc_ = c[r * ldx + i];
+        const double t_ = __builtin_fma(lam, du, cc_);
+        const double lo = 0.1 * cc_;
+        cn = t_ < lo ? lo : t_;
+      }
+      if constexpr (MPB) {
+        strip[r] = cc_;
+        xs[r] = cn;
+        team_sync();
+        double f_old = 0.0, f_new = 0.0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) bad = fmax(bad, strip[j]);
-    if (have && r0_ == 0) {
-      G.status[b] = bad > 0.0 ? PNP_STATUS_NAN : st;
-      G.iters[b] = total_it;
+        for (int k = 0; k < N; ++k) {
+          f_old = __builtin_fma(A.vol[k], strip[k], f_old);
+          f_new = __builtin_fma(A.vol[k], xs[k], f_new);
+        }
+        team_sync();
+        const double free_ = 1.0 - f_old;
+        const double target = fmax(0.1 * free_, 1e-12);
+        if ((1.0 - f_new) < target) {
+          const double theta = (free_ - target) / (f_new - f_old);
+          cn = __builtin_fma(theta, cn - cc_, cc_);
+        }
+      }
+      if (have) {
+        if (spec) c[r * ldx + i] = cn;
+        else phi[i] = __builtin_fma(lam, du, phi[i]);
+      }
     }
     team_sync();
+    // ---- bookkeeping of the team's operating point: iteration -> timestep -> finished -------------------------------------
+    bool finished = false;
+    if (have) {
+      bool accept = false;
+      if (lam == 1.0) {
+        accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol);
+        upd_prev = upd;
+      } else {
+        upd_prev = INFINITY;
+      }
+      if (accept || it >= A.maxit) {
+        total_it += accept ? it : A.maxit + 1;
+        if (!accept) st = PNP_STATUS_MAXIT;
+        step += 1;
+        fresh = true;
+        finished = step >= A.nsteps;
+      }
+    }
+    if (__ballot(finished) != 0ull) {
+      double bad = 0.0;
+      for (int e = r0_; e < nx; e += NB) {
+        double sacc = phi[e];
+#pragma unroll
+        for (int k = 0; k < N; ++k) sacc += c[k * ldx + e];
+        if (!(fabs(sacc) < INFINITY)) bad = 1.0;
+      }
+      strip[r0_] = bad;
+      team_sync();
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bad = fmax(bad, strip[j]);
+      if (finished && r0_ == 0) {
+        G.status[b] = bad > 0.0 ? PNP_STATUS_NAN : st;
+        G.iters[b] = total_it;
+      }
+      team_sync();
+    }
+    if (finished) have = false;
   }
 }
 
