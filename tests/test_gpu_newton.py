@@ -317,6 +317,40 @@ def test_config2_batch_physical_mode_full_size_properties():
         assert np.abs(c[b] - rc).max() <= 2e-9 * np.abs(rc).max() and np.abs(phi[b] - rphi).max() <= 2e-9 * 0.2
 
 
+def test_config4_per_gpu_share_through_the_sweep_kernel():
+    """BASELINE configs[3] (6 species x 1024 points, 262144 lanes over 8 GPUs): one GPU's 32768 lanes, size-modified with a Stern
+    wall, two implicit timesteps -- the batch takes the sweep kernel.  Every lane converges, sampled lanes equal the oracle, and
+    a lane does not depend on its position in the batch (teams pick lanes up in a different order)."""
+    from catint_amd.synthetic import make_batch
+    B, N, nx = 32768, 6, 1024
+    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=6, phi_max=0.2, dt_factor=0.1)
+    pb = np.nan_to_num(pb)
+    radii = [4.1e-10, 3.6e-10, 3.3e-10, 3e-10, 0.0, 3e-10]
+    kw = dict(wall_bc='stern', stern_capacitance=0.2, tol=1e-9, mpb_radius=radii)
+
+    def solve(idx, steps):
+        with _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=len(idx)) as s:
+            s.set_newton(**kw)
+            s.set_batch(c0[idx], pb[idx], vz[idx], fl[idx])
+            s.step(steps)
+            cs, vs, es = s.get_surface()
+            return cs, vs, s.newton_iterations(), s.get_status(), (s.get_state() if len(idx) <= 64 else None)
+    cs, vs, its, st, _ = solve(np.arange(B), 2)
+    assert np.all(st == 0) and np.all(np.isfinite(cs)) and cs.min() > 0 and its.min() >= 4 and its.max() <= 2 * 50
+    sub = np.array([0, 7, 12345, 32767])
+    cs3, vs3, its3, st3, full = solve(np.concatenate([sub, np.arange(100, 160)]), 2)      # 64 lanes: the lane-team kernel
+    assert np.array_equal(its3[:4], its[sub])
+    assert np.abs(cs3[:4] - cs[sub]).max() <= 1e-9 * np.abs(cs).max() and np.abs(vs3[:4] - vs[sub]).max() <= 1e-10
+    c, phi = full[0], full[1]
+    for j, b in enumerate(sub[:2]):
+        p = PH.PhysicalProblem(D=prob.D, charges=prob.charges, beta=prob.beta, eps=prob.eps, dx=prob.dx, nx=nx,
+                               c_bulk=c0[b].reshape(N, nx)[:, -1], phiM=pb[b, 0], stern_capacitance=0.2, mpb_radius=radii)
+        rc, rphi, rit = PH.integrate(p, c0[b].reshape(N, nx), np.zeros(nx), prob.dt, 2, tol=1e-9)
+        assert sum(rit) == its[b]
+        assert np.abs(c[j] - rc).max() <= 2e-9 * np.abs(rc).max() and np.abs(phi[j] - rphi).max() <= 2e-9 * 0.2
+        assert np.abs(cs[b] - rc[:, 0]).max() <= 2e-9 * np.abs(rc).max()
+
+
 def test_config5_shape_size_modified_eight_species_4096_points():
     """BASELINE configs[4]: 8-species size-modified PNP on 4096 grid points (lane-team kernel), two lanes against the oracle."""
     a = [4.1e-10, 3.0e-10, 3.3e-10, 3.6e-10, 0.0, 3.5e-10, 3.2e-10, 0.0]
