@@ -1645,6 +1645,9 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
   bool have = false, fresh = false;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
   double upd_prev = INFINITY;
+#ifdef PNP_SWEEP_STAMPS
+  int stamp_code = 0, stamp_cycles = 0;
+#endif
   for (;;) {
     if (!have && real_team && bnext < G.B) {
       b = bnext;
@@ -1680,6 +1683,9 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
       fresh = false;
     }
     it += 1;
+#ifdef PNP_SWEEP_STAMPS
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
     // ---- forward: assemble, eliminate the sub-diagonal block with the previous row's record, solve, record ------------------
     for (int i = 0; i < nx; ++i) {
       int r = r0_;
@@ -1714,6 +1720,9 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
       }
       team_sync();
     }
+#ifdef PNP_SWEEP_STAMPS
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
     // ---- backward: x_i = rt_i - Ut_i x_{i+1}; the update norms on the way -------------------------------------------------
     double mphi = 0.0, upd = 0.0;
     {
@@ -1755,6 +1764,9 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
     upd = fmax(upd, mphi * A.vt_inv);
     double lam = 1.0;
     if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+#ifdef PNP_SWEEP_STAMPS
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
     // ---- damping, clips, update (oracle/pnp_physical.py: newton_step), row by row -----------------------------------------
     for (int i = 0; i < nx; ++i) {
       const int r = r0_;
@@ -1790,6 +1802,14 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
       }
     }
     team_sync();
+#ifdef PNP_SWEEP_STAMPS
+    {   // diagnosis build: per-mille shares of the forward and backward passes of the LAST iteration, cycles per row in the rest
+      const unsigned long long ts3 = __builtin_readcyclecounter();
+      const double tot = (double)(ts3 - ts0);
+      stamp_code = (int)(1000.0 * (double)(ts1 - ts0) / tot) + 1000 * (int)(1000.0 * (double)(ts2 - ts1) / tot);
+      stamp_cycles = (int)(tot / nx);
+    }
+#endif
     // ---- bookkeeping of the team's operating point: iteration -> timestep -> finished -------------------------------------
     bool finished = false;
     if (have) {
@@ -1823,6 +1843,10 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
       if (finished && r0_ == 0) {
         G.status[b] = bad > 0.0 ? PNP_STATUS_NAN : st;
         G.iters[b] = total_it;
+#ifdef PNP_SWEEP_STAMPS
+        G.iters[b] = stamp_code;
+        G.status[b] = stamp_cycles;
+#endif
       }
       team_sync();
     }
