@@ -1716,7 +1716,9 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
 #pragma unroll
       for (int j = 0; j < NY; ++j) {
         tile[myk * NY + j] = Y[j];
+#ifndef PNP_SWEEP_NOSTORE
         if (real_team) rec[j] = Y[j];        // (the leftover lanes of the wave have no records of their own)
+#endif
       }
       team_sync();
     }
