@@ -270,7 +270,7 @@ def main():
     # one launch per timestep (state read from and written to HBM by every launch) -- reported next to the headline
     fused = None
     if not args.no_fused and args.steps_per_launch != 1:
-        solver.step(16, 1)
+        solver.step(64, 1)
         fw, fe = timed(args.steps, 1)
         lsec = fe * 1e-3 / args.steps
         fused = {'timesteps_per_s': world * B * args.steps / fw, 'ms_per_step': fw / args.steps * 1e3,
@@ -298,7 +298,7 @@ def main():
         lp, lc0, lpb, lvz, lfl = make_batch(LB, N, nx, seed=77, phi_max=0.025, dt_factor=1e-5)
         s2 = solver_from_problem(lp, args.method, batch_capacity=LB, device=device)
         s2.set_batch(lc0, lpb, lvz, lfl)
-        s2.step(16, 1)
+        s2.step(64, 1)
         ls = max(10, min(args.steps, 50))
         s2.synchronize()
         s2.timer_start()
