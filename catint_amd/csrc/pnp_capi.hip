@@ -414,7 +414,9 @@ static int run_steps(pnp_handle* h, int nsteps) {
   }
   // Fused launches: the LDS-staged kernel with one species per wave (choose_step_config) at every batch size
   // (0.75-0.78 of the roofline for B = 1024...16384 against 0.52-0.63), measured with CATINT_PNP_KERNEL=2/4
-  bool rr = step_rr_applicable(a) && a.B >= 2048 && h->P <= 8 && nsteps < 8;
+  // ... except for N >= 5 species (more than the waves of a workgroup hold one each) at B >= 4096, where the register-resident
+  // kernel is ahead again (N = 6: 0.65-0.71 against 0.59-0.65; N = 8: 0.65-0.69 against 0.57-0.63)
+  bool rr = step_rr_applicable(a) && h->P <= 8 && ((nsteps < 8 && a.B >= 2048) || (nsteps >= 8 && a.N >= 5 && a.B >= 4096));
   if (h->kernel_override == 2) rr = false;
   if (h->kernel_override == 4) rr = step_rr_applicable(a);
   if (rr) {
