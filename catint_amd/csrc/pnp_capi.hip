@@ -414,13 +414,23 @@ static int run_steps(pnp_handle* h, int nsteps) {
   }
   // Fused launches: the LDS-staged kernel with one species per wave (choose_step_config) at every batch size
   // (0.75-0.78 of the roofline for B = 1024...16384 against 0.52-0.63), measured with CATINT_PNP_KERNEL=2/4
-  // ... except for N >= 5 species (more than the waves of a workgroup hold one each) at B >= 4096, where the register-resident
-  // kernel is ahead again (N = 6: 0.65-0.71 against 0.59-0.65; N = 8: 0.65-0.69 against 0.57-0.63)
-  bool rr = step_rr_applicable(a) && h->P <= 8 && ((nsteps < 8 && a.B >= 2048) || (nsteps >= 8 && a.N >= 5 && a.B >= 4096));
+  // ... except where one species per wave does not pay (tools/probe/step_config_probe.py): N >= 5 species (more than the waves
+  // of a workgroup hold one each; N = 6: 0.65-0.71 against 0.53-0.65, N = 8: 0.65-0.69 against 0.57-0.63) and short grids
+  // (at most 4 points per lane; N = 2, nx = 200: 0.52-0.65 against 0.48-0.51, N = 3, nx = 256: 0.62-0.70 against 0.47-0.57)
+  // from B = 2048 lanes on: the register-resident kernel, one wave per lane.  Two points per lane at small batch: the same
+  // kernel with one species per wave (N = 3, nx = 128, B = 1024: 0.35 against 0.19-0.28).
+  const bool fused = nsteps >= 8;
+  bool rr = step_rr_applicable(a) && h->P <= 8 &&
+            ((!fused && a.B >= 2048) || (fused && a.B >= 2048 && (h->P <= 4 || a.N >= 5)));
+  int rr_waves = 1;
+  if (fused && step_rr_applicable(a) && h->P == 2 && a.B < 2048) {
+    rr = true;
+    rr_waves = a.N < 3 ? a.N : 3;
+  }
   if (h->kernel_override == 2) rr = false;
   if (h->kernel_override == 4) rr = step_rr_applicable(a);
   if (rr) {
-    int w = 1;
+    int w = rr_waves;
     if (h->waves_override >= 1 && h->waves_override <= 4) w = h->waves_override;
     HIP_TRY(h, launch_step_rr(a, w, h->stream));
   } else {
