@@ -489,7 +489,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.rt = (h->rt_dev && h->rt.n > 0) ? h->rt_dev : nullptr;
   a.n_wk = h->newton_explicit_kinetics ? 0 : h->n_wk;
   a.lane_mask = h->newton_mask;
-  if (newton_sweep_preferred(N + 1, nx, h->B)) {
+  if (newton_sweep_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0))) {
     // one team (N+1 lanes) per operating point, 64/(N+1) per wave; the workspace holds the records of the resident waves: at
     // most four per SIMD, all of the batch capacity, and 32 GiB
     const int64_t tpw = 64 / (N + 1);

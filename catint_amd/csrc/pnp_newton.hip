@@ -1985,12 +1985,15 @@ static hipError_t launch_sweep(const NewtonArgs& a, hipStream_t stream) {
 }
 
 // Large blocks and a batch that fills the chip with teams on its own (measured): the sweep kernel.
-bool newton_sweep_preferred(int nb, int nx, int64_t B) {
+bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode) {
   if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 's' && nb >= 3;
   (void)nx;
   // at least one wave of teams per SIMD (1024 SIMDs): below that the chip is not full and, with uniform control flow, a wave
   // waits for its slowest lane -- the CO2R example (7 species, 4096 lanes, iteration counts 3...30) took 0.84 s instead of 0.51 s
-  return nb >= 6 && (B + 64 / nb - 1) / (64 / nb) >= 1024;
+  const int64_t waves = (B + 64 / nb - 1) / (64 / nb);
+  if (nb >= 6) return waves >= 1024;
+  // N = 4 with steric ions or reactions: the pair kernel spills there (2.5e6 iterations/s against 3.0-3.6e6; equal for point ions)
+  return nb == 5 && mode >= 1 && waves >= 1280;
 }
 
 template <int NB, int TMAX>
@@ -1998,7 +2001,7 @@ static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t 
   const char* force = getenv("CATINT_NEWTON_KERNEL");     // "generic" forces the row-per-thread kernel (tests)
   const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
   if constexpr (NB >= 3) {
-    if (a.sweep && a.sweep_blocks > 0 && newton_sweep_preferred(NB, a.nx, a.B)) return launch_sweep<NB>(a, stream);
+    if (a.sweep && a.sweep_blocks > 0 && newton_sweep_preferred(NB, a.nx, a.B, a.rt ? 2 : (a.mpb ? 1 : 0))) return launch_sweep<NB>(a, stream);
   }
   if constexpr (NB >= 3) {     // lane teams: every large block, and the N = 2..4 grids too long for the pair kernel
     if (a.work && !(force && force[0] == 'g') && (NB >= 6 || tp == 0 || (force && force[0] == 't'))) return launch_team<NB>(a, blocks, stream);
