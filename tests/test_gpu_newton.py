@@ -132,7 +132,7 @@ def test_row_per_thread_kernel(N, nx, monkeypatch):
     assert_close(got, ref)
 
 
-@pytest.mark.parametrize("N,nx,blocks", [(2, 64, 0), (3, 130, 0), (5, 70, 0), (6, 96, 1), (7, 50, 2), (8, 40, 1)])
+@pytest.mark.parametrize("N,nx,blocks", [(2, 64, 0), (3, 130, 0), (4, 77, 1), (5, 70, 0), (6, 96, 1), (7, 50, 2), (8, 40, 1)])
 def test_sweep_kernel(N, nx, blocks, monkeypatch):
     # block Thomas with one lane team per operating point (the large-batch kernel for large blocks), forced onto small batches;
     # blocks > 0 caps its workgroups so that every team walks several operating points one after the other, with teams of a
