@@ -554,6 +554,12 @@ __global__ __launch_bounds__(64 * W, (step_min_waves<P, G>())) void step_kernel(
   for (int i = tid; i < (2 + NR) * RB; i += 64 * W) lds[i] = 0.0;
   wg_sync<W>();
   const int ls2 = pidx<P>(2 * tid);      // LDS slot of this thread's first coalesced pair
+  // Wave 0 carries the Poisson scan on top of its species: it is the wave the others wait for at every barrier, so the SIMD it
+  // shares with waves of other workgroups issues its instructions first -- for the whole step while the batch leaves the chip
+  // latency-bound (headline shape: 5.37 -> 4.97 us per step), during the scan only once the batch oversubscribes it
+  // (B = 8192: 41.2 -> 40.2 us per step; the whole-step priority costs 2 % there).
+  const bool lead_all = W > 1 && wave == 0 && A.B <= 2048;
+  if (lead_all) __builtin_amdgcn_s_setprio(3);
 
   for (int step = 0; step < A.nsteps; ++step) {
     const bool resident = single_round && step > 0;   // rows (and LV) already in LDS from the last step
@@ -587,7 +593,9 @@ __global__ __launch_bounds__(64 * W, (step_min_waves<P, G>())) void step_kernel(
         // instances that sit at their register budget -- reloaded from spill slots, four dependent scratch loads per step.
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
+        if (W > 1 && !lead_all) __builtin_amdgcn_s_setprio(3);
         const double v1w = poisson_wave<P, false, 1>(A, LV, GV, nullptr, GV, vw, vb, gw, gb, lane_o);
+        if (W > 1 && !lead_all) __builtin_amdgcn_s_setprio(0);
         if (lane == 0) {
           GV[V1SLOT] = v1w;
           // CN indexes grad_v with the interior index r <= nx-3 plus, for the bulk boundary term,
