@@ -89,6 +89,10 @@ def load_library():
         raise PnpLibraryError(
             'HIP extension %s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
             '(hipcc --offload-arch=gfx950). There is no CPU fallback for the transport path.' % LIB_PATH)
+    if os.path.exists(os.path.join(_HERE, 'lib', '.partial')) and not os.environ.get('CATINT_ALLOW_PARTIAL'):   # dev runs set it
+        raise PnpLibraryError(
+            '%s was built by tools/devbuild.sh with only one Newton block size instantiated (marker lib/.partial): rebuild the '
+            'full library with `python -c "import __graft_entry__ as g; g.build()"`.' % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     dp = C.POINTER(C.c_double)
     ip = C.POINTER(C.c_int32)

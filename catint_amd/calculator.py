@@ -321,7 +321,10 @@ class Calculator(object):
             tp.descriptors = collections.OrderedDict((k, [tp.system[k]]) for k in keys)
             tp.alldata_names = [[tp.system[keys[0]], tp.system[keys[1]]]]
             tp.alldata = [{'species': {}, 'system': {}}]
-            tp.flux_bound[:, 0] = [float(tp.species[sp].get('flux', 0.0)) for sp in tp.species]
+            # symbolic fluxes ('catmap', equations: transport.py:938-947) carry no number of their own -- the kinetics callback /
+            # the implicit wall kinetics supply it; the prescribed part is zero
+            tp.flux_bound[:, 0] = [0.0 if isinstance(tp.species[sp].get('flux', 0.0), str) else float(tp.species[sp].get('flux', 0.0))
+                                   for sp in tp.species]
             self.run()
             d = tp.alldata[0]
         finally:
@@ -368,65 +371,83 @@ class Calculator(object):
         else:
             cout, status, (v, g, l) = self.integrate_pnp_batch(c0, pb, vz, flux)
         self.status = status
-        names = list(tp.species.keys())
-        from .units import unit_NA
-        radii = np.array([float(tp.species[sp].get('MPB_radius', 0.0)) for sp in names])
+        kf = getattr(self, 'kinetic_flux', None) if self.physical else None
         for i in range(B):
-            cfin = cout[-1, i].reshape(tp.nspecies, tp.nx)
-            d = tp.alldata[i]
-            for k, sp in enumerate(names):
-                d['species'][sp] = {'concentration': cfin[k].copy(), 'surface_concentration': float(cfin[k, 0])}
-            d['system'] = {'potential': v[i].copy(), 'efield': -g[i], 'charge_density': -l[i] * tp.eps,
-                           'surface_potential': float(v[i, 0]), 'surface_efield': float(-g[i, 0]),
-                           keys[0]: lanes[i][0], keys[1]: lanes[i][1], 'status': int(status[i])}
-            if self.physical:
-                # derived fields of the COMSOL reader (comsol_reader.py:57-90, :196-230, :241-261)
-                gamma = 1.0 / (1.0 - (unit_NA * radii[:, None] ** 3 * cfin).sum(axis=0))
-                kf = getattr(self, 'kinetic_flux', None)
-                for k, sp in enumerate(names):
-                    d['species'][sp]['activity_coefficient'] = gamma.copy()
-                    d['species'][sp]['surface_activity_coefficient'] = float(gamma[0])
-                    d['species'][sp]['electrode_flux'] = float(flux[i, k] + (kf[i, k] if kf is not None else 0.0))
-                with np.errstate(divide='ignore', invalid='ignore'):
-                    if 'H+' in names:
-                        ph = -np.log10(cfin[names.index('H+')] / 1000.)
-                    elif 'OH-' in names:
-                        ph = 14 + np.log10(cfin[names.index('OH-')] / 1000.)
-                    else:
-                        ph = None
-                if ph is not None:
-                    d['system']['pH'] = ph - np.log10(gamma)
-                    d['system']['surface_pH'] = float(ph[0] - np.log10(gamma[0]))
-                d['system']['activity_coefficient'] = gamma.copy()
-                # derived electrolyte quantities of the COMSOL model (comsol_model.py:1010-1040), on the cell edges
-                x = np.asarray(tp.xmesh, float)
-                h = np.diff(x)
-                z = tp.charges / unit_F
-                cmid = 0.5 * (cfin[:, 1:] + cfin[:, :-1])
-                um = tp.D * tp.beta                                            # mobility D/(RT)
-                kappa = unit_F ** 2 * ((z ** 2 * um)[:, None] * cmid).sum(axis=0)              # rho_c, S/m
-                w = -np.log(1.0 / gamma)                                                       # -ln(1-phi0)
-                u = (tp.charges * tp.beta)[:, None] * np.diff(v[i])[None, :] + np.diff(w)[None, :]
-                with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
-                    Bu = np.where(np.abs(u) < 1e-8, 1.0 - 0.5 * u, u / np.expm1(u))
-                jtot = -(tp.D[:, None] / h[None, :]) * ((Bu + u) * cfin[:, 1:] - Bu * cfin[:, :-1])   # Scharfetter-Gummel flux
-                jdif = -(tp.D[:, None] / h[None, :]) * np.diff(cfin, axis=1)
-                i_el = unit_F * (z[:, None] * jtot).sum(axis=0)                                # A/m^2
-                with np.errstate(divide='ignore', invalid='ignore'):
-                    dphi_iR = np.concatenate([[0.0], np.cumsum(np.where(kappa > 0, -i_el / kappa, 0.0) * h)])
-                    dphi_diff = np.concatenate([[0.0], np.cumsum(np.where(kappa > 0, unit_F * (z[:, None] * jdif).sum(axis=0) / kappa, 0.0) * h)])
-                d['system'].update({'conductivity': kappa, 'electrolyte_current_density': i_el, 'delta_phi_iR': dphi_iR,
-                                    'delta_phi_diff': dphi_diff, 'delta_phi_iR_inf': float(dphi_iR[-1]),
-                                    'delta_phi_diff_inf': float(dphi_diff[-1]), 'delta_phi_inf': float(v[i, -1] - v[i, 0]),
-                                    'delta_phi_inf_min_iR': float(v[i, -1] - v[i, 0] - dphi_iR[-1])})
-                es = tp.system.get('Stern epsilon', None)
-                if isinstance(es, (int, float)) and es:
-                    d['system']['Stern_efield'] = float(-g[i, 0]) * tp.system['epsilon'] / es
-                    d['system']['Stern_epsilon_func'] = es
-                elif es == 'Booth':           # field-dependent Stern permittivity, comsol_reader.py:102-119, :262-273
-                    from .host import booth_stern_field
-                    d['system']['Stern_efield'], d['system']['Stern_epsilon_func'] = booth_stern_field(-g[i, 0], tp.system['epsilon'])
+            self.fill_alldata(i, cout[-1, i].reshape(tp.nspecies, tp.nx), v[i], g[i], l[i], flux[i], int(status[i]),
+                              None if kf is None else kf[i])
         return cout
+
+    # ------------------------------------------------------------------------------------------
+    def fill_alldata(self, i, cfin, v, g, l, flux, status, kinetic_flux=None):
+        """Descriptor point i: tp.alldata[i]['species'|'system'] in the field contract of the reference's reader
+        (comsol_reader.py:196-326) from the arrays a transport solve leaves behind -- cfin [N][nx], potential v,
+        gradient g and charge row l [nx], prescribed wall fluxes flux [N].  Host arithmetic only (tests/test_results_io.py walks
+        the reference's plotting accesses over its output without a GPU)."""
+        tp = self.tp
+        from .units import unit_NA
+        keys = list(tp.descriptors.keys())
+        lane = tp.alldata_names[i]
+        names = list(tp.species.keys())
+        radii = np.array([float(tp.species[sp].get('MPB_radius', 0.0)) for sp in names])
+        d = tp.alldata[i]
+        for k, sp in enumerate(names):
+            d['species'][sp] = {'concentration': cfin[k].copy(), 'surface_concentration': float(cfin[k, 0])}
+        d['system'] = {'potential': v.copy(), 'efield': -g, 'charge_density': -l * tp.eps,
+                       'surface_potential': float(v[0]), 'surface_efield': float(-g[0]),
+                       keys[0]: lane[0], keys[1]: lane[1], 'status': int(status)}
+        if not self.physical:
+            return d
+        # derived fields of the COMSOL reader (comsol_reader.py:57-90, :196-230, :241-261)
+        gamma = 1.0 / (1.0 - (unit_NA * radii[:, None] ** 3 * cfin).sum(axis=0))
+        ers = getattr(tp, 'electrode_reactions', None) or {}
+        for k, sp in enumerate(names):
+            d['species'][sp]['activity_coefficient'] = gamma.copy()
+            d['species'][sp]['surface_activity_coefficient'] = float(gamma[0])
+            j = float(flux[k] + (kinetic_flux[k] if kinetic_flux is not None else 0.0))
+            d['species'][sp]['electrode_flux'] = j
+            if sp in ers and 'nel' in ers[sp]:          # mA/cm^2, comsol_reader.py:241-246
+                nprod = len([a for a in ers[sp]['reaction'][1] if a == sp])
+                d['species'][sp]['electrode_current_density'] = j * ers[sp]['nel'] * unit_F / nprod / 10.
+        with np.errstate(divide='ignore', invalid='ignore'):
+            if 'H+' in names:
+                ph = -np.log10(cfin[names.index('H+')] / 1000.)
+            elif 'OH-' in names:
+                ph = 14 + np.log10(cfin[names.index('OH-')] / 1000.)
+            else:
+                ph = None
+        if ph is not None:
+            d['system']['pH'] = ph - np.log10(gamma)
+            d['system']['surface_pH'] = float(ph[0] - np.log10(gamma[0]))
+        d['system']['activity_coefficient'] = gamma.copy()
+        # derived electrolyte quantities of the COMSOL model (comsol_model.py:1010-1040), on the cell edges
+        x = np.asarray(tp.xmesh, float)
+        h = np.diff(x)
+        z = tp.charges / unit_F
+        cmid = 0.5 * (cfin[:, 1:] + cfin[:, :-1])
+        um = tp.D * tp.beta                                            # mobility D/(RT)
+        kappa = unit_F ** 2 * ((z ** 2 * um)[:, None] * cmid).sum(axis=0)              # rho_c, S/m
+        w = -np.log(1.0 / gamma)                                                       # -ln(1-phi0)
+        u = (tp.charges * tp.beta)[:, None] * np.diff(v)[None, :] + np.diff(w)[None, :]
+        with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+            Bu = np.where(np.abs(u) < 1e-8, 1.0 - 0.5 * u, u / np.expm1(u))
+        jtot = -(tp.D[:, None] / h[None, :]) * ((Bu + u) * cfin[:, 1:] - Bu * cfin[:, :-1])   # Scharfetter-Gummel flux
+        jdif = -(tp.D[:, None] / h[None, :]) * np.diff(cfin, axis=1)
+        i_el = unit_F * (z[:, None] * jtot).sum(axis=0)                                # A/m^2
+        with np.errstate(divide='ignore', invalid='ignore'):
+            dphi_iR = np.concatenate([[0.0], np.cumsum(np.where(kappa > 0, -i_el / kappa, 0.0) * h)])
+            dphi_diff = np.concatenate([[0.0], np.cumsum(np.where(kappa > 0, unit_F * (z[:, None] * jdif).sum(axis=0) / kappa, 0.0) * h)])
+        d['system'].update({'conductivity': kappa, 'electrolyte_current_density': i_el, 'delta_phi_iR': dphi_iR,
+                            'delta_phi_diff': dphi_diff, 'delta_phi_iR_inf': float(dphi_iR[-1]),
+                            'delta_phi_diff_inf': float(dphi_diff[-1]), 'delta_phi_inf': float(v[-1] - v[0]),
+                            'delta_phi_inf_min_iR': float(v[-1] - v[0] - dphi_iR[-1])})
+        es = tp.system.get('Stern epsilon', None)
+        if isinstance(es, (int, float)) and es:
+            d['system']['Stern_efield'] = float(-g[0]) * tp.system['epsilon'] / es
+            d['system']['Stern_epsilon_func'] = es
+        elif es == 'Booth':           # field-dependent Stern permittivity, comsol_reader.py:102-119, :262-273
+            from .host import booth_stern_field
+            d['system']['Stern_efield'], d['system']['Stern_epsilon_func'] = booth_stern_field(-g[0], tp.system['epsilon'])
+        return d
 
     # ------------------------------------------------------------------------------------------
     def _lane_inputs(self):
@@ -447,7 +468,7 @@ class Calculator(object):
             phiM[i] = system['phiM']
         return pb, vz, phiM
 
-    def run_scf_cycle(self, flux_callback=None, nel=None, nprod=None, max_iter=1000, transport_fn=None):
+    def run_scf_cycle(self, flux_callback=None, nel=None, nprod=None, max_iter=1000, transport_fn=None, label=''):
         """Batched counterpart of the reference's SCF outer loop (catint/calculator.py:294-406): kinetics
         (`flux_callback`, the seam where CatMAP sat, catmap_wrapper.py:106) <-> transport, once per iteration, for
         every descriptor point at the same time.  Each lane carries its own mixing factor, iteration bookkeeping
@@ -464,7 +485,12 @@ class Calculator(object):
         Same iterates as this host loop with surface_kinetic_fluxes(clip=True) as the callback; the hand-over happens after the
         first iteration (>= 2) in which every transport solve converged, and a lane whose solve fails later goes back to the
         state of its last converged solve instead of triggering a whole-batch restart from the bulk state.
+        label: the reference's run_scf_cycle(label='') argument (calculator.py:294; it only names COMSOL's files) -- accepted, also
+        as the first positional argument, and kept in self.scf_label.
         Returns a dict with the per-lane results and bookkeeping."""
+        if isinstance(flux_callback, str):          # reference call shape: run_scf_cycle(label)
+            flux_callback, label = None, flux_callback
+        self.scf_label = label
         tp = self.tp
         device_loop = flux_callback is None
         kinetics = getattr(self, 'surface_kinetics', None)

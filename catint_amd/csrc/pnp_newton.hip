@@ -981,7 +981,8 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
           if (!(dua[k] == dua[k]) || !(dub[k] == dub[k])) upd = INFINITY;
         }
         mphi = fmax(fabs(dua[N]), fabs(dub[N]));
-        if (!(mphi == mphi)) mphi = INFINITY;
+        // fmax drops a NaN operand: test both potential updates, as the other kernels do, so that a NaN update is never accepted
+        if (!(dua[N] == dua[N]) || !(dub[N] == dub[N])) mphi = INFINITY;
         upd = fmax(upd, mphi * A.vt_inv);
         mphi = wave_max(mphi);
         upd = wave_max(upd);

@@ -4,10 +4,10 @@
 Poisson-Nernst-Planck with the bicarbonate/water buffer reactions, a Stern layer and flux boundary conditions -- with every
 voltage of the polarization sweep as one GPU lane (4096 lanes in the BASELINE configuration).
 
-  * species, bulk concentrations (buffer equilibria + electroneutrality), ion size, Stern capacitance, phiPZC, boundary
-    layer thickness: run.py:6-93 / SURVEY.md App. E;
-  * homogeneous reactions and rate constants: the reference's data table (catint/data.py:11-22, 37-51, 114-116), H2O is an
-    excluded species (constant activity), so `H2O <-> OH- + H+` has a constant forward rate;
+  * inputs: the run.py dictionaries themselves (examples/co2r_inputs.py); `Transport` derives species, bulk concentrations
+    (Henry's law, buffer equilibria, electroneutrality), ion size, Stern capacitance, phiPZC, boundary layer thickness and the
+    homogeneous reactions with their rate constants exactly as the reference does (transport.py:537-768, catint/data.py);
+    H2O is an excluded species (constant activity), so `H2O <-> OH- + H+` has a constant forward rate;
   * CatMAP is not available offline: first-order Tafel kinetics `CO2 + H2O + 2e- -> CO + 2 OH-` stand in for it.  They are
     coupled implicitly (Calculator.set_surface_kinetics): the whole polarization curve is ONE batched Newton solve instead of
     hundreds of kinetics<->transport SCF iterations (the SCF loop is available too: --scf);
@@ -25,33 +25,21 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from catint_amd.transport import Transport        # noqa: E402
 from catint_amd.calculator import Calculator      # noqa: E402
 from catint_amd.units import unit_F, unit_R      # noqa: E402
+import co2r_inputs                               # noqa: E402  (examples/co2r_inputs.py: the run.py dictionaries)
 
 
 def build(lanes, nx, phimin=-0.5, phimax=-2.0):
-    species = collections.OrderedDict([           # order and bulk values: SURVEY.md App. E
-        ('K+', {'bulk_concentration': 93.70466795, 'MPB_radius': 2 * 4.1e-10}),
-        ('CO2', {'bulk_concentration': 33.429}),
-        ('OH-', {'bulk_concentration': 6.31e-05}),
-        ('CO', {'bulk_concentration': 0.0}),
-        ('HCO3-', {'bulk_concentration': 93.64969242}),
-        ('CO32-', {'bulk_concentration': 0.02753546}),
-        ('H+', {'bulk_concentration': 1.584893192e-4}),
-    ])
-    phis = list(np.linspace(phimin, phimax, lanes))
-    tp = Transport(species=species, system={'phiM': phis[0], 'temperature': 298, 'boundary thickness': 8e-5, 'bulk_pH': 6.8,
-                                            'phiPZC': 0.16, 'Stern capacitance': 20.0}, nx=nx - 1, descriptors={'phiM': phis})
+    """Transport of the run.py system: the reference's input dictionaries (examples/co2r_inputs.py) in, species list, bulk
+    equilibria, electroneutrality, reaction table out (transport.py:537-768); then the wall-graded mesh."""
+    phis = co2r_inputs.voltages(lanes, phimin, phimax)
+    tp = Transport(species=co2r_inputs.species(), electrode_reactions=co2r_inputs.electrode_reactions(),
+                   electrolyte_reactions=co2r_inputs.electrolyte_reactions(), system=co2r_inputs.system(phiM=phis[0]), nx=nx - 1,
+                   descriptors={'phiM': phis}, model_name='CO2R')
     tp.set_graded_mesh(tp.debye_length / 20.0)
-    tp.reactions = collections.OrderedDict([      # reactants without the excluded species H2O; rates: catint/data.py
-        ('buffer-base', {'reactants': [['CO2', 'OH-'], ['HCO3-']], 'rates': [5.93, 0.00013355855855855855]}),
-        ('buffer-base2', {'reactants': [['HCO3-', 'OH-'], ['CO32-']], 'rates': [1.0e5, 21459.227467811157]}),
-        ('self-dissociation of water', {'reactants': [[], ['OH-', 'H+']], 'rates': [2.4e-5 * 1000., 2.4e-5 / 1e-14 / 1000.]}),
-        ('buffer-acid', {'reactants': [['CO2'], ['HCO3-', 'H+']], 'rates': [3.7e-2, 83.33333333333333]}),
-        ('buffer-acid2', {'reactants': [['HCO3-'], ['CO32-', 'H+']], 'rates': [59.44, 1275536480.6866953]}),
-    ])
-    tp.use_reactions = True
     return tp, np.array(phis)
 
 

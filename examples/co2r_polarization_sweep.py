@@ -14,8 +14,8 @@ What differs from the reference example, and why:
     on (and `vzeta = 0` makes the wall condition the plain flux condition, calculator_old.py:1003-1006)
     -- useless for a one-second mass-transport transient on the example's 80-micron grid
     (dx ~ 400 Debye lengths, SURVEY.md App. E), where the double layer is not resolved anyway;
-  * bulk concentrations are the values the reference's buffer-equilibrium solve produces for this
-    electrolyte, entered directly.
+  * inputs are the run.py dictionaries (examples/co2r_inputs.py); the bulk concentrations come out of `Transport`'s own
+    Henry / buffer-equilibrium / electroneutrality pass (transport.py:537-768), as in the reference.
 
     python examples/co2r_polarization_sweep.py --lanes 4096
 """
@@ -28,24 +28,25 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from catint_amd.transport import Transport        # noqa: E402
 from catint_amd.calculator import Calculator      # noqa: E402
 from catint_amd.units import unit_F, unit_R      # noqa: E402
+import co2r_inputs                               # noqa: E402  (examples/co2r_inputs.py: the run.py dictionaries)
 
 
 def build(lanes, nx=200):
-    species = collections.OrderedDict([           # order and bulk values: SURVEY.md App. E
-        ('K+', {'bulk_concentration': 93.70466795}),
-        ('CO2', {'bulk_concentration': 33.429}),
-        ('OH-', {'bulk_concentration': 6.31e-05}),
-        ('CO', {'bulk_concentration': 0.0}),
-        ('HCO3-', {'bulk_concentration': 93.64969242}),
-        ('CO32-', {'bulk_concentration': 0.02753546}),
-        ('H+', {'bulk_concentration': 1.584893192e-4}),
-    ])
-    phis = list(np.linspace(-0.5, -0.74, lanes))   # beyond ~-0.76 V this Tafel law outruns CO2 transport (negative c)
-    tp = Transport(species=species, system={'phiM': phis[0], 'temperature': 298, 'boundary thickness': 8e-5,
-                                            'bulk_pH': 6.8, 'migration': False, 'vzeta': 0.0}, nx=nx, descriptors={'phiM': phis})
+    """Transport of the run.py system from the reference's input dictionaries (examples/co2r_inputs.py): species list, bulk
+    equilibria and electroneutrality as transport.py:537-768 computes them; diffusion only (see the module docstring)."""
+    phis = co2r_inputs.voltages(lanes, -0.5, -0.74)   # beyond ~-0.76 V this Tafel law outruns CO2 transport (negative c)
+    tp = Transport(species=co2r_inputs.species(steric=False), electrode_reactions=co2r_inputs.electrode_reactions(),
+                   electrolyte_reactions=co2r_inputs.electrolyte_reactions(),
+                   system=co2r_inputs.system(phiM=phis[0], migration=False, vzeta=0.0), nx=nx, descriptors={'phiM': phis},
+                   model_name='CO2R')
+    # the legacy explicit integrator has no use for the buffer's rate constants (up to 1.3e9 1/s against dt = 5e-6 s, and
+    # get_rates keeps only the last reaction per species, calculator_old.py:173,:193): the equilibria set the bulk state only
+    tp.reactions = collections.OrderedDict()
+    tp.use_reactions = False
     return tp, np.array(phis)
 
 

@@ -408,3 +408,39 @@ def test_run_single_step_updates_tp_like_the_comsol_reader():
     assert len(tp.species['K+']['concentration']) == tp.nx and tp.species['K+']['surface_concentration'] > 100.0
     assert tp.system['surface_potential'] < 0 and len(tp.system['potential']) == tp.nx and 'activity_coefficient' in tp.system
     assert list(tp.descriptors['phiM']) == [-0.4, -0.8] and len(tp.alldata) == 2                          # the sweep set-up is untouched
+
+
+def test_gpu_sweep_results_folder_matches_the_reference_reader_manifest(tmp_path):
+    """f4: a real GPU sweep of the run.py system, written with results_io.save_all and walked through the accesses of the
+    reference's plotting tool (tests/results_walk.py), shows the keys and types that the REFERENCE's own reader produced for such a
+    folder (tests/golden/results_manifest.json, generated by tests/golden/make_results_manifest.py); profile lengths follow nx."""
+    import importlib.util
+    import json
+    from catint_amd.results_io import save_all, read_all
+    from tests import results_walk
+    spec = importlib.util.spec_from_file_location('co2r_physical_sweep', os.path.join(os.path.dirname(__file__), '..', 'examples',
+                                                                                       'co2r_physical_sweep.py'))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    tp, phis = ex.build(3, 96, phimin=-0.5, phimax=-0.7)
+    calc = Calculator(transport=tp, calc='comsol')
+    tp.newton = {'tol': 1e-9, 'maxit': 80}
+    calc.set_surface_kinetics([{'species': 'CO2', 'rate': ex.tafel_rate(tp), 'stoichiometry': {'CO2': -1.0, 'CO': 1.0, 'OH-': 2.0}}])
+    calc.run()
+    assert np.all(calc.status == 0)
+    folder = str(tmp_path / 'CO2R_results')
+    save_all(tp, folder)
+
+    class Bare(object):
+        pass
+    got = results_walk.walk(read_all(Bare(), folder, only=['alldata', 'species', 'system', 'xmesh', 'descriptors', 'electrode_reactions']))
+    manifest = json.load(open(os.path.join(GOLDEN, 'results_manifest.json')))
+    assert sorted(got) == sorted(manifest)
+    for key, (kind, n) in manifest.items():
+        assert got[key][0] == kind, (key, got[key], kind)
+        if n is not None and kind in ('list', 'ndarray') and key != "descriptors['phiM']":
+            assert got[key][1] == tp.nx, (key, got[key])
+    # the CO partial current density of the reader's formula (comsol_reader.py:241-246): j * nel * F / nprod / 10
+    names = list(tp.species.keys())
+    j = calc.kinetic_flux[:, names.index('CO')]
+    assert np.allclose([tp.alldata[i]['species']['CO']['electrode_current_density'] for i in range(3)], j * 2 * 96485.33289 / 1 / 10.)

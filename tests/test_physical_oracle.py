@@ -187,3 +187,115 @@ def test_unrepresentable_crowding_is_reported_not_nan():
     p, c0, phi0, lam = binary(-1.0, cb=100.0, mpb_radius=[a, a])       # Dirichlet -1 V at the plane of closest approach
     c, phi, it, _ = PH.newton_step(p, c0, phi0, c0, np.inf, maxit=40)
     assert it == 41 and np.all(np.isfinite(c)) and np.all(np.isfinite(phi))
+
+
+# ---- inputs pinned by the reference ------------------------------------------------------------------------
+import glob      # noqa: E402
+import json      # noqa: E402
+import os        # noqa: E402
+import re        # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, '*_n2_*.npz'))), ids=lambda p: os.path.basename(p)[:-4])
+def test_gouy_chapman_against_the_references_own_arrays(path):
+    """Every two-species fixture stores tp.gouy_chapman(x) as the REFERENCE evaluated it (tests/golden/make_golden.py:108): the
+    analytic answer that pins the oracle is the reference's number, not the oracle's own formula."""
+    d = np.load(path)
+    gc = PH.gouy_chapman(d['xmesh'], float(d['phiM']), float(d['beta']), abs(float(d['charges'][0])), float(d['debye_length']))
+    ref = d['gouy_chapman'][:, 0]
+    assert np.abs(gc - ref).max() <= 1e-14 * max(np.abs(ref).max(), 1e-300)
+    # ... and the stationary solve of the oracle on the fixture's own electrolyte, grid and wall potential approaches it
+    # (the reference's two default species are a 1:1 electrolyte; the grid is the fixture's, so only a loose bound holds)
+    if float(d['dx']) < 0.5 * float(d['debye_length']) and float(d['xmax']) > 8 * float(d['debye_length']):
+        p = PH.PhysicalProblem(D=d['D'], charges=d['charges'], beta=float(d['beta']), eps=float(d['eps']), dx=float(d['dx']),
+                               nx=int(d['nx']), c_bulk=d['c_bulk'], phiM=float(d['phiM']), x=d['xmesh'])
+        c0 = np.repeat(np.asarray(d['c_bulk'], float)[:, None], int(d['nx']), axis=1)
+        c, phi, it, _ = PH.newton_step(p, c0, np.zeros(int(d['nx'])), c0, np.inf, tol=1e-11, maxit=60)
+        assert it <= 60 and np.abs(phi - ref).max() < 0.02 * abs(float(d['phiM']))
+
+
+def _number(expr):
+    """'1.957e-09[m^2/s]' -> 1.957e-09;  '(2e-05+flux_factor*0.0)[F/cm^2]' is evaluated with flux_factor = 1."""
+    body = re.sub(r'\[[^\]]*\]\s*$', '', expr.strip())
+    return float(eval(body, {'__builtins__': {}}, {'flux_factor': 1.0, 'PZC_factor': 1.0}))
+
+
+def _runpy_transport():
+    import collections
+    from catint_amd.transport import Transport
+    from catint_amd.units import unit_NA
+    case = next(c for c in json.load(open(os.path.join(GOLDEN, 'transport_cases.json'))) if c['input']['name'] == 'co2r_runpy')['input']
+    system = dict(case['system'])
+    system['active site density'] = 9.61e-05 / unit_NA * (1e10) ** 2
+    return Transport(species=collections.OrderedDict((n, dict(d)) for n, d in case['species']),
+                     electrode_reactions=case['electrode_reactions'], electrolyte_reactions=case['electrolyte_reactions'],
+                     system=system, nx=case['nx'], descriptors={'phiM': [-0.5, -0.6]})
+
+
+def test_model_coefficients_are_what_the_reference_hands_to_comsol():
+    """tests/golden/comsol_model_runpy.json = every parameter / variable / source expression catint/comsol_model.py emits for the
+    run.py system (generated by running the reference).  The numbers that reach our solver and its oracle from
+    catint_amd.transport.Transport + Calculator._physical_solver are those."""
+    fx = json.load(open(os.path.join(GOLDEN, 'comsol_model_runpy.json')))['co2r_runpy']
+    par, var = fx['pairs']['param'], fx['pairs']['variables_domain']
+    tp = _runpy_transport()
+    names = list(tp.species.keys())
+    assert names == fx['species_order']
+    for i, sp in enumerate(names):
+        assert _number(par['D%d' % (i + 1)]) == tp.D[i] and int(par['Z%d' % (i + 1)]) == tp.species[sp]['charge']
+        assert _number(par['ci%d' % (i + 1)]) == float(repr(float(tp.species[sp]['bulk_concentration'])))
+    assert float(par['L_cell']) == tp.xmax and _number(par['T']) == tp.system['temperature'] and float(par['eps_r']) == tp.system['epsilon']
+    assert _number(par['lambdaD']) == tp.debye_length
+    # Stern Robin wall (comsol_model.py:982 rho_s = ((phiM-phiPZC)-phi)*CS; CS in F/cm^2, :1160-1167): what _physical_solver passes
+    assert var['rho_s'] == '((phiM-phiPZC)-phi)*CS'
+    cs_ref = _number(par['CS']) * 1e4                                 # F/cm^2 -> F/m^2 at the end of the ramp
+    assert abs(cs_ref - float(tp.system['Stern capacitance']) * 1e-2) < 1e-15        # catint_amd/calculator.py:_physical_solver
+    # continuation: the reference ramps phiPZC from phiM (no surface charge) to its value with flux_factor 0 -> 1 (:1147-1155);
+    # ours walks phiM from phiPZC to its value -- the same family of problems from the uncharged wall to the target
+    ramp = re.sub(r'\[V\]$', '', par['phiPZC'])
+    at = lambda ff: eval(ramp, {'__builtins__': {}}, {'flux_factor': ff})
+    assert at(0.0) == tp.system['phiM'] and abs(at(1.0) - tp.system['phiPZC']) < 1e-15
+    assert fx['par_name'] == 'flux_factor' and fx['par_values'] == 'range(0,0.01,1)'
+    # size-modified model (:1041-1063): phi0 = N_A sum a_i^3 c_i, gamma = 1/(1-phi0), activities c*gamma, drift -D phi0'/(1-phi0)
+    assert var['phi_zero'] == 'N_A_const*(+a1^3*cp1)' and var['gamma'] == '1./(1.-phi_zero)' and var['ap3'] == 'cp3*gamma'
+    assert var['tds.u5'] == '-D5*phi_zero_grad/(1-phi_zero)'
+    assert _number(var['a1']) == tp.species['K+']['MPB_radius']
+    # rate constants (:1064-1084), in the order of tp.reactions
+    for j, rx in enumerate(tp.reactions.values()):
+        assert _number(var['k%df' % (j + 1)]) == rx['rates'][0] and _number(var['k%dr' % (j + 1)]) == rx['rates'][1]
+
+
+def test_reaction_source_equals_the_expressions_the_reference_emits():
+    """R_cp1..R_cp7 as catint/comsol_model.py:781-867 writes them (mass action in activities, excluded species at the standard
+    concentration), evaluated at random states, against oracle.pnp_physical.reaction_rates fed from our Transport's table."""
+    fx = json.load(open(os.path.join(GOLDEN, 'comsol_model_runpy.json')))['co2r_runpy']
+    var, tds = fx['pairs']['variables_domain'], fx['pairs']['physics_tds']
+    tp = _runpy_transport()
+    names = list(tp.species.keys())
+    N = len(names)
+    rx = [{'lhs': [names.index(x) for x in r['reactants'][0]], 'rhs': [names.index(x) for x in r['reactants'][1]],
+           'kf': r['rates'][0], 'kr': r['rates'][1]} for r in tp.reactions.values()]
+    radii = [tp.species[s].get('MPB_radius', 0.0) for s in names]
+    p = PH.PhysicalProblem(D=tp.D, charges=tp.charges, beta=tp.beta, eps=tp.eps, dx=1e-9, nx=5, c_bulk=np.ones(N), phiM=0.0,
+                           mpb_radius=radii, reactions=rx)
+    rng = np.random.default_rng(0)
+    c = np.exp(rng.uniform(np.log(1e-4), np.log(300.0), (N, 5)))
+    R, _ = PH.reaction_rates(p, c)
+    for i in range(5):
+        env = {'conc_std': 1.0, 'N_A_const': PH.N_AVOGADRO}
+        for k in range(N):
+            env['cp%d' % (k + 1)] = c[k, i]
+        env['a1'] = _number(var['a1'])
+        env['phi_zero'] = eval(var['phi_zero'].replace('^', '**'), {'__builtins__': {}}, env)
+        env['gamma'] = eval(var['gamma'], {'__builtins__': {}}, env)
+        for k in range(N):
+            env['ap%d' % (k + 1)] = eval(var['ap%d' % (k + 1)], {'__builtins__': {}}, env)
+        for key in var:
+            if re.fullmatch(r'k\d+[fr]', key):
+                env[key] = _number(var[key])
+        for k in range(N):
+            ref = eval(tds['R_cp%d' % (k + 1)], {'__builtins__': {}}, env)
+            scale = max(abs(ref), max(abs(env['k5r'] * env['ap6'] * env['ap7']), 1e-300) * 1e-3)
+            assert abs(R[k, i] - ref) <= 1e-12 * scale, (k, i, R[k, i], ref)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # dev tool: build libcatint_pnp.so with only ONE block size of the Newton kernels instantiated (fast turn-around).
-# usage: tools/devbuild.sh NB      (restore the full library afterwards with `python -c "import __graft_entry__ as g; g.build()"`)
+# usage: tools/devbuild.sh NB   (then run with CATINT_ALLOW_PARTIAL=1: the loader refuses a partial library otherwise)
+#             (restore the full library afterwards with `python -c "import __graft_entry__ as g; g.build()"`)
 NB=${1:-4}
 R=/root/repo/catint_amd
 mkdir -p /tmp/devb
