@@ -32,7 +32,7 @@ struct pnp_handle {
   SpecConst* spec = nullptr;
   int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
   int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
-  int kernel_override = 0;   // CATINT_PNP_KERNEL = 2 (LDS-staged step_kernel) | 4 (register-resident step_kernel_rr)
+  int kernel_override = 0;   // CATINT_PNP_KERNEL = 2 (LDS-staged step_kernel) | 4 (register-resident step_kernel_rr) | 5, 6 (streaming step_kernel_st)
   int32_t* status = nullptr;
   // physical mode (PNP_METHOD_NEWTON)
   bool newton = false;
@@ -235,6 +235,9 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   a.has_rates = 0;
   a.B = 0;
   a.dx = cfg->dx;
+  a.dx2 = cfg->dx * cfg->dx;
+  a.inv2dx = 1.0 / (2 * cfg->dx);
+  a.nxm1 = (double)(cfg->nx - 1);
   a.dt = cfg->dt;
   a.beta = cfg->beta;
   a.eps = cfg->eps;
@@ -429,7 +432,9 @@ static int run_steps(pnp_handle* h, int nsteps) {
   }
   if (h->kernel_override == 2) rr = false;
   if (h->kernel_override == 4) rr = step_rr_applicable(a);
-  if (rr) {
+  if ((h->kernel_override == 5 || h->kernel_override == 6) && step_rr_applicable(a)) {
+    HIP_TRY(h, launch_step_st(a, h->kernel_override == 6 ? 1 : 0, h->stream));
+  } else if (rr) {
     int w = rr_waves;
     if (h->waves_override >= 1 && h->waves_override <= 4) w = h->waves_override;
     HIP_TRY(h, launch_step_rr(a, w, h->stream));

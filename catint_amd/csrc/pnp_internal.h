@@ -44,6 +44,7 @@ struct DevArgs {
   int32_t has_rates; // FTCS: add rates[b][k][i]*dt (computed by rates_kernel before the step)
   int64_t B;
   double dx, dt, beta, eps;
+  double dx2, inv2dx, nxm1;   // dx*dx, 1/(2 dx), (double)(nx-1): wave-uniform fp64 values would otherwise live in (spilled) vector registers
   const SpecConst* spec;  // [N]
   // state
   double* c;          // [B][N][ldx]  concentrations, in place
@@ -85,6 +86,9 @@ hipError_t launch_step(const DevArgs& a, int W, int G, hipStream_t stream);
 // applicable to the Dirichlet/Dirichlet Poisson branch with an even number of points per lane
 bool step_rr_applicable(const DevArgs& a);
 hipError_t launch_step_rr(const DevArgs& a, int W, hipStream_t stream);
+// streaming kernel (pnp_stream.hip: step_kernel_st): persistent single-wave workgroups, next row prefetched behind the current
+// solve; same applicability as the register-resident kernel.  mode 0: registers only, 1: charge / gradient rows of the step in LDS
+hipError_t launch_step_st(const DevArgs& a, int mode, hipStream_t stream);
 // lapl[b][i] = -sum_k q_k c[b][k][i]/eps for all nx points (initial charge row, calculator_old.py:767-771)
 hipError_t launch_charge_row(const DevArgs& a, double* lapl, hipStream_t stream);
 // v, grad_v [B][ldx] from a lapl row (get_potential_and_gradient, calculator_old.py:773-803)

@@ -24,8 +24,9 @@ VARIANTS = {
     'rrW2': dict(CATINT_PNP_KERNEL='4', CATINT_PNP_WAVES_PER_GRID='2'),
     'rrW3': dict(CATINT_PNP_KERNEL='4', CATINT_PNP_WAVES_PER_GRID='3'),
     'st': dict(CATINT_PNP_KERNEL='5'),
+    'stg': dict(CATINT_PNP_KERNEL='6'),
 }
-KEYS = ['CATINT_PNP_KERNEL', 'CATINT_PNP_WAVES_PER_GRID', 'CATINT_PNP_SPECIES_PER_WAVE']
+KEYS = ['CATINT_PNP_KERNEL', 'CATINT_PNP_WAVES_PER_GRID', 'CATINT_PNP_SPECIES_PER_WAVE']      # (CATINT_PNP_ST_WAVES_PER_CU passes through)
 
 
 def measure(prob, c0, pb, vz, fl, B, N, nx, spl, nsteps, reps):
