@@ -2,24 +2,38 @@
 """Benchmark of the batched 1D PNP timestep path (BASELINE.json metric:
 "batched 1D PNP Newton-timesteps/sec at 1/2/4/8 GPU; achieved HBM GB/s vs peak").
 
-One "step" = one pass of the integrator's time-loop body (reference catint/calculator_old.py:512-558)
-over one batch of B operating points.  Headline ("state written every step
-(ntout = nt)", algorithmic bytes 16*(N+1)*nx per lane-step): the reference's time loop runs inside the
-kernel, `--steps-per-launch` timesteps per launch (default 256, what pnp_step/pnp_integrate use); every step's new
-state is written to HBM, the previous state is re-used from registers/LDS instead of being re-read, so the
-MEASURED HBM traffic (roofline.traffic, rocprofv3) is about half the algorithmic figure.  The
-one-launch-per-timestep variant (state read from and written to HBM by every launch) is reported next to
-it as `per_step_launch`.  Workload at N=1: BASELINE.json configs[1] -- batch=1024 operating points,
-3 species, 512 grid points, fp64.  Multi-GPU: the batch shards embarrassingly
-(weak scaling: every rank owns `--batch` lanes), no collective in the timed region; one RCCL
-all_gather of the polarization observables afterwards.
+One "step" = one pass of the integrator's time-loop body (reference catint/calculator_old.py:512-558) over one batch of
+B operating points.  Workload at N=1: BASELINE.json configs[1] -- batch=1024 operating points, 3 species, 512 grid points,
+fp64.  The K timed steps are issued as pnp_step(K, steps_per_launch) (default: the library's fused launches, every step's
+state written to HBM), bracketed by barrier + synchronize on both sides; `value` is lane-timesteps per WALL second of that
+region.  `roofline.achieved` = SURVEY 8(d)'s algorithmic bytes 16(N+1)nx per lane-timestep x the lane-timesteps of one
+launch / that launch's duration by HIP events on the library's own stream.
+
+What the line says about itself:
+  * `roofline.traffic` is MEASURED IN THIS RUN: before the GPU is touched, rank 0 runs this same script as a child under
+    `rocprofv3 --pmc` (separate passes for FETCH_SIZE, WRITE_SIZE and an SQ group, as MI355X_MICROARCH.md prescribes; FETCH_SIZE
+    doubled on gfx950) over the same launch shapes, and reads the per-dispatch counters of the timed kernels.  null (with a
+    reason) if rocprofv3 is unavailable.  `roofline.traffic_over_algorithmic` << 1 means the state stayed on chip between fused
+    steps: such a launch is NOT HBM-bound, and `roofline.limiter` names what the SQ counters say binds instead.
+  * `per_step_launch`: one launch per timestep on the same batch (traffic == algorithmic bytes);
+  * `beyond_cache`: one GPU's share of BASELINE configs[3] (32768 lanes x 6 species x 1024 points, 2.1 GB of state, far beyond
+    the 256 MiB Infinity Cache), one launch per step and fused -- the configuration in which the HBM roofline is the real bound;
+  * `first_launch_after_upload`: pnp_set_batch immediately followed by the first K-step launch (what a cold caller sees);
+  * `physical_mode`: the implicit coupled-Newton path with a measured roofline of its own (fp64 VALU issue, LDS, HBM bytes).
+Multi-GPU: the batch shards embarrassingly (weak scaling: every rank owns `--batch` lanes), no collective in the timed region; one
+RCCL all_gather of the polarization observables afterwards.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,7 +41,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9      # fp64 lane-operations/s: 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz (78.6 TFLOP/s FMA)
+BC_SHAPE = (32768, 6, 1024)    # one GPU's share of BASELINE configs[3]
+RADII8 = [4.1e-10, 3.6e-10, 3.3e-10, 3e-10, 3e-10, 3e-10, 4.5e-10, 3.5e-10]
 
 
 def parse():
@@ -43,17 +60,147 @@ def parse():
                     help='timesteps fused into one launch (state written to HBM every step); 1 = one launch per step')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline sample length')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-fused', action='store_true')
-    ap.add_argument('--large-batch', type=int, default=8192,
-                    help='extra (non-headline) timed run at this batch size to show the oversubscribed regime; 0 = skip')
-    ap.add_argument('--physical-steps', type=int, default=20,
-                    help='extra (non-headline) timed run of the implicit physical mode (coupled Newton, block cyclic reduction) '
-                         'on the same workload shape; 0 = skip')
-    ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'hbm_traffic_latest.json'),
-                    help='rocprofv3 PMC result (tools/pmc_traffic.py) for this workload; merged into roofline.traffic')
+    ap.add_argument('--no-extras', action='store_true', help='headline only (no per-step / beyond-cache / physical records)')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
+    ap.add_argument('--large-batch', type=int, default=8192, help='extra timed run at this batch size; 0 = skip')
+    ap.add_argument('--physical-steps', type=int, default=20, help='implicit physical mode on the headline shape; 0 = skip')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)   # this process is the profiled child
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# workloads (shared by the timed parent and the profiled child so that both launch the same kernels on the same shapes)
+# ------------------------------------------------------------------------------------------------------------------------------------
+def compat_solver(B, N, nx, method, seed, device=0):
+    from catint_amd.synthetic import make_batch
+    from catint_amd.host import solver_from_problem
+    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=seed, phi_max=0.025, dt_factor=1e-5)
+    s = solver_from_problem(prob, method, batch_capacity=B, device=device)
+    return s, (prob, c0, pb, vz, fl)
+
+
+def newton_solver(B, N, nx, seed, device=0, steric=False):
+    from catint_amd import _capi
+    from catint_amd.synthetic import make_batch
+    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=seed, phi_max=0.2, dt_factor=0.1)
+    pb = np.nan_to_num(pb)
+    s = _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=B, device=device)
+    if steric:
+        s.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=1e-8, mpb_radius=RADII8[:N])
+    else:
+        s.set_newton(tol=1e-8)
+    return s, (prob, c0, pb, vz, fl)
+
+
+def pmc_child(args):
+    """The profiled child: the launch shapes of every record, separated by marker dispatches (surface_kernel via get_surface)."""
+    B, N, nx = args.batch, args.nspecies, args.nx
+
+    def item(s, inputs, launches):
+        s.set_batch(*inputs[1:])
+        launches(s, True)          # warm-up
+        s.get_surface()            # marker: timed launches follow
+        launches(s, False)
+        s.get_surface()            # marker: end
+        s.close()
+
+    s, inp = compat_solver(B, N, nx, args.method, 1000)
+    item(s, inp, lambda s, w: s.step(args.steps, args.steps_per_launch))
+    s, inp = compat_solver(B, N, nx, args.method, 1000)
+    item(s, inp, lambda s, w: s.step(8, 1))
+    if not args.no_extras:
+        s, inp = compat_solver(*BC_SHAPE, args.method, 55)
+        item(s, inp, lambda s, w: s.step(4, 1))
+        s, inp = compat_solver(*BC_SHAPE, args.method, 55)
+        item(s, inp, lambda s, w: s.step(32, 32))
+        if args.physical_steps > 0:
+            s, inp = newton_solver(B, N, nx, 4242)
+            item(s, inp, lambda s, w: s.step(3))
+            s, inp = newton_solver(8192, 8, 512, 4444, steric=True)
+            item(s, inp, lambda s, w: s.step(2))
+
+
+PMC_ITEMS = ['headline', 'per_step_launch', 'beyond_cache_per_step', 'beyond_cache_fused', 'physical_pair', 'physical_sweep']
+PMC_GROUPS = [['FETCH_SIZE'], ['WRITE_SIZE'],
+              ['SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_INSTS_LDS', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY',
+               'SQ_ACTIVE_INST_VALU']]
+
+
+def collect_pmc(args):
+    """rocprofv3 --pmc passes over the child (run BEFORE this process touches the GPU).  Returns {item: {...}} or {'error': str}."""
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return {'error': 'rocprofv3 not found'}
+    tmp = tempfile.mkdtemp(prefix='catint_pmc_', dir='/tmp')
+    child = [sys.executable, os.path.abspath(__file__), '--pmc-child', '--batch', str(args.batch), '--nspecies', str(args.nspecies),
+             '--nx', str(args.nx), '--method', args.method, '--steps', str(args.steps), '--steps-per-launch', str(args.steps_per_launch),
+             '--physical-steps', str(args.physical_steps)] + (['--no-extras'] if args.no_extras else [])
+    env = dict(os.environ, TMPDIR='/tmp')
+    out = {}
+    try:
+        for gi, grp in enumerate(PMC_GROUPS):
+            d = os.path.join(tmp, 'g%d' % gi)
+            r = subprocess.run([exe, '--pmc'] + grp + ['--output-format', 'csv', '-d', d, '--'] + child, cwd='/tmp', env=env,
+                               capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return {'error': 'rocprofv3 pass %s failed (rc %d): %s' % (grp[0], r.returncode, (r.stderr or r.stdout)[-300:])}
+            rows = list(csv.DictReader(open(files[0])))
+            disp = {}
+            for row in rows:                       # one row per (dispatch, counter)
+                dd = disp.setdefault(int(row['Dispatch_Id']), {'kernel': row['Kernel_Name'], 'grid': int(row['Grid_Size']),
+                                                                 'wg': int(row['Workgroup_Size']), 'vgpr': int(row.get('VGPR_Count', 0) or 0),
+                                                                 'scratch': int(row.get('Scratch_Size', 0) or 0), 'c': {}})
+                dd['c'][row['Counter_Name']] = dd['c'].get(row['Counter_Name'], 0.0) + float(row['Counter_Value'])
+            seq = [disp[k] for k in sorted(disp)]
+            # segments: marker (surface_kernel) ... timed launches ... marker
+            marks = [i for i, dd in enumerate(seq) if 'surface_kernel' in dd['kernel']]
+            for it, name in enumerate(PMC_ITEMS):
+                if 2 * it + 1 >= len(marks):
+                    break
+                seg = seq[marks[2 * it] + 1:marks[2 * it + 1]]
+                seg = [dd for dd in seg if 'step_kernel' in dd['kernel'] or 'newton' in dd['kernel']]
+                if not seg:
+                    continue
+                main = max(set(dd['kernel'] for dd in seg), key=lambda k: sum(1 for dd in seg if dd['kernel'] == k))
+                seg = [dd for dd in seg if dd['kernel'] == main]
+                rec = out.setdefault(name, {'kernel': main.split('(')[0].replace('void ', ''), 'grid_threads': seg[0]['grid'],
+                                            'workgroup': seg[0]['wg'], 'vgpr': seg[0]['vgpr'], 'scratch_bytes': seg[0]['scratch'],
+                                            'launches': len(seg)})
+                for cname in grp:
+                    vals = sorted(dd['c'].get(cname, 0.0) for dd in seg)
+                    rec[cname] = vals[len(vals) // 2]
+    except Exception as e:       # never let the counters break the headline
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for rec in out.values():
+        if 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
+            # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2
+            rec['hbm_bytes_per_launch'] = (2.0 * rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024.0
+    return out
+
+
+def limiter_from_sq(rec):
+    """What the SQ counters of a launch say binds it (shares of wave lifetime; quad-cycle counters, ratios are unit-free)."""
+    if not rec or 'SQ_WAVE_CYCLES' not in rec or rec['SQ_WAVE_CYCLES'] <= 0:
+        return None
+    wc = rec['SQ_WAVE_CYCLES']
+    waves = max(rec.get('SQ_WAVES', 0.0), 1.0)
+    busy = rec.get('SQ_BUSY_CYCLES', 0.0)
+    d = {'wait_any_share': rec.get('SQ_WAIT_ANY', 0.0) / wc, 'wait_inst_share': rec.get('SQ_WAIT_INST_ANY', 0.0) / wc,
+         'valu_active_share_per_wave': rec.get('SQ_ACTIVE_INST_VALU', 0.0) / wc,
+         'valu_insts_per_wave': rec.get('SQ_INSTS_VALU', 0.0) / waves, 'lds_insts_per_wave': rec.get('SQ_INSTS_LDS', 0.0) / waves}
+    # the largest share of a wave's lifetime names the limiter (shares of parked / issue-stalled / issuing-VALU wave cycles)
+    d['binds'] = max([(d['wait_any_share'], 'waves parked in s_waitcnt (memory / LDS latency)'),
+                      (d['wait_inst_share'], 'issue stalls (dependent fp64 chains, busy pipes)'),
+                      (d['valu_active_share_per_wave'], 'VALU issue')])[1]
+    if busy > 0:
+        d['sq_busy_cycles'] = busy
+    return d
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(prob, c0, pb, vz, fl, method, target_s):
     """The oracle (C port of the reference algorithm, Thomas solves) on the host cores this process may use."""
     from oracle import c_oracle as CO
@@ -96,47 +243,91 @@ def cpu_reference_faithful(prob, c0, pb, vz, fl, method):
     return n / (time.perf_counter() - t0)
 
 
-def physical_mode(args, device, with_cpu):
-    """Implicit physical mode (PNP_METHOD_NEWTON) on the headline shape with SURVEY 8(d)'s synthetic inputs:
-    phiM ~ U(-0.2, 0.2) V, dt = 0.1 lambda_D L / D_max, Newton to a scaled update of 1e-8."""
-    from catint_amd import _capi
-    from catint_amd.synthetic import make_batch
+def timed_steps(s, nsteps, spl, reps=1):
+    """HIP-event time (ms) of pnp_step(nsteps, spl) on the library's stream, median over reps."""
+    ms = []
+    for _ in range(reps):
+        s.timer_start()
+        s.step(nsteps, spl)
+        ms.append(s.timer_stop())
+    return float(np.median(ms))
+
+
+def hbm_record(B, N, nx, steps, launches, ev_ms, pmc):
+    """Record of a timed compat run: algorithmic bytes, per-launch event time, measured traffic when the counters are there."""
+    alg = 16.0 * (N + 1) * nx * B * steps / launches
+    launch_s = ev_ms * 1e-3 / launches
+    rec = {'timesteps_per_s': B * steps / (ev_ms * 1e-3), 'launch_us': launch_s * 1e6, 'timesteps_per_launch': steps / launches,
+           'algorithmic_bytes_per_launch': alg, 'achieved_GBs': alg / launch_s / 1e9, 'frac': alg / launch_s / 1e9 / HBM_PEAK_GBS,
+           'traffic': None}
+    if pmc and 'hbm_bytes_per_launch' in pmc:
+        rec['traffic'] = pmc['hbm_bytes_per_launch']
+        rec['traffic_over_algorithmic'] = pmc['hbm_bytes_per_launch'] / alg
+        rec['hbm_GBs_measured'] = pmc['hbm_bytes_per_launch'] / launch_s / 1e9
+        rec['hbm_frac_measured'] = rec['hbm_GBs_measured'] / HBM_PEAK_GBS
+        rec['kernel'] = pmc.get('kernel')
+        rec['kernel_resources'] = {k: pmc.get(k) for k in ('grid_threads', 'workgroup', 'vgpr', 'scratch_bytes')}
+        lim = limiter_from_sq(pmc)
+        if lim:
+            rec['sq'] = lim
+    return rec
+
+
+def physical_mode(args, device, with_cpu, pmc):
+    """Implicit physical mode (PNP_METHOD_NEWTON) with SURVEY 8(d)'s synthetic inputs: phiM ~ U(-0.2, 0.2) V, dt = 0.1 lambda_D L / D_max,
+    Newton to a scaled update of 1e-8.  Not HBM-bound: its roofline is fp64 VALU issue (and LDS exchange); measured per kernel."""
     B, N, nx = args.batch, args.nspecies, args.nx
-    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=4242, phi_max=0.2, dt_factor=0.1)
-    pb = np.nan_to_num(pb)
-    s = _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=B,
-                        device=device)
-    s.set_newton(tol=1e-8)
+
+    def newton_roofline(rec, iters_per_s, lanes, alg_bytes_per_iter):
+        if not rec or 'SQ_INSTS_VALU' not in rec:
+            return None
+        # per launch: SQ_INSTS_VALU wave-instructions x 64 lanes; upper bound on fp64 lane-operations (integer/select VALU included)
+        lane_ops = rec['SQ_INSTS_VALU'] * 64.0
+        out = {'bound': 'fp64 VALU issue', 'kernel': rec.get('kernel'), 'valu_wave_insts_per_launch': rec['SQ_INSTS_VALU'],
+               'lds_wave_insts_per_launch': rec.get('SQ_INSTS_LDS'), 'peak_fp64_lane_ops_per_s': FP64_VALU_PEAK,
+               'kernel_resources': {k: rec.get(k) for k in ('grid_threads', 'workgroup', 'vgpr', 'scratch_bytes')}}
+        if 'hbm_bytes_per_launch' in rec:
+            out['hbm_bytes_per_launch'] = rec['hbm_bytes_per_launch']
+        lim = limiter_from_sq(rec)
+        if lim:
+            out['sq'] = lim
+        return out, lane_ops
+
+    s, (prob, c0, pb, vz, fl) = newton_solver(B, N, nx, 4242, device)
     s.set_batch(c0, pb, vz, fl)
     s.step(5)
     s.synchronize()
-    s.timer_start()
-    s.step(args.physical_steps)
-    ms = s.timer_stop()
+    ms = timed_steps(s, args.physical_steps, 0)
     it = s.newton_iterations()
     ok = int((s.get_status() == 0).sum())
+    # the launch shape the counters were collected on: 3 steps
+    s.set_batch(c0, pb, vz, fl)
+    s.step(3)
+    ms3 = timed_steps(s, 3, 0)
+    it3 = float(s.newton_iterations().sum())
     s.close()
     sec = ms * 1e-3
-    # fp64 VALU instructions per Newton iteration and lane of the pair kernel for N = 3 (static count of the ISA,
-    # tools/probe/census_newton.py: 256 threads x (760 + 552 + 8 x 288 + 100)); peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
     out = {'workload': 'batch=%d, %d species, %d points, backward Euler dt=%.3g s, Dirichlet wall, tol 1e-8' % (B, N, nx, prob.dt),
            'timesteps_per_s': B * args.physical_steps / sec, 'newton_iterations_per_s': float(it.sum()) / sec,
            'mean_newton_iterations_per_step': float(it.sum()) / (B * args.physical_steps),
-           'ms_per_step': ms / args.physical_steps, 'lanes_ok': ok, 'bound': 'fp64 VALU issue / LDS exchange (not HBM)'}
-    if N == 3 and nx <= 512:
-        out['fp64_valu_util'] = 256 * 3716.0 * out['newton_iterations_per_s'] / (256 * 4 * 16 * 2.4e9)
-    # the same steps with the quadratic error estimate as the stopping rule (pnp_newton_params.error_estimate: stop when the
-    # NEXT update is predicted below tol -- the state meets the same tolerance, the last confirming iteration is not spent)
+           'ms_per_step': ms / args.physical_steps, 'lanes_ok': ok}
+    r = newton_roofline(pmc.get('physical_pair') if isinstance(pmc, dict) else None, 0, B, 0)
+    if r:
+        roof, lane_ops = r
+        roof['achieved_fp64_lane_ops_per_s'] = lane_ops / (ms3 * 1e-3)
+        roof['frac'] = roof['achieved_fp64_lane_ops_per_s'] / FP64_VALU_PEAK
+        roof['valu_wave_insts_per_lane_iteration'] = roof['valu_wave_insts_per_launch'] / max(it3, 1.0)
+        if 'hbm_bytes_per_launch' in roof:
+            roof['hbm_bytes_per_lane_iteration'] = roof['hbm_bytes_per_launch'] / max(it3, 1.0)
+            roof['algorithmic_state_bytes_per_lane_timestep'] = 16.0 * (N + 1) * nx
+        out['roofline'] = roof
     try:
-        s = _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=B,
-                            device=device)
+        s, inp = newton_solver(B, N, nx, 4242, device)
         s.set_newton(tol=1e-8, error_estimate=True)
-        s.set_batch(c0, pb, vz, fl)
+        s.set_batch(*inp[1:])
         s.step(5)
         s.synchronize()
-        s.timer_start()
-        s.step(args.physical_steps)
-        ms_e = s.timer_stop()
+        ms_e = timed_steps(s, args.physical_steps, 0)
         it_e = s.newton_iterations()
         ok_e = int((s.get_status() == 0).sum())
         s.close()
@@ -144,18 +335,14 @@ def physical_mode(args, device, with_cpu):
                                       'mean_newton_iterations_per_step': float(it_e.sum()) / (B * args.physical_steps), 'lanes_ok': ok_e}
     except Exception as e:
         out['with_error_estimate'] = {'error': str(e)}
-    # BASELINE configs[4] shape in the same mode: 8 species (size-modified, Stern wall), 4096 points -- lane-team kernel
+    # BASELINE configs[4] shape in the same mode: 8 species (size-modified, Stern wall), 4096 points
     try:
         LB = max(64, min(1024, B))
-        p8, c8, pb8, vz8, fl8 = make_batch(LB, 8, 4096, seed=4343, phi_max=0.2, dt_factor=0.1)
-        s8 = _capi.PnpSolver(8, 4096, p8.dx, p8.dt, p8.beta, p8.eps, p8.D, p8.charges, method='Newton', batch_capacity=LB, device=device)
-        s8.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=1e-8, mpb_radius=[4.1e-10, 3.6e-10, 3.3e-10, 3e-10, 3e-10, 3e-10, 4.5e-10, 3.5e-10])
-        s8.set_batch(c8, np.nan_to_num(pb8), vz8, fl8)
+        s8, inp = newton_solver(LB, 8, 4096, 4343, device, steric=True)
+        s8.set_batch(*inp[1:])
         s8.step(1)
         s8.synchronize()
-        s8.timer_start()
-        s8.step(3)
-        ms8 = s8.timer_stop()
+        ms8 = timed_steps(s8, 3, 0)
         it8 = s8.newton_iterations()
         ok8 = int((s8.get_status() == 0).sum())
         s8.close()
@@ -167,21 +354,30 @@ def physical_mode(args, device, with_cpu):
     # large batch of large blocks: the sweep kernel (block Thomas, one lane team per operating point)
     try:
         SB = 8192
-        p8, c8, pb8, vz8, fl8 = make_batch(SB, 8, 512, seed=4444, phi_max=0.2, dt_factor=0.1)
-        s8 = _capi.PnpSolver(8, 512, p8.dx, p8.dt, p8.beta, p8.eps, p8.D, p8.charges, method='Newton', batch_capacity=SB, device=device)
-        s8.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=1e-8, mpb_radius=[4.1e-10, 3.6e-10, 3.3e-10, 3e-10, 3e-10, 3e-10, 4.5e-10, 3.5e-10])
-        s8.set_batch(c8, np.nan_to_num(pb8), vz8, fl8)
+        s8, inp = newton_solver(SB, 8, 512, 4444, device, steric=True)
+        s8.set_batch(*inp[1:])
         s8.step(1)
         s8.synchronize()
-        s8.timer_start()
-        s8.step(4)
-        ms8 = s8.timer_stop()
+        ms8 = timed_steps(s8, 4, 0)
         it8 = s8.newton_iterations()
         ok8 = int((s8.get_status() == 0).sum())
+        s8.set_batch(*inp[1:])
+        s8.step(2)
+        ms2 = timed_steps(s8, 2, 0)
+        it2 = float(s8.newton_iterations().sum())
         s8.close()
-        out['large_batch_8_species'] = {'workload': 'batch=%d, 8 species size-modified, 512 points, Stern wall (sweep kernel)' % SB,
-                                        'timesteps_per_s': SB * 4 / (ms8 * 1e-3), 'newton_iterations_per_s': float(it8.sum()) / (ms8 * 1e-3),
-                                        'lanes_ok': ok8}
+        rec = {'workload': 'batch=%d, 8 species size-modified, 512 points, Stern wall (sweep kernel)' % SB,
+               'timesteps_per_s': SB * 4 / (ms8 * 1e-3), 'newton_iterations_per_s': float(it8.sum()) / (ms8 * 1e-3), 'lanes_ok': ok8}
+        r = newton_roofline(pmc.get('physical_sweep') if isinstance(pmc, dict) else None, 0, SB, 0)
+        if r:
+            roof, lane_ops = r
+            roof['achieved_fp64_lane_ops_per_s'] = lane_ops / (ms2 * 1e-3)
+            roof['frac'] = roof['achieved_fp64_lane_ops_per_s'] / FP64_VALU_PEAK
+            roof['valu_wave_insts_per_lane_iteration'] = roof['valu_wave_insts_per_launch'] / max(it2, 1.0)
+            if 'hbm_bytes_per_launch' in roof:
+                roof['hbm_bytes_per_lane_iteration'] = roof['hbm_bytes_per_launch'] / max(it2, 1.0)
+            rec['roofline'] = roof
+        out['large_batch_8_species'] = rec
     except Exception as e:
         out['large_batch_8_species'] = {'error': str(e)}
     if with_cpu:
@@ -198,9 +394,16 @@ def physical_mode(args, device, with_cpu):
 
 def main():
     args = parse()
+    if args.pmc_child:
+        pmc_child(args)
+        return
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # counters first: the child processes must be started before this process initialises the GPU
+    pmc = {'error': 'skipped'}
+    if rank == 0 and world == 1 and not args.no_pmc:
+        pmc = collect_pmc(args)
     import torch
     dist = None
     if not torch.cuda.is_available():
@@ -218,12 +421,8 @@ def main():
     torch.cuda.set_device(device)
     comm_dev = torch.device('cuda', device) if backend == 'nccl' else torch.device('cpu')
 
-    from catint_amd.synthetic import make_batch
-    from catint_amd.host import solver_from_problem
     B, N, nx = args.batch, args.nspecies, args.nx
-    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=1000 + rank, phi_max=0.025, dt_factor=1e-5)
-    solver = solver_from_problem(prob, args.method, batch_capacity=B, device=device)
-    solver.set_batch(c0, pb, vz, fl)
+    solver, (prob, c0, pb, vz, fl) = compat_solver(B, N, nx, args.method, 1000 + rank, device)
 
     def barrier():
         solver.synchronize()
@@ -246,17 +445,20 @@ def main():
             wall, ev_ms = float(t[0]), float(t[1])
         return wall, ev_ms
 
-    # Settling (untimed, not part of W).  Measured (tools/probe/cold_start_probe.py, slow_start_probe*.py): the clocks of a cold
-    # GPU settle over ~0.1 s of load, and the first two or three launches that follow an upload (pnp_set_batch) run 1.5x slower
-    # from start to end however long they are.  The number reported is the sustained rate of a trajectory in flight: 0.3 s of load
-    # on a throw-away trajectory, then the state is uploaded and four 8-step launches take the slow launches; the W warmup steps
-    # and the K timed steps follow on the same trajectory.  (The reference's lagged-potential integrator does not survive
-    # long runs on this workload -- lanes turn NaN after ~3000 steps, tools/probe/long_trajectory_probe.py, in the oracle too --
-    # hence the fresh upload; lanes_ok reports the state the timed steps leave behind.)
+    # ---- settling (untimed, not part of W): code objects loaded, clocks up (a cold GPU's clocks settle over ~0.1 s of load) ---------
+    solver.set_batch(c0, pb, vz, fl)
+    solver.step(args.steps, args.steps_per_launch)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.3:
         solver.step(512, args.steps_per_launch)
         solver.synchronize()
+    # ---- what a caller sees right after an upload: pnp_set_batch, then immediately the K-step launch (reported next to the sustained
+    # rate; the first launches after an upload run slower, cause not identified -- DESIGN.md section 6).  The reference's
+    # lagged-potential integrator does not survive long runs on this workload (lanes turn NaN after ~3000 steps, in the oracle
+    # too), hence the fresh upload before the timed region as well.
+    solver.set_batch(c0, pb, vz, fl)
+    cold_wall, cold_ev = timed(args.steps, args.steps_per_launch)
+    # ---- sustained rate: upload, four 8-step launches, the W warm-up steps, then the K timed steps ------------------------------------
     solver.set_batch(c0, pb, vz, fl)
     for _ in range(4):
         solver.step(8, 8)
@@ -267,15 +469,14 @@ def main():
     steps_total = world * B * args.steps
     value = steps_total / wall
 
-    # one launch per timestep (state read from and written to HBM by every launch) -- reported next to the headline
-    fused = None
-    if not args.no_fused and args.steps_per_launch != 1:
+    extras = rank == 0 and world == 1 and not args.no_extras
+    per_step = None
+    if extras and args.steps_per_launch != 1:
         solver.step(64, 1)
-        fw, fe = timed(args.steps, 1)
-        lsec = fe * 1e-3 / args.steps
-        fused = {'timesteps_per_s': world * B * args.steps / fw, 'ms_per_step': fw / args.steps * 1e3,
-                 'steps_per_launch': 1, 'launch_us': lsec * 1e6,
-                 'frac': 16.0 * (N + 1) * nx * B / lsec / 1e9 / HBM_PEAK_GBS}
+        fw, fe = timed(args.steps, 1)          # K launches back to back, no host synchronisation in between
+        per_step = hbm_record(B, N, nx, args.steps, args.steps, fe, pmc.get('per_step_launch'))
+        per_step.update({'wall_timesteps_per_s': B * args.steps / fw, 'ms_per_step_wall': fw / args.steps * 1e3, 'steps_per_launch': 1,
+                         'wall_over_event': fw / (fe * 1e-3)})
 
     # the only exchange of the path: gather the polarization observables (RCCL all_gather over xGMI)
     cs, vs, es = solver.get_surface()
@@ -291,44 +492,73 @@ def main():
         assert curve.shape == (world * B, N + 2)
     solver.close()
 
-    # oversubscribed regime (not the headline): same lanes-shape, many more of them than SIMDs
     large = None
-    if world == 1 and args.large_batch > 0:
+    if extras and args.large_batch > 0:
         LB = args.large_batch
-        lp, lc0, lpb, lvz, lfl = make_batch(LB, N, nx, seed=77, phi_max=0.025, dt_factor=1e-5)
-        s2 = solver_from_problem(lp, args.method, batch_capacity=LB, device=device)
-        s2.set_batch(lc0, lpb, lvz, lfl)
+        s2, inp = compat_solver(LB, N, nx, args.method, 77, device)
+        s2.set_batch(*inp[1:])
         s2.step(64, 1)
         ls = max(10, min(args.steps, 50))
         s2.synchronize()
-        s2.timer_start()
-        s2.step(ls, 1)
-        lms = s2.timer_stop()
+        lms = timed_steps(s2, ls, 1)
         lok = int((s2.get_status() == 0).sum())
+        large = hbm_record(LB, N, nx, ls, ls, lms, None)
+        large.update({'batch': LB, 'steps': ls, 'lanes_ok': lok, 'steps_per_launch': 1, 'state_MB': 8.0 * (N + 2) * nx * LB / 1e6})
+        s2.set_batch(*inp[1:])
+        for _ in range(4):
+            s2.step(8, 8)
+        s2.step(args.steps_per_launch, args.steps_per_launch)
+        s2.synchronize()
+        fms = timed_steps(s2, args.steps, args.steps_per_launch)
         s2.close()
-        lsec = lms * 1e-3 / ls
-        large = {'batch': LB, 'steps': ls, 'timesteps_per_s': LB / lsec, 'launch_us': lsec * 1e6,
-                 'achieved_GBs': 16.0 * (N + 1) * nx * LB / lsec / 1e9,
-                 'frac': 16.0 * (N + 1) * nx * LB / lsec / 1e9 / HBM_PEAK_GBS, 'lanes_ok': lok, 'steps_per_launch': 1}
-        # the same batch in fused launches (like the headline)
-        s3 = solver_from_problem(lp, args.method, batch_capacity=LB, device=device)
-        s3.set_batch(lc0, lpb, lvz, lfl)
-        for _ in range(4):        # past the slow launches that follow an upload (see above)
-            s3.step(8, 8)
-        s3.step(args.steps_per_launch, args.steps_per_launch)
-        s3.synchronize()
-        s3.timer_start()
-        s3.step(args.steps, args.steps_per_launch)
-        fms = s3.timer_stop()
-        s3.close()
         large['fused'] = {'timesteps_per_s': LB * args.steps / (fms * 1e-3), 'steps_per_launch': args.steps_per_launch,
                           'frac': 16.0 * (N + 1) * nx * LB * args.steps / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
+    beyond = None
+    if extras:
+        BB, BN, BX = BC_SHAPE
+        try:
+            s3, inp = compat_solver(BB, BN, BX, args.method, 55, device)
+            s3.set_batch(*inp[1:])
+            s3.step(8, 1)
+            s3.synchronize()
+            ms1 = timed_steps(s3, 8, 1, reps=3)
+            ok1 = int((s3.get_status() == 0).sum())
+            rec1 = hbm_record(BB, BN, BX, 8, 8, ms1, pmc.get('beyond_cache_per_step'))
+            s3.set_batch(*inp[1:])
+            s3.step(32, 32)
+            s3.synchronize()
+            ms32 = timed_steps(s3, 32, 32, reps=3)
+            rec32 = hbm_record(BB, BN, BX, 32, 1, ms32, pmc.get('beyond_cache_fused'))
+            s3.close()
+            beyond = {'workload': "one GPU's share of BASELINE configs[3]: batch=%d, %d species, %d grid points, Crank-Nicolson compat "
+                                  'integrator' % (BB, BN, BX), 'state_MB': 8.0 * (BN + 2) * BX * BB / 1e6, 'lanes_ok': ok1,
+                      'per_step_launch': rec1, 'fused_32_steps_per_launch': rec32}
+        except Exception as e:
+            beyond = {'error': '%s: %s' % (type(e).__name__, e)}
+
     if rank == 0:
         # 2*8*(N+1)*nx bytes per lane-timestep; a launch advances B lanes by steps_per_launch steps
-        alg_bytes_per_launch = 16.0 * (N + 1) * nx * B * args.steps / n_launch
-        launch_s = ev_ms * 1e-3 / n_launch
-        achieved = alg_bytes_per_launch / launch_s / 1e9
+        head = hbm_record(B, N, nx, args.steps, n_launch, ev_ms, pmc.get('headline') if isinstance(pmc, dict) else None)
+        roof = {'bound': 'hbm', 'achieved': head['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': head['frac'],
+                'traffic': head['traffic'],
+                'kernel': head.get('kernel') or 'pnp::step_kernel* (P=%d points/lane)' % next((P for P in (1, 2, 4, 8, 16) if nx - 2 <= 64 * P), 16),
+                'launch_us': head['launch_us'], 'algorithmic_bytes_per_launch': head['algorithmic_bytes_per_launch'],
+                'timesteps_per_launch': head['timesteps_per_launch'],
+                'achieved_is': 'algorithmic bytes (16(N+1)nx per lane-timestep, state written every step) / HIP-event launch time'}
+        for k in ('traffic_over_algorithmic', 'hbm_GBs_measured', 'hbm_frac_measured', 'kernel_resources', 'sq'):
+            if k in head:
+                roof[k] = head[k]
+        if head['traffic'] is not None:
+            roof['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ (separate passes) over this command\'s launch shapes, ' \
+                                     'collected by this run before its timed region; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB'
+            if head['traffic_over_algorithmic'] < 0.7:
+                roof['note'] = ('fused launch: the previous state is re-used from LDS/registers and L2 write-combines successive steps, so ' +
+                                'HBM sees %.2fx the algorithmic bytes -- this launch is bound by %s, not by HBM; the HBM-bound figures are ' +
+                                'per_step_launch and beyond_cache') % (head['traffic_over_algorithmic'],
+                                                                       head.get('sq', {}).get('binds', 'the latency chain of a step'))
+        else:
+            roof['traffic_reason'] = pmc.get('error', 'no counters for this launch') if isinstance(pmc, dict) else 'no counters'
         out = {
             'metric': 'batched 1D PNP Newton-timesteps/sec', 'value': value, 'unit': 'timesteps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
@@ -337,37 +567,22 @@ def main():
                                    'compat integrator, Dirichlet-Dirichlet Poisson' % (B, N, nx, args.method),
                        'batch_per_gpu': B, 'nspecies': N, 'nx': nx, 'steps_per_launch': args.steps_per_launch,
                        'parallelism': 'batch-sharded x%d' % world},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'pnp::step_kernel* (P=%d points/lane)' % next((P for P in (1, 2, 4, 8, 16) if nx - 2 <= 64 * P), 16),
-                         'launch_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg_bytes_per_launch,
-                         'timesteps_per_launch': args.steps / n_launch},
+            'roofline': roof,
+            'timed_region': {'wall_us': wall * 1e6, 'event_us': ev_ms * 1e3, 'host_launch_and_sync_us': wall * 1e6 - ev_ms * 1e3,
+                             'event_timesteps_per_s': B * args.steps / (ev_ms * 1e-3), 'wall_over_event': wall / (ev_ms * 1e-3)},
+            'first_launch_after_upload': {'timesteps_per_s_wall': world * B * args.steps / cold_wall,
+                                          'timesteps_per_s_event': B * args.steps / (cold_ev * 1e-3), 'event_us': cold_ev * 1e3,
+                                          'sustained_over_cold': (cold_ev / ev_ms) if ev_ms > 0 else None},
             'lanes_ok': int((status == 0).sum()), 'lanes_total': int(B),
         }
-        # measured HBM bytes per launch come from a separate rocprofv3 --pmc pass of this same command
-        # (profiles/, MI355X_MICROARCH.md HBM section: FETCH_SIZE doubled on gfx950); null when absent
-        try:
-            tj = json.load(open(args.traffic_json))
-            # only for the launch shape the counters were collected on (same lanes, same fused launch length)
-            if (tj.get('batch'), tj.get('nspecies'), tj.get('nx'), tj.get('steps_per_launch')) == \
-                    (B, N, nx, args.steps_per_launch) and tj.get('method') == args.method and \
-                    args.steps == n_launch * args.steps_per_launch and world == 1:
-                out['roofline']['traffic'] = tj['hbm_bytes_per_launch']
-                out['roofline']['traffic_source'] = tj.get('source')
-                if tj.get('sq_insts_valu_per_wave'):
-                    # fp64 vector utilisation next to the HBM figure.  Every VALU instruction of the kernel counted as
-                    # a 64-lane fp64 operation (upper bound; SQ_INSTS_VALU of the same rocprofv3 run) against 256 CUs x 4 SIMDs x
-                    # 16 fp64 lanes per cycle x 2.4 GHz
-                    lane_ops = tj['sq_insts_valu_per_wave'] / args.steps_per_launch * tj.get('waves_per_lane', 1.0) * 64.0
-                    out['roofline']['fp64_valu_util'] = lane_ops * (B / launch_s * args.steps / n_launch) / (256 * 4 * 16 * 2.4e9)
-        except Exception:
-            pass
-        if fused:
-            out['per_step_launch'] = fused
+        if per_step:
+            out['per_step_launch'] = per_step
         if large:
             out['large_batch'] = large
-        if world == 1 and args.physical_steps > 0:
-            out['physical_mode'] = physical_mode(args, device, not args.no_cpu_baseline)
+        if beyond:
+            out['beyond_cache'] = beyond
+        if extras and args.physical_steps > 0:
+            out['physical_mode'] = physical_mode(args, device, not args.no_cpu_baseline, pmc if isinstance(pmc, dict) else {})
         if gather_ms is not None:
             out['gather_ms'] = gather_ms
         if world == 1 and not args.no_cpu_baseline:

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "pnp_internal.h"
+#include "pnp_step_table.h"
 
 using namespace pnp;
 
@@ -395,6 +396,25 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   return PNP_OK;
 }
 
+// nearest measured entry: exact points per lane and launch mode, nearest species count (ties to the smaller), nearest batch
+// bucket on a log scale
+static const StepTableEntry* lookup_step(int N, int P, int64_t B, bool fused) {
+  const StepTableEntry* best = nullptr;
+  double best_d = 1e300;
+  for (int i = 0; i < kStepTableSize; ++i) {
+    const StepTableEntry& e = kStepTable[i];
+    if (e.P != P || e.fused != (fused ? 1 : 0)) continue;
+    const double dn = std::fabs((double)(e.N - N)) + (e.N > N ? 0.25 : 0.0);
+    const double db = std::fabs(std::log2((double)(B < 1 ? 1 : B)) - std::log2((double)e.B));
+    const double d = dn * 100.0 + db;
+    if (d < best_d) {
+      best_d = d;
+      best = &e;
+    }
+  }
+  return best;
+}
+
 // one or more fused timesteps in a single launch
 static int run_steps(pnp_handle* h, int nsteps) {
   DevArgs a = h->a;
@@ -405,42 +425,34 @@ static int run_steps(pnp_handle* h, int nsteps) {
     if (nsteps != 1) return fail(h, PNP_EINVAL, "internal: rate terms need one step per launch");
     HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
   }
-  // Measured on MI355X.  One timestep per launch: while the batch has fewer lanes than ~2 per SIMD
-  // the LDS-staged kernel with three interleaved species per wave has the shortest critical path; once the batch
-  // oversubscribes the chip the register-resident kernel (one wave per lane, 3 waves/SIMD) wins because the LDS pipe
-  // stops being the shared bottleneck.  P = 16 keeps the LDS-staged kernel (twice the occupancy).
+  // grids beyond 1026 points: several waves per tridiagonal system
   if (waves_per_system(a.nx) > 1) {
     HIP_TRY(h, launch_step_mw(a, h->stream));
     if (nsteps & 1) h->cur = 1 - h->cur;
     h->steps_done += nsteps;
     return PNP_OK;
   }
-  // Fused launches: the LDS-staged kernel with one species per wave (choose_step_config) at every batch size
-  // (0.75-0.78 of the roofline for B = 1024...16384 against 0.52-0.63), measured with CATINT_PNP_KERNEL=2/4
-  // ... except where one species per wave does not pay (tools/probe/step_config_probe.py): N >= 5 species (more than the waves
-  // of a workgroup hold one each; N = 6: 0.65-0.71 against 0.53-0.65, N = 8: 0.65-0.69 against 0.57-0.63) and short grids
-  // (at most 4 points per lane; N = 2, nx = 200: 0.52-0.65 against 0.48-0.51, N = 3, nx = 256: 0.62-0.70 against 0.47-0.57)
-  // from B = 2048 lanes on: the register-resident kernel, one wave per lane.  Two points per lane at small batch: the same
-  // kernel with one species per wave (N = 3, nx = 128, B = 1024: 0.35 against 0.19-0.28).
+  // Which kernel: the measured table (pnp_step_table.h, generated by tools/make_step_table.py from a sweep of every variant
+  // over species count x points per lane x batch x fused/per-step on an MI355X: profiles/r02_config_sweep.jsonl) at the nearest
+  // measured species count and batch bucket.  The register-resident and streaming kernels cover the Dirichlet/Dirichlet Poisson
+  // branch with an even number of points per lane and no FTCS rate term; everything else runs the LDS-staged kernel with the
+  // table's (W, G) when the entry is of that family, else with choose_step_config's.
   const bool fused = nsteps >= 8;
-  bool rr = step_rr_applicable(a) && h->P <= 8 &&
-            ((!fused && a.B >= 2048) || (fused && a.B >= 2048 && (h->P <= 4 || a.N >= 5)));
-  int rr_waves = 1;
-  if (fused && step_rr_applicable(a) && h->P == 2 && a.B < 2048) {
-    rr = true;
-    rr_waves = a.N < 3 ? a.N : 3;
-  }
-  if (h->kernel_override == 2) rr = false;
-  if (h->kernel_override == 4) rr = step_rr_applicable(a);
-  if ((h->kernel_override == 5 || h->kernel_override == 6) && step_rr_applicable(a)) {
+  const StepTableEntry* te = lookup_step(a.N, h->P, a.B, fused);
+  int kind = te ? te->kind : 0, W = te ? te->W : 1, G = te ? te->G : 1;
+  const bool direct_ok = step_rr_applicable(a);
+  if (kind != 0 && !direct_ok) kind = 0, W = 0;
+  if (h->kernel_override == 2) kind = 0, W = (te && te->kind == 0) ? W : 0;
+  if (h->kernel_override == 4 && direct_ok) kind = 1, W = (te && te->kind == 1) ? W : 1;
+  if ((h->kernel_override == 5 || h->kernel_override == 6) && direct_ok) kind = 2;
+  if (kind == 2) {
     HIP_TRY(h, launch_step_st(a, h->kernel_override == 6 ? 1 : 0, h->stream));
-  } else if (rr) {
-    int w = rr_waves;
+  } else if (kind == 1) {
+    int w = W;
     if (h->waves_override >= 1 && h->waves_override <= 4) w = h->waves_override;
     HIP_TRY(h, launch_step_rr(a, w, h->stream));
   } else {
-    int W = 1, G = 1;
-    choose_step_config(a.N, a.B, h->P, nsteps >= 8, &W, &G);
+    if (W == 0 || !step_config_supported(W, G)) choose_step_config(a.N, a.B, h->P, fused, &W, &G);
     if (h->waves_override >= 1 || h->species_override >= 1) {
       const int w2 = h->waves_override >= 1 ? h->waves_override : W;
       const int g2 = h->species_override >= 1 ? h->species_override : 1;
