@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libcatint_pnp.so')
+LIB_PATH = os.environ.get('CATINT_PNP_LIB') or os.path.join(_HERE, 'lib', 'libcatint_pnp.so')   # (env: diagnosis builds of tools/probe)
 
 PNP_MAX_SPECIES = 16
 PNP_MAX_REACTIONS = 16

@@ -444,9 +444,12 @@ static int run_steps(pnp_handle* h, int nsteps) {
   if (kind != 0 && !direct_ok) kind = 0, W = 0;
   if (h->kernel_override == 2) kind = 0, W = (te && te->kind == 0) ? W : 0;
   if (h->kernel_override == 4 && direct_ok) kind = 1, W = (te && te->kind == 1) ? W : 1;
-  if ((h->kernel_override == 5 || h->kernel_override == 6) && direct_ok) kind = 2;
+  if (h->kernel_override >= 5 && h->kernel_override <= 7 && direct_ok) kind = 2;
   if (kind == 2) {
-    HIP_TRY(h, launch_step_st(a, h->kernel_override == 6 ? 1 : 0, h->stream));
+    // 16 points per lane: the gradient row of the step in LDS (two waves per SIMD instead of one: 0.53 -> 0.60 of the roofline per
+    // step and 0.68 -> 0.72 fused on one GPU's share of configs[3]); shorter grids: registers only
+    const int st_mode = h->kernel_override == 6 ? 1 : (h->kernel_override == 7 ? 2 : (h->kernel_override == 5 ? 0 : (h->P == 16 ? 2 : 0)));
+    HIP_TRY(h, launch_step_st(a, st_mode, h->stream));
   } else if (kind == 1) {
     int w = W;
     if (h->waves_override >= 1 && h->waves_override <= 4) w = h->waves_override;

@@ -39,6 +39,61 @@ __device__ __forceinline__ double poisson_wave(const DevArgs& A, double* LV, dou
   const double dx = A.dx;
   double vown[P], gown[P];
   double v1;   // v at grid point 1
+  if constexpr (!WANT_V && P >= 2) {
+    if (A.pb_mode == PNP_PB_DD) {
+      // The timestep kernels' Dirichlet-Dirichlet fast path: step_kernel_rr / step_kernel_st's register arithmetic statement for
+      // statement (DPP prefix scans instead of six LDS round trips), so that every kernel family walks the same bits:
+      //   w_i = v_{i+1}-v_i = w_0 + H_i,  H_i = sum_{j=1..i} h_j,  h = lapl*dx^2,  G_{nx-1} = sum_r (m - r) h_r,
+      //   w_0 = (vb - vw - G_{nx-1})/(nx-1),  grad_v[i] = ((w_0 + H_i) + (w_0 + H_{i-1}))/(2dx),  ends extrapolated (:785-786)
+      double Hi[P];
+      const double dx2 = A.dx2;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        double h = LV[pidx<P>(r0 + j + 1)] * dx2;
+        h = (r0 + j == m) ? 0.0 : h;                      // the bulk point is not part of the interior sum
+        Hi[j] = h;
+        s0 += h;
+        s1 = __builtin_fma((double)j, h, s1);
+      }
+      const double wsum = __builtin_fma((double)(m - r0), s0, -s1);
+      const double hm1 = pick_blocked<P>(Hi, r0, m - 1), hm2 = pick_blocked<P>(Hi, r0, m - 2);
+      const double h0 = read_lane(Hi[0], 0), h1 = read_lane(Hi[1], 0);
+#pragma unroll
+      for (int j = 1; j < P; ++j) Hi[j] += Hi[j - 1];
+      const double incT = wave_scan_incl(Hi[P - 1]);
+      const double incW = wave_scan_incl(wsum);
+      const double base = from_prev_lane(0.0, incT);
+      const double tot1 = read_lane(incT, 63), totG = read_lane(incW, 63);
+#pragma unroll
+      for (int j = 0; j < P; ++j) Hi[j] += base;          // Hi[j] = H_{grid r0+j+1}
+      const double w0 = (vb - vw - totG) / A.nxm1;
+      const double inv2dx = A.inv2dx;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const double Hx = (j == 0) ? base : Hi[j > 0 ? j - 1 : 0];
+        GV[pidx<P>(r0 + j + 1 + SHIFT)] = inv2dx * ((w0 + Hi[j]) + (w0 + Hx));     // (v[i+1]-v[i-1])/(2dx), :784
+      }
+      const double g1 = inv2dx * ((w0 + h0) + (w0 + 0.0));
+      const double g2 = inv2dx * ((w0 + (h0 + h1)) + (w0 + h0));
+      const double g_first = g1 + (g1 - g2);
+      const double Hm1 = tot1 - hm1, Hm2 = Hm1 - hm2;     // H_{nx-3}, H_{nx-4}; H_{nx-2} = tot1
+      const double gm1 = inv2dx * ((w0 + tot1) + (w0 + Hm1));
+      const double gm2 = inv2dx * ((w0 + Hm1) + (w0 + Hm2));
+      const double g_last = gm1 + (gm1 - gm2);
+      lds_sync();
+      if (lane == 0) {
+        GV[pidx<P>(0 + SHIFT)] = g_first;
+        GV[pidx<P>(nx - 1 + SHIFT)] = g_last;
+        if constexpr (SHIFT == 1) {
+          GV[pidx<P>(0)] = g_first;          // interior index -1 clamps to grad_v[0]  (add_boundary_values :496)
+          GV[pidx<P>(nx + 1)] = g_last;      // one past the end, read by the FTCS window of padded rows
+        }
+      }
+      lds_sync();
+      return vw + w0;
+    }
+  }
   if (A.pb_mode == PNP_PB_DD) {
     // v'' = lapl with v[0]=vw, v[nx-1]=vb (solve_poisson :716-730) as two prefix scans:
     // w_i = v_{i+1}-v_i = w_0 + H_i,  H_i = sum_{j=1..i} h_j,  h = lapl*dx^2

@@ -23,11 +23,21 @@ namespace pnp {
 #ifndef ST_TOUCH
 #define ST_TOUCH 0
 #endif
+// Issue priority of a wave by phase (s_setprio; waves of one SIMD are arbitrated by priority, then age).  Measured on one GPU's
+// share of configs[3] / N = 3, nx = 512, B = 32768, one launch per step (tools/probe/stream_probe.py, gpurun_out/stream_probe_prio*.txt):
+// (assembly, store) = (0,0) 0.551 / 0.552 -> (2,1) 0.584 / 0.575 -> (2,3) 0.601 / 0.592: the phases that talk to memory go first, the
+// long tridiagonal solve fills the gaps.
+#ifndef ST_PRIO_ASM
+#define ST_PRIO_ASM 2
+#endif
+#ifndef ST_PRIO_STORE
+#define ST_PRIO_STORE 3
+#endif
 #ifndef ST_TOUCH_AUX
 #define ST_TOUCH_AUX 16   // sc1: served by L2, no allocation in the (32 KiB) vector L1
 #endif
 
-template <int P, bool GL>
+template <int P, int GL>
 constexpr int step_st_min_waves() {
 #ifndef ST_MINW8
 #define ST_MINW8 3
@@ -35,7 +45,7 @@ constexpr int step_st_min_waves() {
 #ifndef ST_MINW8GL
 #define ST_MINW8GL 3
 #endif
-  return P <= 4 ? 4 : (P == 8 ? (GL ? ST_MINW8GL : ST_MINW8) : (GL ? 2 : 1));
+  return P <= 4 ? 4 : (P == 8 ? (GL ? ST_MINW8GL : ST_MINW8) : (GL ? 2 : 1));   // P = 16: two waves per SIMD need a row in LDS
 }
 
 template <int P>
@@ -49,12 +59,12 @@ constexpr int st_gl_doubles() {   // two transposed arrays [P][guard | 64 lanes 
 //         layout stored directly makes every lane's 16 bytes an L2 write request of its own: 4x the requests, measured as the
 //         limit of step_kernel_rr at large batch).  Its head doubles as the strip of the cyclic reduction.
 //   ACCS  the charge row under construction, transposed [j][lane] (conflict-free, own entries only)
-template <int P, bool GL>
+template <int P, int GL>
 constexpr int st_lds_doubles() {
-  return rowbuf_doubles<P>() + 64 * P + (GL ? st_gl_doubles<P>() : 0);
+  return rowbuf_doubles<P>() + 64 * P + (GL == 1 ? st_gl_doubles<P>() : (GL == 2 ? st_gl_doubles<P>() / 2 : 0));
 }
 
-template <int P, bool CN, bool GL>
+template <int P, bool CN, int GL>
 __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_st(const DevArgs A) {
   static_assert(P >= 2 && P % 2 == 0, "window loads need an even P");
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -147,17 +157,17 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
         const double gm1 = inv2dx * ((w0 + tot1) + (w0 + Hm1));
         const double gm2 = inv2dx * ((w0 + Hm1) + (w0 + Hm2));
         g_last = gm1 + (gm1 - gm2);
-        if constexpr (GL) {
+        if constexpr (GL != 0) {
           lds_sync();                                       // the previous step's readers of GS / LS are done
 #pragma unroll
           for (int j = 0; j < P; ++j) {
             GS[j * 66 + 1 + lane_p] = gown[j];
-            LS[j * 66 + 1 + lane_p] = lw[j + 1];
+            if constexpr (GL == 1) LS[j * 66 + 1 + lane_p] = lw[j + 1];
           }
           if (lane_p == 0) {                                  // what "lane_p -1" would hold: grad_v[0] twice (:496), lapl_v[0]
             GS[(P - 2) * 66] = g_first;
             GS[(P - 1) * 66] = g_first;
-            LS[(P - 1) * 66] = lw[0];
+            if constexpr (GL == 1) LS[(P - 1) * 66] = lw[0];
             GS[65] = 0.0;                                   // "lane_p 64", row 0 (FTCS window of the last lane_p)
           }
           lds_sync();
@@ -175,17 +185,17 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
           }
         }
       } else {
-        if constexpr (GL) {
+        if constexpr (GL != 0) {
           lds_sync();
 #pragma unroll
           for (int j = 0; j < P; ++j) {
             GS[j * 66 + 1 + lane_p] = 0.0;
-            LS[j * 66 + 1 + lane_p] = 0.0;
+            if constexpr (GL == 1) LS[j * 66 + 1 + lane_p] = 0.0;
           }
           if (lane_p == 0) {
             GS[(P - 2) * 66] = 0.0;
             GS[(P - 1) * 66] = 0.0;
-            LS[(P - 1) * 66] = 0.0;
+            if constexpr (GL == 1) LS[(P - 1) * 66] = 0.0;
             GS[65] = 0.0;
           }
           lds_sync();
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
       }
       // grad_v[r0 - 1 + t] and lapl_v[r0 + j] as the stencil wants them
       auto grad_at = [&](int t, int r0o) -> double {
-        if constexpr (GL) {
+        if constexpr (GL != 0) {
           const int lo = r0o / P;      // (opaque) lane
           double g = (t == 0) ? GS[(P - 2) * 66 + lo] : (t == 1) ? GS[(P - 1) * 66 + lo]
                      : (t == P + 2) ? GS[2 + lo] : GS[(t - 2) * 66 + 1 + lo];
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
         }
       };
       auto lapl_at = [&](int j, int lo) -> double {
-        if constexpr (GL) return (j == 0) ? LS[(P - 1) * 66 + lo] : LS[(j - 1) * 66 + 1 + lo];
+        if constexpr (GL == 1) return (j == 0) ? LS[(P - 1) * 66 + lo] : LS[(j - 1) * 66 + 1 + lo];
         else return lw[j];
       };
 
@@ -227,6 +237,9 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
         // scalar registers that spill through v_writelane / v_readlane.
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
+        // a wave that is about to request memory issues first on its SIMD: the stencil assembly and the window requests behind
+        // it run at raised priority, the long tridiagonal solve at the default one
+        __builtin_amdgcn_s_setprio(ST_PRIO_ASM);
         const int r0 = lane_o * P;
         double (&cc)[P + 2] = cw;                            // patched in place: the prefetch below overwrites it anyway
         const double c0old = read_lane(cc[0], 0);
@@ -304,8 +317,12 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+#ifndef ST_NOCOMPUTE   // (diagnosis build: the memory-side ceiling of this access pattern, tools/probe: results are wrong)
         if (cn) tridiag_wave<P, 1>(ta, tc, x, strip, XS, lane_o);            // np.linalg.solve(A,B), :556
+#endif
         // ---- results: charge contribution, status, then the row leaves through LDS as coalesced stores ----------------
+        __builtin_amdgcn_s_setprio(ST_PRIO_STORE);
 #pragma unroll
         for (int j = 0; j < P; ++j) {
           const double xv = (r0 + j < m) ? x[0][j] : 0.0;
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int P, bool CN, bool GL>
+template <int P, bool CN, int GL>
 static hipError_t launch_st_inst(const DevArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)st_lds_doubles<P, GL>() * sizeof(double);
   static int blocks_per_cu = 0;
@@ -405,19 +422,20 @@ static hipError_t launch_st_inst(const DevArgs& a, hipStream_t stream) {
 }
 
 template <int P>
-static hipError_t launch_st_p(const DevArgs& a, bool gl, hipStream_t stream) {
+static hipError_t launch_st_p(const DevArgs& a, int gl, hipStream_t stream) {
   const bool cn = a.method == PNP_METHOD_CRANK_NICOLSON;
-  if (gl) return cn ? launch_st_inst<P, true, true>(a, stream) : launch_st_inst<P, false, true>(a, stream);
-  return cn ? launch_st_inst<P, true, false>(a, stream) : launch_st_inst<P, false, false>(a, stream);
+  if (gl == 1) return cn ? launch_st_inst<P, true, 1>(a, stream) : launch_st_inst<P, false, 1>(a, stream);
+  if (gl == 2) return cn ? launch_st_inst<P, true, 2>(a, stream) : launch_st_inst<P, false, 2>(a, stream);
+  return cn ? launch_st_inst<P, true, 0>(a, stream) : launch_st_inst<P, false, 0>(a, stream);
 }
 
-// mode: 0 registers only, 1 charge / gradient rows in LDS
+// mode: 0 registers only, 1 charge + gradient rows of the step in LDS, 2 gradient row in LDS
 hipError_t launch_step_st(const DevArgs& a, int mode, hipStream_t stream) {
   switch (points_per_lane(a.nx)) {
-    case 2: return launch_st_p<2>(a, mode == 1, stream);
-    case 4: return launch_st_p<4>(a, mode == 1, stream);
-    case 8: return launch_st_p<8>(a, mode == 1, stream);
-    case 16: return launch_st_p<16>(a, mode == 1, stream);
+    case 2: return launch_st_p<2>(a, mode, stream);
+    case 4: return launch_st_p<4>(a, mode, stream);
+    case 8: return launch_st_p<8>(a, mode, stream);
+    case 16: return launch_st_p<16>(a, mode, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -25,7 +25,7 @@ def run(p, method, c0, pb, vz, fl, nsteps, spl):
         return s.get_state() + (s.get_status(),)
 
 
-@pytest.mark.parametrize('mode', ['5', '6'])
+@pytest.mark.parametrize('mode', ['5', '6', '7'])
 @pytest.mark.parametrize('N,nx,B', [(3, 512, 700), (2, 200, 513), (6, 1024, 300), (3, 130, 257), (1, 66, 300), (4, 1026, 260), (6, 515, 259)])
 @pytest.mark.parametrize('method', ['Crank-Nicolson', 'FTCS'])
 def test_streaming_kernel_matches_oracle_and_previous_kernels(mode, N, nx, B, method, monkeypatch):
@@ -37,7 +37,9 @@ def test_streaming_kernel_matches_oracle_and_previous_kernels(mode, N, nx, B, me
     fl = rng.uniform(-1e-4, 1e-4, fl.shape)
     nsteps = 4
     monkeypatch.setenv('CATINT_PNP_KERNEL', '4')
+    monkeypatch.setenv('CATINT_PNP_WAVES_PER_GRID', '1')                 # (several waves per lane add the charge row in another order)
     ref = run(p, method, c0, pb, vz, fl, nsteps, 1)                      # the register-resident kernel, one launch per step
+    monkeypatch.delenv('CATINT_PNP_WAVES_PER_GRID')
     monkeypatch.setenv('CATINT_PNP_KERNEL', mode)
     monkeypatch.setenv('CATINT_PNP_ST_WAVES_PER_CU', '1')
     got1 = run(p, method, c0, pb, vz, fl, nsteps, 1)                     # streaming kernel, one launch per step

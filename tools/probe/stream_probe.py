@@ -25,6 +25,7 @@ VARIANTS = {
     'rrW3': dict(CATINT_PNP_KERNEL='4', CATINT_PNP_WAVES_PER_GRID='3'),
     'st': dict(CATINT_PNP_KERNEL='5'),
     'stg': dict(CATINT_PNP_KERNEL='6'),
+    'stg2': dict(CATINT_PNP_KERNEL='7'),
 }
 KEYS = ['CATINT_PNP_KERNEL', 'CATINT_PNP_WAVES_PER_GRID', 'CATINT_PNP_SPECIES_PER_WAVE']      # (CATINT_PNP_ST_WAVES_PER_CU passes through)
 
