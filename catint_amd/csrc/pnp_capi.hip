@@ -448,7 +448,7 @@ static int run_steps(pnp_handle* h, int nsteps) {
   if (kind == 2) {
     // 16 points per lane: the gradient row of the step in LDS (two waves per SIMD instead of one: 0.53 -> 0.60 of the roofline per
     // step and 0.68 -> 0.72 fused on one GPU's share of configs[3]); shorter grids: registers only
-    const int st_mode = h->kernel_override == 6 ? 1 : (h->kernel_override == 7 ? 2 : (h->kernel_override == 5 ? 0 : (h->P == 16 ? 2 : 0)));
+    const int st_mode = h->kernel_override == 6 ? 1 : (h->kernel_override == 7 ? 2 : (h->kernel_override == 5 ? 0 : ((h->P == 16 && a.B >= 2048) ? 2 : 0)));
     HIP_TRY(h, launch_step_st(a, st_mode, h->stream));
   } else if (kind == 1) {
     int w = W;

@@ -22,9 +22,9 @@ VARIANTS.update({
     'W2G2': dict(CATINT_PNP_KERNEL='2', CATINT_PNP_WAVES_PER_GRID='2', CATINT_PNP_SPECIES_PER_WAVE='2'),
     'W4G1': dict(CATINT_PNP_KERNEL='2', CATINT_PNP_WAVES_PER_GRID='4', CATINT_PNP_SPECIES_PER_WAVE='1'),
 })
-NAMES = ['W1G1', 'W1G2', 'W1G3', 'W2G1', 'W2G2', 'W3G1', 'W4G1', 'rrW1', 'rrW2', 'rrW3', 'st']
+NAMES = ['W1G1', 'W1G2', 'W1G3', 'W2G1', 'W2G2', 'W3G1', 'W4G1', 'rrW1', 'rrW2', 'rrW3', 'st', 'stg2']
 SPECIES = [2, 3, 4, 6, 8]
-GRIDS = [66, 130, 258, 512, 1024]            # P = 1, 2, 4, 8, 16
+GRIDS = [int(x) for x in os.environ.get('SWEEP_GRIDS', '66,130,258,512,1024').split(',')]            # P = 1, 2, 4, 8, 16
 BATCHES = [1024, 4096, 16384]
 
 
@@ -58,6 +58,8 @@ def main():
                 for spl in (1, 64):
                     for name in ['default'] + NAMES:
                         if name.startswith(('rr', 'st')) and nx <= 66:
+                            continue
+                        if name == 'stg2' and nx != 1024:        # the gradient row in LDS pays at 16 points per lane only
                             continue
                         for k in KEYS:
                             os.environ.pop(k, None)
