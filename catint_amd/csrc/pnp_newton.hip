@@ -551,10 +551,13 @@ __device__ __forceinline__ double wave_max(double v) {
 
 // One workgroup per operating point (grid-stride over the batch).  blockDim.x = T threads, thread t owns block rows
 // t, t+T, ...  Dynamic LDS: the row buffer when A.work == nullptr.
-// Launch bounds: every kernel of this file is compiled for at most 256 registers per thread (bound 512).  With the
-// 512-register budget (bound 256) the N >= 6 instances spilled into the accumulator half of the register file and
-// then produced run-to-run different, sometimes wrong, solutions on MI355X (tools/probe/repro_newton.py); with 256
-// they are bitwise reproducible.  The larger blocks pay with scratch traffic instead.
+// Launch bounds: the kernels of this file are compiled for at most 256 registers per thread (bound 512): two waves per SIMD.
+// History: an early version of this kernel (ping-pong PCR through LDS / device memory) gave run-to-run different results when
+// built for 512 registers; the present one (in-place cyclic reduction) does not -- its 512-register builds (256 VGPRs + 74...166
+// accumulator registers as spill space, no scratch) are bitwise reproducible, equal to the 256-register builds bit for bit and
+// unchanged under -ftrivial-auto-var-init=zero / =pattern (no uninitialised local reaches a result; tools/probe/trap_repro.py,
+// gpurun_out/trap_repro.txt).  The register budget is an occupancy choice, not a correctness requirement; both builds of
+// NB = 6, 7 are kept and compared by tests/test_gpu_newton.py::test_register_budget_does_not_change_results.
 template <int NB, int TMAX, int MODE>
 __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
   constexpr int N = NB - 1;
@@ -2041,13 +2044,17 @@ static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t 
 }
 
 hipError_t launch_newton(const NewtonArgs& a, int blocks, hipStream_t stream) {
+  const char* rg = getenv("CATINT_NEWTON_REGS");
+  const bool regs512 = rg && atoi(rg) == 512;
   switch (a.N + 1) {
     case 2: return launch_newton_nb<2, 512>(a, blocks, stream);
     case 3: return launch_newton_nb<3, 512>(a, blocks, stream);
     case 4: return launch_newton_nb<4, 512>(a, blocks, stream);
     case 5: return launch_newton_nb<5, 512>(a, blocks, stream);
-    case 6: return launch_newton_nb<6, 512>(a, blocks, stream);
-    case 7: return launch_newton_nb<7, 512>(a, blocks, stream);
+    // (the row-per-thread kernel of these two block sizes also exists in a 512-register build -- launch bound 256, accumulator
+    // registers as spill space -- selected by CATINT_NEWTON_REGS=512: tests/test_gpu_newton.py checks that it walks the same bits)
+    case 6: return regs512 ? launch_newton_nb<6, 256>(a, blocks, stream) : launch_newton_nb<6, 512>(a, blocks, stream);
+    case 7: return regs512 ? launch_newton_nb<7, 256>(a, blocks, stream) : launch_newton_nb<7, 512>(a, blocks, stream);
     case 8: return launch_newton_nb<8, 512>(a, blocks, stream);
     case 9: return launch_newton_nb<9, 512>(a, blocks, stream);
     default: return hipErrorInvalidValue;
