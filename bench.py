@@ -449,8 +449,9 @@ def main():
     solver.set_batch(c0, pb, vz, fl)
     solver.step(args.steps, args.steps_per_launch)
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.3:
-        solver.step(512, args.steps_per_launch)
+    while time.perf_counter() - t_spin < 0.3:       # (launches of the timed length only: the rocprofv3 --stats average of the
+        for _ in range(8):                            # headline kernel then IS the per-launch time of this shape)
+            solver.step(args.steps, args.steps_per_launch)
         solver.synchronize()
     # ---- what a caller sees right after an upload: pnp_set_batch, then immediately the K-step launch (reported next to the sustained
     # rate; the first launches after an upload run slower, cause not identified -- DESIGN.md section 6).  The reference's
@@ -458,10 +459,10 @@ def main():
     # too), hence the fresh upload before the timed region as well.
     solver.set_batch(c0, pb, vz, fl)
     cold_wall, cold_ev = timed(args.steps, args.steps_per_launch)
-    # ---- sustained rate: upload, four 8-step launches, the W warm-up steps, then the K timed steps ------------------------------------
+    # ---- sustained rate: upload, four K-step launches (past the slow ones), the W warm-up steps, then the K timed steps -------------
     solver.set_batch(c0, pb, vz, fl)
     for _ in range(4):
-        solver.step(8, 8)
+        solver.step(args.steps, args.steps_per_launch)
     solver.step(args.warmup, args.steps_per_launch)
     wall, ev_ms = timed(args.steps, args.steps_per_launch)
     status = solver.get_status()
