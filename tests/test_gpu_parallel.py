@@ -1,0 +1,87 @@
+"""GPU: the N > 1 path with REAL solves -- two ranks (one process each, as bench.py --gpus N launches them) share the one GPU of the
+test box, each advances its contiguous block of lanes with the HIP path and the surface observables are gathered with
+torch.distributed (gloo, and RCCL = backend 'nccl' where two ranks may share a device); every rank must hold the table a single
+rank computes for the whole batch.  (tests/test_parallel_gloo.py covers the gather alone on the CPU.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+from catint_amd.synthetic import make_batch
+from catint_amd.host import solver_from_problem
+from catint_amd.parallel import shard_bounds, gather_observables
+backend = sys.argv[2]
+torch.cuda.set_device(0)
+if backend == 'nccl':
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+else:
+    dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+B, N, nx, steps = int(sys.argv[1]), 3, 130, 12
+p, c0, pb, vz, fl = make_batch(B, N, nx, seed=5, phi_max=0.02, dt_factor=1e-4)
+lo, hi = shard_bounds(B, world, rank)
+with solver_from_problem(p, 'Crank-Nicolson', batch_capacity=hi - lo) as s:
+    s.set_batch(c0[lo:hi], pb[lo:hi], vz[lo:hi], fl[lo:hi])
+    s.step(steps)
+    cs, vs, es = s.get_surface()
+    assert (s.get_status() == 0).all()
+local = np.concatenate([cs, vs[:, None], es[:, None]], axis=1)
+dev = torch.device('cuda', 0) if backend == 'nccl' else torch.device('cpu')
+full = gather_observables(local, B, dist, device=dev)
+with solver_from_problem(p, 'Crank-Nicolson', batch_capacity=B) as s:       # the whole batch on one handle
+    s.set_batch(c0, pb, vz, fl)
+    s.step(steps)
+    cs, vs, es = s.get_surface()
+ref = np.concatenate([cs, vs[:, None], es[:, None]], axis=1)
+assert full.shape == (B, N + 2) and np.array_equal(full, ref), np.abs(full - ref).max()
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok', lo, hi)
+''' % ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(B, backend, world=2):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, '-c', WORKER, str(B), backend], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    return procs, outs
+
+
+@pytest.mark.parametrize('B', [48, 37])
+def test_two_ranks_solve_their_shards_and_gather_gloo(B):
+    procs, outs = run_world(B, 'gloo')
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and 'ok' in o, e[-2000:]
+
+
+def test_two_ranks_solve_their_shards_and_gather_rccl():
+    procs, outs = run_world(48, 'nccl')
+    if any(p.returncode != 0 for p in procs) and any('Duplicate GPU' in e or 'invalid usage' in e or 'unhandled' in e for _, e in outs):
+        pytest.skip('this RCCL build refuses two ranks on one device')
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and 'ok' in o, e[-2000:]
