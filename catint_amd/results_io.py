@@ -65,3 +65,44 @@ def read_all(tp, folder, only=None):
     tp.nt = len(tp.tmesh)
     tp.dt = tp.tmesh[1] - tp.tmesh[0]
     return tp
+
+
+# -- COMSOL text tables (optional export) ---------------------------------------------------------------------
+# The reference's reader (catint/comsol_reader.py:125-326) parses the plain-text tables COMSOL's data export writes: comment lines
+# starting with '%' up to '% Description', then ONE header line naming the columns `<variable> (<unit>) @ <parameter>=<value>`, then
+# rows `x value value ...`; '% Nodes: 2' marks a table evaluated on the two boundary points (only the row at x = 0 is read).  The
+# reference asks for three tables (comsol_model.py:120-125): concentrations.txt (cp1..cpN), electrostatics.txt (phi, es.Ex),
+# electrode_flux.txt (j1..jN on the boundary).  export_comsol_text writes them for one descriptor point, so the reference's own
+# Reader -- and every tool behind it -- can take a GPU solve where a COMSOL run used to be.
+def _comsol_table(path, x, columns, names, units, par_name, par_value, nodes, description):
+    with open(path, 'w') as f:
+        f.write('%% Model:              %s\n' % 'pnp_transport.mph')
+        f.write('% Version:            catint_amd (COMSOL data export layout)\n')
+        f.write('% Dimension:          1\n')
+        f.write('%% Nodes:              %d\n' % nodes)
+        f.write('%% Expressions:        %d\n' % len(names))
+        f.write('%% Description:        %s\n' % description)
+        head = '% x' + ' ' * 22
+        for n, u in zip(names, units):
+            head += ' %s (%s) @ %s=%s    ' % (n, u, par_name, repr(float(par_value)))
+        f.write(head.rstrip() + '\n')
+        for i in range(len(x)):
+            f.write(' '.join([repr(float(x[i]))] + [repr(float(col[i])) for col in columns]) + '\n')
+
+
+def export_comsol_text(tp, index, folder, par_name='flux_factor', par_value=1.0):
+    """Write concentrations.txt, electrostatics.txt and electrode_flux.txt of descriptor point `index` (tp.alldata[index], filled by
+    Calculator.run / fill_alldata) in the layout the reference's comsol_reader.Reader parses."""
+    os.makedirs(folder, exist_ok=True)
+    d = tp.alldata[index]
+    names = list(tp.species.keys())
+    x = np.asarray(tp.xmesh, float)
+    _comsol_table(os.path.join(folder, 'concentrations.txt'), x, [np.asarray(d['species'][sp]['concentration'], float) for sp in names],
+                  ['cp%d' % (k + 1) for k in range(len(names))], ['mol/m^3'] * len(names), par_name, par_value, len(x), 'Concentrations')
+    _comsol_table(os.path.join(folder, 'electrostatics.txt'), x,
+                  [np.asarray(d['system']['potential'], float), np.asarray(d['system']['efield'], float)], ['phi', 'es.Ex'], ['V', 'V/m'],
+                  par_name, par_value, len(x), 'Potential, Field')
+    flux = [float(d['species'][sp].get('electrode_flux', 0.0)) for sp in names]
+    _comsol_table(os.path.join(folder, 'electrode_flux.txt'), [0.0, float(x[-1])], [[f, 0.0] for f in flux],
+                  ['j%d' % (k + 1) for k in range(len(names))], ['mol/m^2/s'] * len(names), par_name, par_value, 2, 'Electrode flux')
+    return folder
