@@ -33,7 +33,7 @@ SYMBOLS = [
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
-    'pnp_set_potential', 'pnp_set_wall_kinetics', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
+    'pnp_set_potential', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
 ]
 
 
@@ -125,6 +125,8 @@ def load_library():
     lib.pnp_set_potential.argtypes = [vp, dp]
     lib.pnp_set_wall_kinetics.argtypes = [vp, C.c_int32, ip, dp, dp]
     lib.pnp_set_wall_kinetics.restype = C.c_int
+    lib.pnp_set_wall_rate_law.argtypes = [vp, C.c_int32, dp, dp]
+    lib.pnp_set_wall_rate_law.restype = C.c_int
     lib.pnp_set_grid.argtypes = [vp, dp]
     lib.pnp_set_grid.restype = C.c_int
     lib.pnp_solve_surface.argtypes = [vp, dp, C.c_int32, dp, dp, dp, ip]
@@ -252,9 +254,11 @@ class PnpSolver(object):
         """Non-uniform grid x[nx] of the physical mode (electrode at x[0]); dx of the constructor stays the scaling length."""
         self._check(self._lib.pnp_set_grid(self._h, _dptr(_f64(x, (self.nx,)))))
 
-    def set_wall_kinetics(self, species, nu, k):
-        """First-order surface reactions coupled implicitly: species [n] (index, -1 = zeroth order), nu [n][N] stoichiometry
-        of the flux into the domain, k [B][n] rate constants per lane.  Empty lists remove the table."""
+    def set_wall_kinetics(self, species, nu, k, alpha=None, saturation=None):
+        """Surface reactions coupled implicitly: species [n] (index, -1 = zeroth order), nu [n][N] stoichiometry of the flux
+        into the domain, k [B][n] rate constants per lane.  Empty lists remove the table.  alpha [n] (1/V) / saturation [n]
+        (m^3/mol): Butler-Volmer factor exp(alpha (phiM - phi(x=0))) and Langmuir saturation c/(1 + K c) (pnp_set_wall_rate_law);
+        None: first order."""
         n = len(species)
         if n == 0:
             self._check(self._lib.pnp_set_wall_kinetics(self._h, 0, None, None, None))
@@ -262,6 +266,10 @@ class PnpSolver(object):
         sp = np.ascontiguousarray(species, dtype=np.int32)
         self._check(self._lib.pnp_set_wall_kinetics(self._h, n, _iptr(sp), _dptr(_f64(nu, (n, self.N))),
                                                     _dptr(_f64(k, (self.B, n)))))
+        if alpha is not None or saturation is not None:
+            al = _f64(np.zeros(n) if alpha is None else alpha, (n,))
+            ks = _f64(np.zeros(n) if saturation is None else saturation, (n,))
+            self._check(self._lib.pnp_set_wall_rate_law(self._h, n, _dptr(al), _dptr(ks)))
 
     def solve_stationary(self, tol=0.0, maxit=0):
         st = np.zeros(self.B, np.int32)

@@ -221,12 +221,20 @@ class Calculator(object):
         return s
 
     def set_surface_kinetics(self, reactions):
-        """First-order electrode kinetics solved WITH the transport instead of around it (physical mode only):
+        """Electrode kinetics solved WITH the transport instead of around it (physical mode only):
         reactions = [{'species': name (or None: zeroth order), 'rate': K(phiM[B]) -> [B] in m/s (mol m^-2 s^-1 if zeroth order),
-        'stoichiometry': {species name: nu}}], flux into the electrolyte nu*K*c_species(x=0) (educts negative,
-        calculator.py:415-432).  One stationary solve then returns what run_scf_cycle iterates towards."""
+        'stoichiometry': {species name: nu}, 'alpha': a (1/V, optional), 'saturation': K_sat (m^3/mol, optional)}], flux into the
+        electrolyte nu*K*g(c_species(x=0))*exp(a*(phiM - phi(x=0))), g(c) = c/(1 + K_sat c) (educts negative,
+        calculator.py:415-432).  alpha / saturation give the Butler-Volmer and Langmuir forms of the reference's user-defined flux
+        equations (docs/source/topics/flux_definition.rst:90-160); without them the reaction is first order.  One stationary
+        solve then returns what run_scf_cycle iterates towards."""
         if not self.physical:
             raise CalculatorError('surface kinetics are part of the physical mode (calc="comsol")')
+        for r in reactions:
+            if float(r.get('saturation', 0.0)) < 0.0:
+                raise CalculatorError('surface kinetics: saturation must be >= 0')
+            if float(r.get('saturation', 0.0)) != 0.0 and r.get('species') is None:
+                raise CalculatorError('surface kinetics: saturation needs a species')
         self.surface_kinetics = list(reactions)
 
     def _apply_surface_kinetics(self, solver, phiM):
@@ -241,11 +249,14 @@ class Calculator(object):
                 nu[i, names.index(sp)] = v
         k = np.stack([np.broadcast_to(np.asarray(r['rate'](phiM) if callable(r['rate']) else r['rate'], float), phiM.shape)
                       for r in rx], axis=1)
-        solver.set_wall_kinetics(species, nu, k)
+        alpha = [float(r.get('alpha', 0.0)) for r in rx]
+        sat = [float(r.get('saturation', 0.0)) for r in rx]
+        law = any(alpha) or any(sat)
+        solver.set_wall_kinetics(species, nu, k, alpha if law else None, sat if law else None)
 
-    def surface_kinetic_fluxes(self, csurf, phiM, clip=False, reactions=None):
-        """Flux [B][N] into the electrolyte implied by set_surface_kinetics at the surface state csurf [B][N]
-        (clip: negative surface concentrations count as zero, as in the explicit SCF loop)."""
+    def surface_kinetic_fluxes(self, csurf, phiM, clip=False, reactions=None, vsurf=None):
+        """Flux [B][N] into the electrolyte implied by set_surface_kinetics at the surface state csurf [B][N], vsurf [B] = phi(x=0)
+        (needed when a reaction has an 'alpha'; clip: negative surface concentrations count as zero, as in the explicit SCF loop)."""
         names = list(self.tp.species.keys())
         out = np.zeros_like(csurf)
         for r in (reactions if reactions is not None else getattr(self, 'surface_kinetics', None)) or []:
@@ -253,8 +264,15 @@ class Calculator(object):
             cs = csurf[:, names.index(r['species'])] if r.get('species') is not None else 1.0
             if clip and r.get('species') is not None:
                 cs = np.maximum(cs, 0.0)
+            g = cs
+            if float(r.get('saturation', 0.0)) != 0.0:
+                g = g * (1.0 / (1.0 + float(r['saturation']) * cs))
+            if float(r.get('alpha', 0.0)) != 0.0:
+                if vsurf is None:
+                    raise CalculatorError('surface_kinetic_fluxes: a reaction with alpha needs the surface potential')
+                g = g * np.exp(float(r['alpha']) * (phiM - np.asarray(vsurf, float)))
             for sp, v in r['stoichiometry'].items():
-                out[:, names.index(sp)] += v * K * cs
+                out[:, names.index(sp)] += v * K * g
         return out
 
     def solve_physical(self, solver, c0, phiM, flux, nramp=8, warm=False):
@@ -366,7 +384,7 @@ class Calculator(object):
                 cfin, v, g, l = s.get_state()
                 self.newton_iterations = s.newton_iterations()
                 if getattr(self, 'surface_kinetics', None):
-                    self.kinetic_flux = self.surface_kinetic_fluxes(cfin[:, :, 0], phiM)
+                    self.kinetic_flux = self.surface_kinetic_fluxes(cfin[:, :, 0], phiM, vsurf=v[:, 0])
             cout = cfin.reshape(1, B, tp.nspecies * tp.nx)
         else:
             cout, status, (v, g, l) = self.integrate_pnp_batch(c0, pb, vz, flux)
@@ -498,7 +516,7 @@ class Calculator(object):
             if not (self.physical and self.mode == 'stationary' and kinetics and transport_fn is None):
                 raise CalculatorError('run_scf_cycle without a callback needs the physical mode (stationary) and set_surface_kinetics')
             flux_callback = lambda state: self.surface_kinetic_fluxes(state['surface_concentration'], state['phiM'], clip=True,  # noqa: E731
-                                                                      reactions=kinetics)
+                                                                      reactions=kinetics, vsurf=state['surface_potential'])
         names = list(tp.species.keys())
         N = tp.nspecies
         pb, vz, phiM = self._lane_inputs()

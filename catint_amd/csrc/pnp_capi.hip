@@ -48,6 +48,7 @@ struct pnp_handle {
   int32_t wk_species[PNP_MAX_WALL_REACTIONS] = {0};
   double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES] = {{0}};
   double* wk_k = nullptr;
+  double wk_alpha[PNP_MAX_WALL_REACTIONS] = {0}, wk_sat[PNP_MAX_WALL_REACTIONS] = {0};     // pnp_set_wall_rate_law
   double *gw = nullptr, *gv = nullptr;
   std::vector<double> xgrid;
   int64_t stash_stride = 0;
@@ -533,6 +534,8 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   }
   memcpy(a.wk_species, h->wk_species, sizeof(a.wk_species));
   memcpy(a.wk_nu, h->wk_nu, sizeof(a.wk_nu));
+  memcpy(a.wk_alpha, h->wk_alpha, sizeof(a.wk_alpha));
+  memcpy(a.wk_sat, h->wk_sat, sizeof(a.wk_sat));
   a.wk_k = h->wk_k;
   a.gw = h->gw;
   a.gv = h->gv;
@@ -608,6 +611,7 @@ int pnp_set_wall_kinetics(pnp_handle* h, int32_t n, const int32_t* species, cons
   for (int r = 0; r < n; ++r) {
     if (species[r] < -1 || species[r] >= N) return fail(h, PNP_EINVAL, "pnp_set_wall_kinetics: species index out of range");
     h->wk_species[r] = species[r];
+    h->wk_alpha[r] = h->wk_sat[r] = 0.0;      // a new table is first order until pnp_set_wall_rate_law says otherwise
     for (int kk = 0; kk < PNP_NEWTON_MAX_SPECIES; ++kk) h->wk_nu[r][kk] = kk < N ? nu[r * N + kk] : 0.0;
   }
   std::vector<double> kp((size_t)h->B * PNP_MAX_WALL_REACTIONS, 0.0);
@@ -617,6 +621,22 @@ int pnp_set_wall_kinetics(pnp_handle* h, int32_t n, const int32_t* species, cons
   HIP_TRY(h, hipMemcpyAsync(h->wk_k, kp.data(), kp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->n_wk = n;
+  return PNP_OK;
+}
+
+int pnp_set_wall_rate_law(pnp_handle* h, int32_t n, const double* alpha, const double* saturation) {
+  if (!h) return PNP_EINVAL;
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_set_wall_rate_law: the handle was not created with PNP_METHOD_NEWTON");
+  if (n != h->n_wk) return fail(h, PNP_ESTATE, "pnp_set_wall_rate_law: n differs from the table of pnp_set_wall_kinetics (call that first)");
+  for (int r = 0; r < n; ++r) {
+    const double al = alpha ? alpha[r] : 0.0, ks = saturation ? saturation[r] : 0.0;
+    if (!(al == al) || !(ks >= 0.0)) return fail(h, PNP_EINVAL, "pnp_set_wall_rate_law: alpha must be a number, saturation >= 0");
+    if (ks != 0.0 && h->wk_species[r] < 0) return fail(h, PNP_EINVAL, "pnp_set_wall_rate_law: saturation on a zeroth-order reaction");
+  }
+  for (int r = 0; r < n; ++r) {
+    h->wk_alpha[r] = alpha ? alpha[r] : 0.0;
+    h->wk_sat[r] = saturation ? saturation[r] : 0.0;
+  }
   return PNP_OK;
 }
 
@@ -696,6 +716,9 @@ int pnp_scf_cycle(pnp_handle* h, const pnp_scf_params* p, const double* nel, con
   a.faraday = p->faraday;
   memcpy(a.wk_species, h->wk_species, sizeof(a.wk_species));
   memcpy(a.wk_nu, h->wk_nu, sizeof(a.wk_nu));
+  memcpy(a.wk_alpha, h->wk_alpha, sizeof(a.wk_alpha));
+  memcpy(a.wk_sat, h->wk_sat, sizeof(a.wk_sat));
+  a.pb = h->pb;
   for (int k = 0; k < N; ++k) {
     a.nel[k] = nel ? nel[k] : 1.0;
     a.nprod[k] = nprod ? nprod[k] : 1.0;

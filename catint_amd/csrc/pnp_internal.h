@@ -128,6 +128,8 @@ struct NewtonArgs {
   int32_t wk_species[PNP_MAX_WALL_REACTIONS];                     // species whose surface concentration enters, -1: zeroth order
   double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES];   // stoichiometry of the flux INTO the domain
   const double* wk_k;                    // [B][PNP_MAX_WALL_REACTIONS] rate constants per lane
+  double wk_alpha[PNP_MAX_WALL_REACTIONS];   // Butler-Volmer exponent [1/V]: rate *= exp(alpha (phiM - phi(x=0)))  (pnp_set_wall_rate_law)
+  double wk_sat[PNP_MAX_WALL_REACTIONS];     // Langmuir saturation [m^3/mol]: c_s -> c_s/(1 + K_sat c_s)
   const double* gw;                      // [nx] grid: dx/h_e of edge e (points e, e+1); 1 on the uniform grid
   const double* gv;                      // [nx] grid: control volume V_i/dx; 1 inside a uniform grid, 1/2 at the ends
   double* c;                             // [B][N][ldx] state = Newton iterate, in place
@@ -166,6 +168,8 @@ struct ScfArgs {
   double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES];
   double nel[PNP_NEWTON_MAX_SPECIES], nprod[PNP_NEWTON_MAX_SPECIES];
   const double* wk_k;                    // [B][PNP_MAX_WALL_REACTIONS]
+  double wk_alpha[PNP_MAX_WALL_REACTIONS], wk_sat[PNP_MAX_WALL_REACTIONS];     // rate law (pnp_set_wall_rate_law), see NewtonArgs
+  const double* pb;                      // [B][4]: wall potential phiM first
   double *sc, *sc_old, *flux, *cd_old;   // [B][N]
   double *mix, *acc, *surface_pH, *vsurf, *esurf;      // [B]
   int32_t *step_to_check, *active, *failed;            // [B]

@@ -484,12 +484,19 @@ __device__ __forceinline__ void fill_row(const NewtonArgs& A, const double* c, c
       const int sp = A.wk_species[r];
       const double kr = wk[r];
       const double cs = sp >= 0 ? c[sp * ldx] : 1.0;
+      // rate law K g(c_s) E: Langmuir g = c_s/(1 + K_sat c_s), Butler-Volmer E = exp(alpha (phiM - phi(0))) in the Stern-layer
+      // drop (docs/source/topics/flux_definition.rst:90-160 of the reference: exp(-(Ga + alpha F (phiM - phi - phiEq))/RT));
+      // alpha = K_sat = 0 is the first-order table: g = c_s, dg = 1, same bits as before
+      const double al = A.wk_alpha[r], den = 1.0 / (1.0 + A.wk_sat[r] * cs);
+      const double E = al != 0.0 ? exp(al * (phiM - P0.phi)) : 1.0;
+      const double g = cs * den * E, dg = den * den * E;
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         const double a = A.wk_nu[r][k] * kr * A.fl[k];
-        X[k][2 * NB] += a * cs;
+        X[k][2 * NB] += a * g;
 #pragma unroll
-        for (int j = 0; j < N; ++j) M[k][j] -= (j == sp) ? a : 0.0;
+        for (int j = 0; j < N; ++j) M[k][j] -= (j == sp) ? a * dg : 0.0;
+        if (al != 0.0) M[k][N] += a * al * g;
       }
     }
   }
@@ -1307,7 +1314,7 @@ __device__ __forceinline__ void team_assemble_row(const NewtonArgs& A, const New
           }
         }
       }
-      if (wall && A.n_wk > 0) {   // implicit first-order surface kinetics, see fill_row
+      if (wall && A.n_wk > 0) {   // implicit surface kinetics, see fill_row
         for (int q = 0; q < A.n_wk; ++q) {
           const int sp = A.wk_species[q];
           double nu = 0.0;
@@ -1315,9 +1322,13 @@ __device__ __forceinline__ void team_assemble_row(const NewtonArgs& A, const New
           for (int k = 0; k < N; ++k) nu = (k == r) ? A.wk_nu[q][k] : nu;
           const double a = nu * wk[q] * fl_r;
           const double cs = sp >= 0 ? c[sp * ldx] : 1.0;
-          rhs += a * cs;
+          const double al = A.wk_alpha[q], den = 1.0 / (1.0 + A.wk_sat[q] * cs);
+          const double E = al != 0.0 ? exp(al * (phiM - p0)) : 1.0;
+          const double g = cs * den * E, dg = den * den * E;
+          rhs += a * g;
 #pragma unroll
-          for (int j = 0; j < N; ++j) Dr[j] -= (j == sp) ? a : 0.0;
+          for (int j = 0; j < N; ++j) Dr[j] -= (j == sp) ? a * dg : 0.0;
+          if (al != 0.0) Dr[N] += a * al * g;
         }
       }
       Xr[2 * NB] = rhs;

@@ -5,8 +5,9 @@
 // (:328-344, negative values fall back to the previous iterate), update the surface pH (:346-359), ask the kinetic model for
 // fluxes (:373), solve the transport problem (:385), compare current densities with the previous iteration
 // (evaluate_accuracy :260-283, signed quotient) and decay the mixing factor every 40 iterations (:319-323).  Here the
-// kinetic model is analytic -- the first-order table of pnp_set_wall_kinetics, flux_k = sum_r nu_rk K_r[lane] c_s(r)(x=0),
-// a Tafel / Butler-Volmer law once K carries the potential dependence -- so the whole iteration stays on the device:
+// kinetic model is analytic -- the table of pnp_set_wall_kinetics, flux_k = sum_r nu_rk K_r[lane] g_r(c_s(r)(x=0)) E_r, a Tafel
+// law in the electrode potential once K carries it, Butler-Volmer in the Stern-layer drop and Langmuir saturation through
+// pnp_set_wall_rate_law (E_r = exp(alpha_r (phiM - phi(0))), g_r = c/(1 + K_sat c)) -- so the whole iteration stays on the device:
 // scf_pre_kernel (bookkeeping + fluxes), the Newton solve of the active lanes (pnp_newton.hip, lane mask), scf_keep_kernel
 // (a converged lane's state becomes its snapshot, a failed lane gets its snapshot back), scf_post_kernel (surface state,
 // accuracy, flags).  The host only reads one counter every few iterations to see whether lanes are left.
@@ -54,9 +55,16 @@ __global__ __launch_bounds__(256) void scf_pre_kernel(const ScfArgs A) {
     const double K = A.wk_k[b * PNP_MAX_WALL_REACTIONS + r];
     const int sp = A.wk_species[r];
     const double cs = sp >= 0 ? fmax(s[sp], 0.0) : 1.0;
+    // rate law of pnp_set_wall_rate_law, evaluated explicitly: Langmuir saturation in the mixed surface concentration,
+    // Butler-Volmer factor in the Stern-layer drop of the PREVIOUS transport solve (the state the reference hands CatMAP,
+    // catmap_wrapper.py: surface potential of the last COMSOL run).  alpha = K_sat = 0: g = cs exactly.
+    const double al = A.wk_alpha[r], ks = A.wk_sat[r];
+    double g = cs;
+    if (ks != 0.0) g = __dmul_rn(g, __ddiv_rn(1.0, __dadd_rn(1.0, __dmul_rn(ks, cs))));
+    if (al != 0.0) g = __dmul_rn(g, exp(__dmul_rn(al, __dsub_rn(A.pb[b * 4], A.vsurf[b]))));
     for (int k = 0; k < N; ++k) {
       const double nu = A.wk_nu[r][k];
-      if (nu != 0.0) f[k] = __dadd_rn(f[k], __dmul_rn(__dmul_rn(nu, K), cs));
+      if (nu != 0.0) f[k] = __dadd_rn(f[k], __dmul_rn(__dmul_rn(nu, K), g));
     }
   }
   for (int k = 0; k < N; ++k) A.flux[b * N + k] = f[k];

@@ -163,6 +163,17 @@ int pnp_set_grid(pnp_handle* h, const double* x);
  * a surface concentration -- obtained in ONE solve and without host round trips.  n = 0 removes the table.
  * species[n], nu[n][N], k[B][n]; call after pnp_set_batch (k is per lane). */
 int pnp_set_wall_kinetics(pnp_handle* h, int32_t n, const int32_t* species, const double* nu, const double* k);
+/* Rate law of the table above beyond first order -- the forms the reference's user-defined flux equations take
+ * (docs/source/topics/flux_definition.rst:90-160: rho*coverage*exp(-(Ga + alpha*F*(phiM - phi - phiEq))/RT), with a Langmuir
+ * coverage K c/(1 + K c); handed to COMSOL as text by comsol_model.py:392-456):
+ *   rate_r = k[b][r] * c_s/(1 + saturation[r] c_s) * exp(alpha[r] * (phiM[b] - phi(x=0)))
+ * alpha[r] [1/V] (a cathodic Butler-Volmer branch has alpha = -alpha_BV F/RT; the equilibrium potential and activation energy
+ * are constants inside k), saturation[r] [m^3/mol] >= 0.  phi(x=0) is the potential at the reaction plane, so with a Stern layer
+ * (wall_bc = PNP_WALL_STERN) the driving force is the Stern-layer drop and the kinetics feed back on the double layer; both the
+ * concentration and the potential derivative enter the Newton Jacobian.  In pnp_scf_cycle the factor is evaluated explicitly
+ * from the surface potential of the previous transport solve.  n must equal the n of pnp_set_wall_kinetics, which resets both
+ * arrays to zero (first order); either pointer may be NULL (= zeros). */
+int pnp_set_wall_rate_law(pnp_handle* h, int32_t n, const double* alpha, const double* saturation);
 /* Stationary solve of every lane from the current state as the initial guess (studies=['stat'], transport.py:811-812).
  * tol/maxit <= 0 keep the values of pnp_set_newton.  status[B] nullable. */
 int pnp_solve_stationary(pnp_handle* h, double tol, int32_t maxit, int32_t* status);

@@ -44,9 +44,11 @@ SERIES_U = 0.05                  # |u| below which B(u) and B'(u) use their Tayl
 
 class PhysicalProblem(object):
     """One operating point.  reactions: list of dicts {'lhs': [species idx...], 'rhs': [...], 'kf':, 'kr':}.
-    wall_kinetics: list of dicts {'species': s (or -1 for zeroth order), 'k': K, 'nu': [nu_k]}: first-order surface
-    reactions whose flux INTO the domain, nu_k K c_s(x=0), is part of the nonlinear system (what the SCF loop of
-    catint/calculator.py:294-406 converges to when the kinetics are rate = K(phiM) c_surface)."""
+    wall_kinetics: list of dicts {'species': s (or -1 for zeroth order), 'k': K, 'nu': [nu_k], 'alpha': a (optional, 1/V),
+    'saturation': K_sat (optional, m^3/mol)}: surface reactions whose flux INTO the domain,
+    nu_k K c_s/(1 + K_sat c_s) exp(a (phiM - phi(x=0))), is part of the nonlinear system (what the SCF loop of
+    catint/calculator.py:294-406 converges to when the kinetics are rate = K(phiM) c_surface; alpha / saturation: the
+    Butler-Volmer / Langmuir forms of the user-defined flux equations, docs/source/topics/flux_definition.rst:90-160)."""
 
     def __init__(self, D, charges, beta, eps, dx, nx, c_bulk, phiM, flux=None, phi_bulk=0.0, stern_capacitance=None,
                  phi_pzc=0.0, mpb_radius=None, reactions=None, wall_kinetics=None, x=None):
@@ -145,6 +147,16 @@ def reaction_rates(p, c):
     return R, dR
 
 
+def wall_rate_law(p, wk, c, phi):
+    """g, dg/dc_s, alpha of one surface reaction at the wall state: rate = K g, g = c_s/(1 + K_sat c_s) exp(alpha (phiM - phi_0))
+    (so d rate/d phi_0 = -alpha K g)."""
+    cs = c[wk['species'], 0] if wk['species'] >= 0 else 1.0
+    al, ks = float(wk.get('alpha', 0.0)), float(wk.get('saturation', 0.0))
+    den = 1.0 / (1.0 + ks * cs)
+    E = np.exp(al * (p.phiM - phi[0])) if al != 0.0 else 1.0
+    return cs * den * E, den * den * E, al
+
+
 def residual_and_jacobian(p, c, phi, c_old, dt, want_jacobian=True):
     """Scaled residual F[(N+1), nx] and the block-tridiagonal Jacobian (L, M, U)[nx, N+1, N+1]."""
     N, nx, dx = p.N, p.nx, p.dx
@@ -171,7 +183,7 @@ def residual_and_jacobian(p, c, phi, c_old, dt, want_jacobian=True):
         F[k, 1:-1] = sig * v[1:-1] * (c[k, 1:-1] - c_old[k, 1:-1]) + J[1:] - J[:-1] - rs * v[1:-1] * R[k, 1:-1]
         jw = p.flux[k]
         for wk in p.wall_kinetics:
-            jw = jw + wk['nu'][k] * wk['k'] * (c[wk['species'], 0] if wk['species'] >= 0 else 1.0)
+            jw = jw + wk['nu'][k] * wk['k'] * wall_rate_law(p, wk, c, phi)[0]
         F[k, 0] = sig * v[0] * (c[k, 0] - c_old[k, 0]) + J[0] - jw * dx / p.D[k] - rs * v[0] * R[k, 0]
         F[k, -1] = c[k, -1] - p.c_bulk[k]
         if not want_jacobian:
@@ -188,8 +200,10 @@ def residual_and_jacobian(p, c, phi, c_old, dt, want_jacobian=True):
         M[0, k, N] += -Ju[0] * qb
         U[0, k, N] += Ju[0] * qb
         for wk in p.wall_kinetics:
+            gw, dgw, al = wall_rate_law(p, wk, c, phi)
             if wk['species'] >= 0:
-                M[0, k, wk['species']] += -wk['nu'][k] * wk['k'] * dx / p.D[k]
+                M[0, k, wk['species']] += -wk['nu'][k] * wk['k'] * dgw * dx / p.D[k]
+            M[0, k, N] += wk['nu'][k] * wk['k'] * al * gw * dx / p.D[k]
         for j in range(N):                                    # steric coupling through u and reactions
             if p.mpb:
                 M[ii, k, j] += -Ju[ii] * g[j, ii] - Ju[ii - 1] * g[j, ii]

@@ -314,6 +314,47 @@ def test_device_scf_loop_walks_the_same_iterates_as_the_host_loop():
     assert np.allclose(dev['surface_concentration'][:, 2], 34.0 / (1.0 + kap), rtol=2e-4)
 
 
+def test_butler_volmer_kinetics_implicit_solve_and_both_scf_loops_agree():
+    """Rate law beyond first order (pnp_set_wall_rate_law): Butler-Volmer factor in the Stern-layer drop phiM - phi(0) and Langmuir
+    saturation, with a charged product so that the kinetics feed back on the double layer.  The implicit solve (Jacobian carries
+    d/dc_s and d/dphi_0), the device SCF loop (explicit, surface potential of the previous solve) and the host SCF loop with the
+    same law as a Python callback land on the same state."""
+    phis = list(np.linspace(-0.5, -1.0, 6))
+    kin = [{'species': 'CO2', 'rate': lambda phiM: 2e-5 * np.ones_like(phiM), 'alpha': -8.0, 'saturation': 0.02,
+            'stoichiometry': {'CO2': -1.0, 'CO': 1.0, 'HCO3-': 1.0}}]
+    tp = _physical_transport(phis, mpb=False)
+    calc = Calculator(transport=tp, calc='comsol')
+    calc.set_surface_kinetics(kin)
+    calc.run()
+    assert np.all(calc.status == 0)
+    cs = np.array([tp.alldata[i]['species']['CO2']['surface_concentration'] for i in range(len(phis))])
+    v0 = np.array([tp.alldata[i]['system']['surface_potential'] for i in range(len(phis))])
+    L = (tp.nx - 1) * tp.dx
+    j = -calc.kinetic_flux[:, 2]
+    E = np.exp(-8.0 * (np.array(phis) - v0))
+    assert np.allclose(j, 2e-5 * cs / (1.0 + 0.02 * cs) * E, rtol=1e-12)
+    assert np.allclose(cs, 34.0 - j * L / tp.D[2], rtol=1e-7)                    # neutral educt: linear profile carries the flux
+    assert E[-1] > 20 * E[0] and j[-1] > 5 * j[0] and cs[-1] < cs[0]       # the potential dependence is live
+    outs = []
+    for device in (False, True):
+        tp2 = _physical_transport(phis, mpb=False)
+        scf = Calculator(transport=tp2, calc='comsol', tau_scf=1e-7, mix_scf=0.05)
+        if device:
+            scf.set_surface_kinetics(kin)
+            outs.append(scf.run_scf_cycle(nel=[1, 1, 2, 2], max_iter=4000))
+        else:           # no table on this Calculator: its transport solves see prescribed fluxes only
+            cb = lambda st: scf.surface_kinetic_fluxes(st['surface_concentration'], st['phiM'], clip=True, reactions=kin,   # noqa: E731
+                                                       vsurf=st['surface_potential'])
+            outs.append(scf.run_scf_cycle(cb, nel=[1, 1, 2, 2], max_iter=4000))
+    host, dev = outs
+    assert host['converged'].all() and dev['converged'].all() and not dev['failed'].any()
+    assert dev['iterations'] == host['iterations'] and host['iterations'] > 50
+    assert np.allclose(dev['surface_concentration'], host['surface_concentration'], rtol=1e-9, atol=1e-12)
+    assert np.allclose(dev['flux'], host['flux'], rtol=1e-9, atol=1e-18)
+    assert np.allclose(dev['surface_concentration'][:, 2], cs, rtol=2e-4)
+    assert np.allclose(-dev['flux'][:, 2], j, rtol=2e-4)
+
+
 def test_device_scf_loop_freezes_converged_lanes_and_puts_failed_ones_back():
     """pnp_scf_cycle through the C-ABI with a hand-made loop state: lane 2 asks for a flux far beyond the diffusion limit (no
     solution in the positive cone) -> its solve fails, the lane reports -1 (the reference's negative-concentration answer),

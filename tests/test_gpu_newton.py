@@ -62,8 +62,11 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
         s.set_reactions([(r['lhs'], r['rhs'], r['kf'], r['kr']) for r in reactions])
     s.set_batch(c0, pb, np.zeros(B), fl)
     if wall_kinetics:
+        law = any('alpha' in w or 'saturation' in w for w in wall_kinetics)
         s.set_wall_kinetics([w['species'] for w in wall_kinetics], [w['nu'] for w in wall_kinetics],
-                            np.array([w['k'] for w in wall_kinetics]).T)
+                            np.array([w['k'] for w in wall_kinetics]).T,
+                            [w.get('alpha', 0.0) for w in wall_kinetics] if law else None,
+                            [w.get('saturation', 0.0) for w in wall_kinetics] if law else None)
     if stationary:
         st = s.solve_stationary()
     else:
@@ -227,6 +230,43 @@ def test_implicit_wall_kinetics():
     got, ref = run_both(N, 150, B=B, seed=17, wall_kinetics=wk,
                         newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=[4.1e-10, 0.0, 0.0, 0.0]))
     assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx,B,kernel", [(4, 150, 5, None), (3, 128, 4, None), (6, 96, 4, None), (8, 64, 3, None), (4, 150, 5, 'generic'),
+                                           (6, 96, 70, 'sweep')])
+def test_butler_volmer_and_langmuir_wall_kinetics(N, nx, B, kernel, monkeypatch):
+    """pnp_set_wall_rate_law: rate = K c/(1 + K_sat c) exp(alpha (phiM - phi(0))) inside the Newton system (both derivatives), Stern
+    wall so that phi(0) is an unknown -- against the oracle, in every kernel family (pair/row-per-thread N <= 4, lane teams N >= 5,
+    sweep)."""
+    if kernel:
+        monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    rng = np.random.default_rng(N * 100 + nx)
+    nu = lambda **kw: [kw.get(k, 0.0) for k in range(N)]      # noqa: E731
+    wk = [{'species': 2, 'k': rng.uniform(0.05, 1.0, B), 'nu': [0.0, 0.0, -1.0] + [1.0] * (N > 3) + [0.0] * max(N - 4, 0), 'alpha': -6.0,
+           'saturation': 0.05},
+          {'species': 0, 'k': rng.uniform(1e-4, 1e-3, B), 'nu': [-1.0, 0.0, 0.5] + [0.0] * (N - 3), 'alpha': 3.0},
+          {'species': -1, 'k': rng.uniform(1e-6, 1e-5, B), 'nu': [0.0, 1.0, 0.0] + [0.0] * (N - 3), 'alpha': -4.0},
+          {'species': 1, 'k': rng.uniform(1e-4, 1e-3, B), 'nu': [0.0, -1.0, 0.0] + [0.0] * (N - 3), 'saturation': 0.2}]
+    got, ref = run_both(N, nx, B=B, seed=23 + N, wall_kinetics=wk,
+                        newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, phi_pzc=0.05, mpb_radius=[4.1e-10] + [0.0] * (N - 1)))
+    assert_close(got, ref)
+    # the potential dependence is live: the same table without alpha gives a different surface state
+    got0, _ = run_both(N, nx, B=B, seed=23 + N, wall_kinetics=[dict(w, alpha=0.0) for w in wk],
+                       newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, phi_pzc=0.05, mpb_radius=[4.1e-10] + [0.0] * (N - 1)))
+    assert np.abs(got[0][:, 2, 0] - got0[0][:, 2, 0]).max() > 1e-3 * np.abs(got0[0][:, 2, 0]).max()
+
+
+def test_rate_law_argument_checks():
+    D, q, cb, dx, phiM = make_lanes(3, 32, 2, 1)
+    with _capi.PnpSolver(3, 32, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=2) as s:
+        s.set_newton()
+        s.set_batch(np.repeat(cb[:, :, None], 32, axis=2), np.zeros((2, 4)), np.zeros(2), np.zeros((2, 3)))
+        with pytest.raises(_capi.PnpError, match='n differs'):
+            s._check(s._lib.pnp_set_wall_rate_law(s._h, 1, None, None))
+        with pytest.raises(_capi.PnpError, match='saturation'):
+            s.set_wall_kinetics([-1], [[0.0, 1.0, 0.0]], np.ones((2, 1)), None, [0.5])
+        with pytest.raises(_capi.PnpError, match='saturation'):
+            s.set_wall_kinetics([1], [[0.0, 1.0, 0.0]], np.ones((2, 1)), None, [-0.5])
 
 
 @pytest.mark.parametrize("N,nx,kw", [(3, 96, {}), (3, 257, dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=[4.1e-10, 3e-10, 0.0])),

@@ -27,7 +27,8 @@ class FakeSolver(object):
     def set_flux(self, flux):
         self.calls.append(('set_flux', np.array(flux, float).copy()))
 
-    def set_wall_kinetics(self, species, nu, k):
+    def set_wall_kinetics(self, species, nu, k, alpha=None, saturation=None):
+        self.law = (alpha, saturation)
         self.calls.append(('kinetics', list(species), np.array(nu, float).copy(), np.array(k, float).copy()))
 
     def solve_stationary(self):
@@ -98,6 +99,35 @@ def test_far_potentials_and_kinetics_walk_from_phi_pzc_in_200mV_stages():
     cs = np.array([[100.0, 100.0, 2.0]] * 4)
     f = calc.surface_kinetic_fluxes(cs, phis)
     assert np.allclose(f[:, 2], -rate(phis) * 2.0) and np.allclose(f[:, 1], 0.5 * rate(phis) * 2.0) and np.all(f[:, 0] == 0)
+
+
+def test_rate_law_beyond_first_order_reaches_the_solver_and_the_flux_formula():
+    """'alpha' (Butler-Volmer in the Stern-layer drop) and 'saturation' (Langmuir) of set_surface_kinetics: handed to the C-ABI
+    wrapper as pnp_set_wall_rate_law arrays, and evaluated by surface_kinetic_fluxes as K c/(1 + K_sat c) exp(alpha (phiM - phi_0))
+    (the reference's user-defined flux form, docs/source/topics/flux_definition.rst:90-160)."""
+    phis = np.array([0.1, 0.2])
+    tp = make_tp(phis)
+    calc = Calculator(transport=tp, calc='comsol')
+    kin = [{'species': 'CO2', 'rate': 2e-3, 'alpha': -9.0, 'saturation': 0.25, 'stoichiometry': {'CO2': -1.0, 'HCO3-': 1.0}},
+           {'species': None, 'rate': 1e-6, 'stoichiometry': {'K+': 1.0}}]
+    calc.set_surface_kinetics(kin)
+    s = FakeSolver(); s.B = 2
+    calc._apply_surface_kinetics(s, phis)
+    assert s.law == ([-9.0, 0.0], [0.25, 0.0]) and s.calls[-1][1] == [2, -1]
+    cs = np.array([[100.0, 100.0, 8.0], [100.0, 100.0, -1.0]])
+    v0 = np.array([0.05, 0.02])
+    f = calc.surface_kinetic_fluxes(cs, phis, vsurf=v0)
+    g0 = 8.0 / (1.0 + 0.25 * 8.0) * np.exp(-9.0 * (0.1 - 0.05))
+    assert np.isclose(f[0, 2], -2e-3 * g0, rtol=1e-15) and np.isclose(f[0, 1], 2e-3 * g0, rtol=1e-15) and f[0, 0] == 1e-6
+    assert calc.surface_kinetic_fluxes(cs, phis, clip=True, vsurf=v0)[1, 2] == 0.0       # clipped surface concentration
+    with pytest.raises(CalculatorError, match='surface potential'):
+        calc.surface_kinetic_fluxes(cs, phis)
+    with pytest.raises(CalculatorError, match='saturation'):
+        calc.set_surface_kinetics([{'species': None, 'rate': 1.0, 'saturation': 0.1, 'stoichiometry': {}}])
+    # first-order tables keep the old call shape (no rate-law arrays)
+    calc.set_surface_kinetics([{'species': 'CO2', 'rate': 1.0, 'stoichiometry': {'CO2': -1.0}}])
+    calc._apply_surface_kinetics(s, phis)
+    assert s.law == (None, None)
 
 
 def test_warm_and_time_dependent_paths():

@@ -73,6 +73,40 @@ def test_jacobian_matches_finite_differences():
     assert (np.abs(J - Jfd) / col[None, :]).max() < 1e-5
 
 
+def test_jacobian_of_butler_volmer_and_langmuir_wall_kinetics_matches_finite_differences():
+    """Wall rate law K c/(1 + K_sat c) exp(alpha (phiM - phi_0)) (docs/source/topics/flux_definition.rst:90-160 of the reference):
+    concentration AND surface-potential derivatives of the wall rows."""
+    rng = np.random.default_rng(5)
+    nx, nb = 8, 4
+    wk = [{'species': 2, 'k': 3e-2, 'nu': [0.0, 1.0, -1.0], 'alpha': -19.5, 'saturation': 0.08},
+          {'species': 0, 'k': 2e-3, 'nu': [-1.0, 0.0, 1.0], 'alpha': 12.0},
+          {'species': -1, 'k': 4e-6, 'nu': [0.0, 1.0, 0.0], 'alpha': -7.0},
+          {'species': 1, 'k': 5e-3, 'nu': [0.0, -1.0, 0.0], 'saturation': 0.3}]
+    p = PH.PhysicalProblem(D=[1.957e-9, 1.185e-9, 1e-9], charges=[F, -F, 0.0], beta=BETA, eps=EPS, dx=3e-10, nx=nx,
+                           c_bulk=[10, 10, 5], phiM=-0.4, stern_capacitance=0.2, phi_pzc=0.05, wall_kinetics=wk)
+    c = rng.uniform(1, 20, (3, nx)); phi = rng.uniform(-0.15, 0.0, nx); co = c.copy()
+    F0, L, M, U = PH.residual_and_jacobian(p, c, phi, co, np.inf)
+    x0 = np.concatenate([c, phi[None]], 0)
+    for s_ in range(nb):                       # only the wall point's unknowns enter the wall kinetics
+        h = 1e-6 * max(abs(x0[s_, 0]), 1e-3)
+        xp = x0.copy(); xp[s_, 0] += h
+        xm = x0.copy(); xm[s_, 0] -= h
+        fd = (PH.residual(p, xp[:3], xp[3], co, np.inf) - PH.residual(p, xm[:3], xm[3], co, np.inf)) / (2 * h)
+        assert np.abs(M[0][:, s_] - fd[:, 0]).max() <= 2e-6 * np.abs(fd[:, 0]).max()
+    # the potential column is not a rounding-level effect: the BV terms are a sizeable part of it
+    p0 = PH.PhysicalProblem(D=p.D, charges=p.q, beta=BETA, eps=EPS, dx=3e-10, nx=nx, c_bulk=[10, 10, 5], phiM=-0.4,
+                            stern_capacitance=0.2, phi_pzc=0.05, wall_kinetics=[dict(w, alpha=0.0) for w in wk])
+    M0 = PH.residual_and_jacobian(p0, c, phi, co, np.inf)[2]
+    assert np.abs(M[0][:3, 3] - M0[0][:3, 3]).max() > 1e-3 * np.abs(M[0][:3, 3]).max()
+    # alpha = saturation = 0 is the first-order table, bit for bit
+    first = [{k: v for k, v in w.items() if k in ('species', 'k', 'nu')} for w in wk]
+    zero = [dict(w, alpha=0.0, saturation=0.0) for w in first]
+    pa = PH.PhysicalProblem(D=p.D, charges=p.q, beta=BETA, eps=EPS, dx=3e-10, nx=nx, c_bulk=[10, 10, 5], phiM=-0.4, wall_kinetics=first)
+    pz = PH.PhysicalProblem(D=p.D, charges=p.q, beta=BETA, eps=EPS, dx=3e-10, nx=nx, c_bulk=[10, 10, 5], phiM=-0.4, wall_kinetics=zero)
+    ra, rz = PH.residual_and_jacobian(pa, c, phi, co, np.inf), PH.residual_and_jacobian(pz, c, phi, co, np.inf)
+    assert all(np.array_equal(a, b) for a, b in zip(ra, rz))
+
+
 def test_block_pcr_mirror_equals_banded_lu():
     rng = np.random.default_rng(1)
     p, c0, phi0, lam = binary(0.1, ppl=4, ncell=16)
