@@ -21,7 +21,7 @@ from .units import unit_F
 CALC_LIST = ['FTCS', 'Crank-Nicolson', 'odeint', 'vode', 'lsoda', 'dopri5', 'dop853', 'odeint', 'odespy', 'comsol']
 CALC_LIST = CALC_LIST + ['Newton']
 GPU_CALCS = ('FTCS', 'Crank-Nicolson')
-MOL_CALCS = ('odeint', 'lsoda', 'dopri5', 'dop853')   # method of lines: scipy driver, RHS on the GPU
+MOL_CALCS = ('odeint', 'lsoda', 'dopri5', 'dop853')   # method of lines: RHS on the GPU; 'dopri5' integrates on the device too, the others through scipy
 # physical mode: what run_single_step asks COMSOL for (calculator.py:408-535, comsol_wrapper.py:145,158) solved on the
 # GPU by the fully implicit coupled Newton kernel; 'comsol' is accepted as its name so reference scripts keep working
 PHYSICAL_CALCS = ('comsol', 'Newton')
@@ -142,9 +142,20 @@ class Calculator(object):
         modes = {pb_mode_from_bound(p) for p in pb}
         if len(modes) != 1:
             raise CalculatorError('all lanes of a batch must use the same pb_bound combination')
+        if self.calc in MOL_CALCS and self.calc != 'dopri5':
+            raise CalculatorError("descriptor sweeps along the method of lines run with calc='dopri5' (integrator on the device); "
+                                  "'%s' is driven by scipy, one operating point at a time (integrate_pnp)" % self.calc)
         with self._solver(B, modes.pop(), dx, nx, dt) as s:
             s.set_batch(c0, pb, vzeta, flux)
-            cout, status = s.integrate(nt, itout)
+            if self.calc == 'dopri5':
+                # every lane its own adaptive DOPRI5 (pnp_integrate_dopri5); output n = state at (n+1) dt (calculator_old.py:959-969);
+                # status: 0 ok, 1 = the integrator gave up on the lane (nsteps / step size / stiffness: self.ode_idid)
+                out = [int(n) for n in itout if n < nt]
+                cout, idid, self.ode_stats, _ = s.integrate_dopri5(nt, out, nsteps=10000, **getattr(self, 'ode_options', {}))
+                self.ode_idid = idid
+                status = (idid < 0).astype(np.int32)
+            else:
+                cout, status = s.integrate(nt, itout)
             _, v, g, l = s.get_state()
         return cout, status, (v, g, l)
 
@@ -167,15 +178,24 @@ class Calculator(object):
         return [cout[i, 0].copy() for i in range(cout.shape[0])]
 
     def _integrate_mol(self, dx, nx, dt, nt):
-        """integrate_odeint (calculator_old.py:821-973): scipy's integrators driving the method-of-lines RHS,
-        with the RHS (ode_func :827-935) evaluated by the HIP kernel.  Output indexing follows the reference:
-        odeint/lsoda return the state at tmesh[n]; the `ode` family appends r.integrate(r.t+dt), so entry n
-        is the state at (n+1)*dt (:959-963)."""
+        """integrate_odeint (calculator_old.py:821-973): the method-of-lines right-hand side (ode_func :827-935) is the HIP kernel.
+        calc='dopri5': the integrator runs on the device as well (pnp_integrate_dopri5: Hairer's DOPRI5 as scipy wraps it, one call
+        per interval, :955-963) unless self.ode_on_device is False; 'odeint'/'lsoda'/'dop853': scipy's integrators drive the device
+        right-hand side from the host.  Output indexing follows the reference: odeint/lsoda return the state at tmesh[n]; the `ode`
+        family appends r.integrate(r.t+dt), so entry n is the state at (n+1)*dt (:959-963)."""
         import scipy.integrate as integrate
         tp = self.tp
         pb = tp.pb_array()[None, :]
         with self._solver(1, pb_mode_from_bound(pb[0]), dx, nx, dt) as s:
             s.set_batch(tp.c0[None, :], pb, [tp.system['vzeta']], tp.flux_bound[None, :, 0])
+            if self.calc == 'dopri5' and getattr(self, 'ode_on_device', True):
+                out = [n for n in range(nt) if n in tp.itout]
+                cout, idid, stats, t_end = s.integrate_dopri5(nt, out, nsteps=10000, **getattr(self, 'ode_options', {}))
+                self.status = 0
+                self.ode_idid, self.ode_stats = int(idid[0]), stats[0].copy()
+                # a failed call ends the reference's loop after appending its result (:959-963): sol stops at that interval
+                nsol = nt if idid[0] >= 0 else int(stats[0, 4]) + 1
+                return [cout[j, 0].copy() for j, n in enumerate(out) if n < nsol]
 
             def f_ty(t, c):
                 return s.mol_rhs(c[None, :])[0]
@@ -183,7 +203,7 @@ class Calculator(object):
             if self.calc in ('lsoda', 'odeint'):     # :946-948
                 sol = integrate.odeint(lambda c, t: f_ty(t, c), tp.c0, tp.tmesh, ml=tp.nspecies, mu=tp.nspecies)
             else:                                    # :955-963 (the reference's nsteps=10000 branch)
-                r = integrate.ode(f_ty).set_integrator(self.calc, nsteps=10000)
+                r = integrate.ode(f_ty).set_integrator(self.calc, nsteps=10000, **getattr(self, 'ode_options', {}))
                 r.set_initial_value(tp.c0)
                 sol = []
                 while r.successful() and r.t < nt * dt:

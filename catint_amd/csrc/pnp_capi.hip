@@ -29,6 +29,8 @@ struct pnp_handle {
   double *pb = nullptr, *vzeta = nullptr, *flux = nullptr, *cbulk = nullptr, *csurf = nullptr;
   double *ytmp = nullptr, *ftmp = nullptr;   // method-of-lines scratch: state in, derivative out
   double* mol_lapl = nullptr;                // ... and its charge row for grids beyond one wave
+  double* ode_buf = nullptr;                 // pnp_integrate_dopri5: k1..k6, y1, ysti ([cap][N][ldx] each) + per-lane reals
+  int32_t* ode_int = nullptr;                // ... per-lane integers + 64 counters
   double* stage = nullptr;                   // upload staging [B][N][nx] (pnp_set_batch)
   SpecConst* spec = nullptr;
   int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
@@ -104,7 +106,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->ode_buf, (void*)h->ode_int})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -899,6 +901,31 @@ static int ensure_potential_buffers(pnp_handle* h) {
   return PNP_OK;
 }
 
+// ode_func (calculator_old.py:827-935) of every lane: f[B][N][ldx] from y[B][N][ldx], both on the device
+static int eval_mol_rhs(pnp_handle* h, const double* y, double* f) {
+  DevArgs a = h->a;
+  if (a.has_rates) {
+    a.c = const_cast<double*>(y);   // get_rates(C) of the state being differentiated (calculator_old.py:872-873)
+    HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
+  }
+  if (waves_per_system(a.nx) > 1) {
+    // grids beyond one wave: charge row of the state -> Poisson (multi-wave scans) -> point-wise right-hand side
+    const int rc = ensure_potential_buffers(h);
+    if (rc != PNP_OK) return rc;
+    if (!h->mol_lapl) HIP_TRY(h, dev_alloc(h, &h->mol_lapl, (size_t)h->cfg.batch_capacity * a.ldx));
+    DevArgs ay = a;
+    ay.c = const_cast<double*>(y);
+    if (a.use_mig) {
+      HIP_TRY(h, launch_charge_row(ay, h->mol_lapl, h->stream));
+      HIP_TRY(h, launch_poisson(a, h->mol_lapl, h->v, h->gradv, h->stream));
+    }
+    HIP_TRY(h, launch_mol_rhs_pointwise(a, y, h->gradv, f, h->stream));
+  } else {
+    HIP_TRY(h, launch_mol_rhs(a, y, f, h->stream));
+  }
+  return PNP_OK;
+}
+
 int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
   if (!h || !c || !dcdt) return fail(h, PNP_EINVAL, "pnp_mol_rhs: null argument");
   if (h->newton) return fail(h, PNP_EINVAL, "pnp_mol_rhs: not part of the physical mode");
@@ -914,28 +941,128 @@ int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
   }
   const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
   HIP_TRY(h, hipMemcpy2DAsync(h->ytmp, dp, c, w, w, (size_t)B * N, hipMemcpyHostToDevice, h->stream));
-  DevArgs a = h->a;
-  if (a.has_rates) {
-    a.c = h->ytmp;   // get_rates(C) of the state being differentiated (calculator_old.py:872-873)
-    HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
-  }
-  if (waves_per_system(a.nx) > 1) {
-    // grids beyond one wave: charge row of the state -> Poisson (multi-wave scans) -> point-wise right-hand side
-    const int rc = ensure_potential_buffers(h);
-    if (rc != PNP_OK) return rc;
-    if (!h->mol_lapl) HIP_TRY(h, dev_alloc(h, &h->mol_lapl, (size_t)h->cfg.batch_capacity * ldx));
-    DevArgs ay = a;
-    ay.c = h->ytmp;
-    if (a.use_mig) {
-      HIP_TRY(h, launch_charge_row(ay, h->mol_lapl, h->stream));
-      HIP_TRY(h, launch_poisson(a, h->mol_lapl, h->v, h->gradv, h->stream));
-    }
-    HIP_TRY(h, launch_mol_rhs_pointwise(a, h->ytmp, h->gradv, h->ftmp, h->stream));
-  } else {
-    HIP_TRY(h, launch_mol_rhs(a, h->ytmp, h->ftmp, h->stream));
-  }
+  const int rc = eval_mol_rhs(h, h->ytmp, h->ftmp);
+  if (rc != PNP_OK) return rc;
   HIP_TRY(h, hipMemcpy2DAsync(dcdt, w, h->ftmp, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
+int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
+                         int32_t* idid, int64_t* stats, double* t_end) {
+  if (!h || !p) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: null argument");
+  if (h->newton) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: not part of the physical mode");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_integrate_dopri5: call pnp_set_batch first");
+  if (p->struct_size != (int32_t)sizeof(pnp_ode_params)) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: struct_size mismatch (ABI)");
+  if (nt < 0 || n_out < 0 || (n_out > 0 && (!itout || !cout))) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: bad output request");
+  for (int j = 0; j < n_out; ++j)
+    if (itout[j] < 0 || itout[j] >= nt || (j > 0 && itout[j] <= itout[j - 1]))
+      return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: itout must be ascending and inside [0, nt)");
+  if (p->rtol < 0.0 || p->atol < 0.0 || p->first_step < 0.0 || p->max_step < 0.0 || p->nsteps < 0 || p->nstiff < 0)
+    return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: negative parameter");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
+  const int64_t B = h->B, cap = h->cfg.batch_capacity;
+  const size_t cnt = (size_t)cap * N * ldx;
+  hipStream_t st = h->stream;
+  if (!h->ode_buf) {
+    HIP_TRY(h, dev_alloc(h, &h->ode_buf, 8 * cnt + (size_t)cap * ODE_ND));
+    HIP_TRY(h, dev_alloc(h, &h->ode_int, (size_t)cap * ODE_NI + 64));
+    HIP_TRY(h, hipMemsetAsync(h->ode_buf, 0, (8 * cnt + (size_t)cap * ODE_ND) * sizeof(double), st));   // pads of the rows stay zero
+  }
+  OdeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.nx = nx; a.ldx = ldx; a.B = B;
+  a.nmax = p->nsteps > 0 ? p->nsteps : 500;
+  a.nstiff = p->nstiff > 0 ? p->nstiff : 1000;
+  a.rtol = p->rtol > 0.0 ? p->rtol : 1e-6;
+  a.atol = p->atol > 0.0 ? p->atol : 1e-12;
+  a.safe = p->safety > 0.0 ? p->safety : 0.9;
+  a.facc1 = 1.0 / (p->dfactor > 0.0 ? p->dfactor : 0.2);
+  a.facc2 = 1.0 / (p->ifactor > 0.0 ? p->ifactor : 10.0);
+  a.beta = p->beta == 0.0 ? 0.04 : (p->beta < 0.0 ? 0.0 : p->beta);     // DOPRI5: WORK(5) = 0 -> 0.04, < 0 -> 0
+  a.expo1 = 0.2 - a.beta * 0.75;
+  a.max_step = p->max_step;
+  a.dt = h->a.dt;
+  a.y = h->c;
+  for (int j = 0; j < 6; ++j) a.k[j] = h->ode_buf + (size_t)j * cnt;
+  a.y1 = h->ode_buf + 6 * cnt;
+  a.ysti = h->ode_buf + 7 * cnt;
+  a.d = h->ode_buf + 8 * cnt;
+  a.i = h->ode_int;
+  a.counters = h->ode_int + (size_t)cap * ODE_NI;
+  {   // t = 0, h = first_step, IDID = 1, counters zero
+    std::vector<double> d0((size_t)B * ODE_ND, 0.0);
+    std::vector<int32_t> i0((size_t)B * ODE_NI, 0);
+    for (int64_t b = 0; b < B; ++b) {
+      d0[b * ODE_ND + ODE_H] = p->first_step;
+      i0[b * ODE_NI + ODE_IDID] = 1;
+      i0[b * ODE_NI + ODE_INTERVAL] = -1;
+    }
+    HIP_TRY(h, hipMemcpyAsync(a.d, d0.data(), d0.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(a.i, i0.data(), i0.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipStreamSynchronize(st));      // the staging vectors go out of scope
+  }
+  const int every = p->check_every > 0 ? (p->check_every < 32 ? p->check_every : 32) : 4;
+  const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
+  int next_out = 0;
+  int64_t step = 0;
+  for (int n = 0; n < nt; ++n) {
+    a.interval = n;
+    HIP_TRY(h, launch_ode_begin(a, st));
+    int rc = eval_mol_rhs(h, a.y, a.k[0]);
+    if (rc != PNP_OK) return rc;
+    if (n == 0 && p->first_step == 0.0) {
+      HIP_TRY(h, launch_ode_hinit(a, 0, st));
+      rc = eval_mol_rhs(h, a.y1, a.k[1]);
+      if (rc != PNP_OK) return rc;
+      HIP_TRY(h, launch_ode_hinit(a, 1, st));
+    }
+    HIP_TRY(h, launch_ode_open(a, st));
+    int32_t left = 1;
+    // a lane needs at most nmax + 1 attempted steps per interval; the counter is read every `every` steps
+    for (int64_t tries = 0; left != 0 && tries <= (int64_t)a.nmax + 1; tries += every) {
+      for (int e = 0; e < every; ++e) {
+        static const int dst[6] = {1, 2, 3, 4, 5, 1};      // k2..k6, then k7 into k2's buffer
+        for (int sgi = 2; sgi <= 7; ++sgi) {
+          HIP_TRY(h, launch_ode_stage(a, sgi, st));
+          rc = eval_mol_rhs(h, sgi == 6 ? a.ysti : a.y1, a.k[dst[sgi - 2]]);
+          if (rc != PNP_OK) return rc;
+        }
+        a.slot = (int32_t)(step++ & 63);
+        HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
+        HIP_TRY(h, launch_ode_control(a, st));
+      }
+      HIP_TRY(h, hipMemcpyAsync(&left, a.counters + a.slot, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    if (next_out < n_out && itout[next_out] == n) {
+      HIP_TRY(h, hipMemcpy2DAsync(cout + (size_t)next_out * B * N * nx, w, a.y, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, st));
+      ++next_out;
+    }
+  }
+  // the last right-hand side of the reference's run is k7 = f(final state): tp.potential / efield belong to the state returned
+  // (calculator_old.py:816-818 inside ode_func).  Same here: charge row of the integrated state for pnp_get_state / pnp_get_surface.
+  h->cur = 0;
+  HIP_TRY(h, launch_charge_row(h->a, h->lapl[0], st));
+  h->steps_done = 0;
+  std::vector<double> dh((size_t)B * ODE_ND);
+  std::vector<int32_t> ih((size_t)B * ODE_NI);
+  HIP_TRY(h, hipMemcpyAsync(dh.data(), a.d, dh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(ih.data(), a.i, ih.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t* s = ih.data() + b * ODE_NI;
+    if (idid) idid[b] = s[ODE_IDID];
+    if (t_end) t_end[b] = dh[b * ODE_ND + ODE_X];
+    if (stats) {
+      stats[b * 5 + 0] = s[ODE_TOT_NSTEP];
+      stats[b * 5 + 1] = s[ODE_TOT_NACCPT];
+      stats[b * 5 + 2] = s[ODE_TOT_NREJCT];
+      stats[b * 5 + 3] = s[ODE_TOT_NFCN];
+      stats[b * 5 + 4] = s[ODE_INTERVAL];
+    }
+  }
   return PNP_OK;
 }
 

@@ -184,4 +184,27 @@ hipError_t launch_scf_pre(const ScfArgs& a, hipStream_t stream);     // mixing, 
 hipError_t launch_scf_keep(const ScfArgs& a, hipStream_t stream);    // converged lanes: state -> snapshot; failed lanes: snapshot -> state
 hipError_t launch_scf_post(const ScfArgs& a, hipStream_t stream);    // surface state, accuracy, convergence flags
 
+// ---- method-of-lines integrator on the device (pnp_ode.hip; scipy 'dopri5' = Hairer's DOPRI5, calculator_old.py:955-963) ----
+enum { ODE_X = 0, ODE_H, ODE_XEND, ODE_FACOLD, ODE_HLAMB, ODE_HMAX, ODE_ERR, ODE_HTRY, ODE_DNF, ODE_ND = 10 };
+enum { ODE_ACTIVE = 0, ODE_LAST, ODE_REJECT, ODE_NSTEP, ODE_NACCPT, ODE_IASTI, ODE_NONSTI, ODE_IDID, ODE_INTERVAL,
+       ODE_TOT_NSTEP, ODE_TOT_NACCPT, ODE_TOT_NREJCT, ODE_TOT_NFCN, ODE_NI = 14 };
+struct OdeArgs {
+  int32_t N, nx, ldx, nmax;
+  int32_t nstiff, slot, interval, pad_;
+  int64_t B;
+  double rtol, atol, safe, facc1, facc2, beta, expo1, max_step, dt;
+  double* y;          // [B][N][ldx] the state (the handle's c)
+  double* k[6];       // k1..k6; k7 = f(y1) lands in k[1] (a_72 = e_2 = 0)
+  double* y1;         // stage argument / new state
+  double* ysti;       // argument of stage 6 (stiffness detection)
+  double* d;          // [B][ODE_ND] per-lane reals
+  int32_t* i;         // [B][ODE_NI] per-lane integers
+  int32_t* counters;  // [64] lanes still inside the interval after a step (slot = step & 63)
+};
+hipError_t launch_ode_begin(const OdeArgs& a, hipStream_t stream);
+hipError_t launch_ode_hinit(const OdeArgs& a, int half, hipStream_t stream);
+hipError_t launch_ode_open(const OdeArgs& a, hipStream_t stream);
+hipError_t launch_ode_stage(const OdeArgs& a, int stage, hipStream_t stream);     // stage 2..7
+hipError_t launch_ode_control(const OdeArgs& a, hipStream_t stream);
+
 }  // namespace pnp

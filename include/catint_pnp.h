@@ -135,6 +135,29 @@ int pnp_integrate(pnp_handle* h, int32_t nt, const int32_t* itout, int32_t n_out
  * (catint_amd/calculator.py) does the same with this entry point.  The state on the device is not touched. */
 int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt);
 
+/* The reference's calc='dopri5' path with the integrator itself on the device: scipy.integrate.ode(ode_func).set_integrator(
+ * 'dopri5', nsteps=10000), r.integrate(r.t + dt) once per interval (calculator_old.py:955-963).  scipy's 'dopri5' is Hairer's
+ * DOPRI5 (Dormand-Prince 5(4), error norm sqrt(mean((e_i/(atol + rtol max(|y_i|,|ynew_i|)))^2)), Lund-stabilised controller,
+ * stiffness detection); every lane runs it with its own step size, no host round trip per right-hand side.  Defaults (fields left
+ * at 0) are scipy's: rtol 1e-6, atol 1e-12, nsteps 500, safety 0.9, ifactor 10, dfactor 0.2, beta 0 (-> 0.04), max_step 0 (-> the
+ * interval), first_step 0 (-> HINIT), nstiff 1000. */
+typedef struct {
+  int32_t struct_size;   /* sizeof(pnp_ode_params) */
+  int32_t nsteps;        /* NMAX: attempted steps per interval */
+  double rtol, atol;
+  double first_step, max_step;
+  double safety, ifactor, dfactor, beta;
+  int32_t nstiff;
+  int32_t check_every;   /* steps enqueued between two reads of the "lanes left" counter (default 4) */
+} pnp_ode_params;
+/* Integrates the state on the device (pnp_set_batch) over nt intervals of cfg.dt starting at t = 0.  cout[n_out][B][N][nx]: the
+ * state after interval n = itout[j] (0-based: the state at (n+1) dt, the indexing of the reference's `sol` list, :959-969);
+ * idid[B]: DOPRI5's IDID of the lane's last call (1 ok, -2 nsteps exceeded, -3 step size too small, -4 stiff) -- a failed lane
+ * stays at the state of its last accepted step, as r.successful() ends the reference's loop; stats[B][5] (nullable): attempted
+ * steps, accepted, rejected, right-hand-side evaluations, interval of the last call; t_end[B] (nullable): time reached. */
+int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
+                         int32_t* idid, int64_t* stats, double* t_end);
+
 /* ---- physical mode (PNP_METHOD_NEWTON) -------------------------------------------------------------- */
 typedef struct pnp_newton_params {
   int32_t struct_size;       /* = sizeof(pnp_newton_params) */

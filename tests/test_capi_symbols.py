@@ -19,7 +19,7 @@ def lib():
 def declared_symbols():
     src = open(os.path.join(ROOT, 'include', 'catint_pnp.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(pnp_[a-z_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(pnp_[a-z0-9_]+)\s*\(', src)))
 
 
 def test_header_and_binding_agree():

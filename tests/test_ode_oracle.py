@@ -1,0 +1,81 @@
+"""oracle/dopri5.py pinned against the integrator the reference calls: scipy.integrate.ode(f).set_integrator('dopri5', nsteps=10000),
+one integrate(t + dt) per interval (catint/calculator_old.py:955-963).  Same sequence of right-hand-side evaluations (times),
+same trajectory bit for bit, same failure exits."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.integrate as si
+
+from oracle.dopri5 import Dopri5
+
+
+def logged(fun):
+    calls = []
+
+    def f(t, y):
+        calls.append(t)
+        return fun(t, y)
+    return f, calls
+
+
+def oscillator(t, y):
+    return np.array([y[1], -y[0] * (1 + 0.3 * np.sin(y[1])), -50 * (y[2] - np.cos(t))])
+
+
+def diffusion(t, y):        # a small method-of-lines problem: heat equation with a reaction term, 24 unknowns
+    d = np.zeros_like(y)
+    d[1:-1] = 400.0 * (y[2:] - 2 * y[1:-1] + y[:-2]) - 3.0 * y[1:-1] ** 2
+    return d
+
+
+@pytest.mark.parametrize('fun,y0,dt,nt,kw', [
+    (oscillator, [1.0, 0.0, 0.3], 0.7, 30, {}),
+    (oscillator, [1.0, 0.0, 0.3], 0.05, 40, {'rtol': 1e-9, 'atol': 1e-10}),
+    (diffusion, list(np.sin(np.linspace(0, np.pi, 24)) ** 2), 0.01, 25, {}),
+    (diffusion, list(np.sin(np.linspace(0, np.pi, 24)) ** 2), 0.01, 10, {'first_step': 1e-4, 'max_step': 2e-3, 'safety': 0.8, 'ifactor': 5.0,
+                                                                         'dfactor': 0.3, 'beta': 0.08}),
+    (diffusion, list(np.sin(np.linspace(0, np.pi, 24)) ** 2), 0.01, 10, {'beta': -1.0}),
+])
+def test_restatement_equals_scipy_bit_for_bit(fun, y0, dt, nt, kw):
+    f, ca = logged(fun)
+    g, cb = logged(fun)
+    r = si.ode(f).set_integrator('dopri5', nsteps=10000, **kw)
+    r.set_initial_value(y0)
+    o = Dopri5(g, nsteps=10000, **kw).set_initial_value(y0)
+    for _ in range(nt):
+        a = r.integrate(r.t + dt)
+        b = o.integrate(o.t + dt)
+        assert np.array_equal(a, b) and r.t == o.t
+    # DOPRI5 counts two evaluations per call; the second one (HINIT's) only happens in the first call, and only without first_step
+    assert np.array_equal(ca, cb) and len(ca) == o.nfcn - nt + (0 if kw.get('first_step') else 1)
+
+
+def stiff(t, y):
+    return np.array([-2e4 * y[0] + np.sin(t), -y[1]])
+
+
+@pytest.mark.parametrize('nsteps,idid,msg', [(100000, -4, 'stiff'), (50, -2, 'larger nsteps')])
+def test_failure_exits_match_scipy(nsteps, idid, msg):
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        r = si.ode(stiff).set_integrator('dopri5', nsteps=nsteps)
+        r.set_initial_value([1.0, 1.0])
+        a = r.integrate(5.0)
+    assert not r.successful() and msg in str(w[0].message)
+    o = Dopri5(stiff, nsteps=nsteps).set_initial_value([1.0, 1.0])
+    b = o.integrate(5.0)
+    assert o.idid == idid and not o.successful() and o.t == r.t and np.array_equal(a, b)
+
+
+def test_step_size_is_carried_between_calls_but_the_controller_memory_is_not():
+    f, calls = logged(oscillator)
+    o = Dopri5(f).set_initial_value([1.0, 0.0, 0.3])
+    o.integrate(0.7)
+    n1 = len(calls)
+    h_carried = o.h
+    nlog = len(o.log)
+    o.integrate(1.4)
+    # second call: one evaluation for k1 (no HINIT), first attempted step = the carried prediction
+    assert calls[n1] == 0.7 and o.log[nlog][1] == h_carried and h_carried < 0.7
+    assert (len(calls) - n1 - 1) % 6 == 0
