@@ -363,6 +363,8 @@ int pnp_set_pb(pnp_handle* h, const double* pb, const double* vzeta) {
   return PNP_OK;
 }
 
+static int ensure_potential_buffers(pnp_handle* h);
+
 int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, const double* vzeta, const double* flux) {
   if (!h || !c0 || !pb || !vzeta || !flux) return fail(h, PNP_EINVAL, "pnp_set_batch: null argument");
   if (!h->have_species) return fail(h, PNP_ESTATE, "pnp_set_batch: call pnp_set_species first");
@@ -394,6 +396,18 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   h->cur = 0;
   HIP_TRY(h, launch_charge_row(h->a, h->lapl[0], h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // Potential and gradient of the uploaded state (what pnp_get_state would compute on demand).  It is also the dispatch that
+  // keeps the first large launch after an upload at the sustained rate: measured on MI355X (profiles/r02_slow_start_after_upload.txt,
+  // DESIGN.md section 6), a launch that fills every SIMD in one round runs 1.45 x slower for its whole duration -- and so do the
+  // next one or two -- when the dispatch before it ON THIS QUEUE was one of the upload's small element-wise kernels; after a
+  // wave-per-operating-point kernel (this one, or a one-step launch) it runs at full rate.  Dispatches on other queues, idle time
+  // and extra synchronisation change nothing.
+  if (!getenv("CATINT_PNP_NO_POST_UPLOAD_DISPATCH")) {
+    const int rc = ensure_potential_buffers(h);
+    if (rc != PNP_OK) return rc;
+    HIP_TRY(h, launch_poisson(h->a, h->lapl[0], h->v, h->gradv, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
   h->have_batch = true;
   h->steps_done = 0;
   return PNP_OK;
