@@ -273,7 +273,7 @@ def hbm_record(B, N, nx, steps, launches, ev_ms, pmc):
     return rec
 
 
-def physical_mode(args, device, with_cpu, pmc):
+def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
     """Implicit physical mode (PNP_METHOD_NEWTON) with SURVEY 8(d)'s synthetic inputs: phiM ~ U(-0.2, 0.2) V, dt = 0.1 lambda_D L / D_max,
     Newton to a scaled update of 1e-8.  Not HBM-bound: its roofline is fp64 VALU issue (and LDS exchange); measured per kernel."""
     B, N, nx = args.batch, args.nspecies, args.nx
@@ -297,6 +297,7 @@ def physical_mode(args, device, with_cpu, pmc):
     s.set_batch(c0, pb, vz, fl)
     s.step(5)
     s.synchronize()
+    warm()
     ms = timed_steps(s, args.physical_steps, 0)
     it = s.newton_iterations()
     ok = int((s.get_status() == 0).sum())
@@ -327,6 +328,7 @@ def physical_mode(args, device, with_cpu, pmc):
         s.set_batch(*inp[1:])
         s.step(5)
         s.synchronize()
+        warm()
         ms_e = timed_steps(s, args.physical_steps, 0)
         it_e = s.newton_iterations()
         ok_e = int((s.get_status() == 0).sum())
@@ -342,6 +344,7 @@ def physical_mode(args, device, with_cpu, pmc):
         s8.set_batch(*inp[1:])
         s8.step(1)
         s8.synchronize()
+        warm()
         ms8 = timed_steps(s8, 3, 0)
         it8 = s8.newton_iterations()
         ok8 = int((s8.get_status() == 0).sum())
@@ -358,6 +361,7 @@ def physical_mode(args, device, with_cpu, pmc):
         s8.set_batch(*inp[1:])
         s8.step(1)
         s8.synchronize()
+        warm()
         ms8 = timed_steps(s8, 4, 0)
         it8 = s8.newton_iterations()
         ok8 = int((s8.get_status() == 0).sum())
@@ -453,16 +457,14 @@ def main():
         for _ in range(8):                            # headline kernel then IS the per-launch time of this shape)
             solver.step(args.steps, args.steps_per_launch)
         solver.synchronize()
-    # ---- what a caller sees right after an upload: pnp_set_batch, then immediately the K-step launch (reported next to the sustained
-    # rate; the first launches after an upload run slower, cause not identified -- DESIGN.md section 6).  The reference's
-    # lagged-potential integrator does not survive long runs on this workload (lanes turn NaN after ~3000 steps, in the oracle
-    # too), hence the fresh upload before the timed region as well.
+    # ---- what a caller sees right after an upload: pnp_set_batch, then immediately the K-step launch, reported next to the sustained
+    # rate (round 1: 1.45 x slower; its cause -- the dispatch preceding a launch that only just fits -- is removed inside
+    # pnp_set_batch since round 2).  The reference's lagged-potential integrator does not survive long runs on
+    # this workload (lanes turn NaN after ~3000 steps, in the oracle too), hence the fresh upload before the timed region as well.
     solver.set_batch(c0, pb, vz, fl)
     cold_wall, cold_ev = timed(args.steps, args.steps_per_launch)
-    # ---- sustained rate: upload, four K-step launches (past the slow ones), the W warm-up steps, then the K timed steps -------------
+    # ---- the timed region of the contract: upload, the W warm-up steps, then exactly K timed steps -----------------------------------
     solver.set_batch(c0, pb, vz, fl)
-    for _ in range(4):
-        solver.step(args.steps, args.steps_per_launch)
     solver.step(args.warmup, args.steps_per_launch)
     wall, ev_ms = timed(args.steps, args.steps_per_launch)
     status = solver.get_status()
@@ -491,7 +493,16 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t0) * 1e3
         assert curve.shape == (world * B, N + 2)
-    solver.close()
+
+    def warm_clocks(seconds=0.2):
+        """The sub-benchmarks below build their inputs on the host for up to seconds while the GPU idles; >= 10 ms of idle time cost
+        the next launches ~10 % (clocks, profiles/r02_slow_start_after_upload.txt).  Load from the headline handle right before a
+        timed loop brings them back up, as the settling loop does for the headline."""
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(4):
+                solver.step(256, 256)
+            solver.synchronize()
 
     large = None
     if extras and args.large_batch > 0:
@@ -501,6 +512,8 @@ def main():
         s2.step(64, 1)
         ls = max(10, min(args.steps, 50))
         s2.synchronize()
+        warm_clocks()
+        s2.step(16, 1)
         lms = timed_steps(s2, ls, 1)
         lok = int((s2.get_status() == 0).sum())
         large = hbm_record(LB, N, nx, ls, ls, lms, None)
@@ -510,6 +523,7 @@ def main():
             s2.step(8, 8)
         s2.step(args.steps_per_launch, args.steps_per_launch)
         s2.synchronize()
+        warm_clocks()
         fms = timed_steps(s2, args.steps, args.steps_per_launch)
         s2.close()
         large['fused'] = {'timesteps_per_s': LB * args.steps / (fms * 1e-3), 'steps_per_launch': args.steps_per_launch,
@@ -523,12 +537,15 @@ def main():
             s3.set_batch(*inp[1:])
             s3.step(8, 1)
             s3.synchronize()
+            warm_clocks()
+            s3.step(8, 1)
             ms1 = timed_steps(s3, 8, 1, reps=3)
             ok1 = int((s3.get_status() == 0).sum())
             rec1 = hbm_record(BB, BN, BX, 8, 8, ms1, pmc.get('beyond_cache_per_step'))
             s3.set_batch(*inp[1:])
             s3.step(32, 32)
             s3.synchronize()
+            warm_clocks()
             ms32 = timed_steps(s3, 32, 32, reps=3)
             rec32 = hbm_record(BB, BN, BX, 32, 1, ms32, pmc.get('beyond_cache_fused'))
             s3.close()
@@ -583,7 +600,7 @@ def main():
         if beyond:
             out['beyond_cache'] = beyond
         if extras and args.physical_steps > 0:
-            out['physical_mode'] = physical_mode(args, device, not args.no_cpu_baseline, pmc if isinstance(pmc, dict) else {})
+            out['physical_mode'] = physical_mode(args, device, not args.no_cpu_baseline, pmc if isinstance(pmc, dict) else {}, warm_clocks)
         if gather_ms is not None:
             out['gather_ms'] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
@@ -592,6 +609,7 @@ def main():
                 cb['reference_faithful_dense_1core'] = cpu_reference_faithful(prob, c0, pb, vz, fl, args.method)
             out['cpu_baseline'] = cb
         print(json.dumps(out))
+    solver.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

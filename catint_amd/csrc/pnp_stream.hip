@@ -33,6 +33,15 @@ namespace pnp {
 #ifndef ST_PRIO_STORE
 #define ST_PRIO_STORE 3
 #endif
+// Cache policy of the row traffic (buffer instruction aux bits; 2 = nt).  The state is read once and overwritten in place per
+// launch; tools/probe/access_pattern2.hip: an in-place streaming copy runs at 0.66 of 8 TB/s with the default policy and 0.70 with
+// nt loads + nt stores (out of place: 0.68 either way).
+#ifndef ST_AUX_LOAD
+#define ST_AUX_LOAD 0
+#endif
+#ifndef ST_AUX_STORE
+#define ST_AUX_STORE 0
+#endif
 #ifndef ST_TOUCH_AUX
 #define ST_TOUCH_AUX 16   // sc1: served by L2, no allocation in the (32 KiB) vector L1
 #endif
@@ -88,8 +97,8 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
   double lw[P + 2];        // lagged charge row window: lapl_v[r0 + t]
   double cw[P + 2];        // concentration window in flight: C[k][r0 + t]
   // prologue: the first operating point's charge row and first species row
-  if (A.use_mig) load_window<P>(row_rsrc(A.lapl_a + b * (int64_t)ldx, ldx), lw, lane);
-  load_window<P>(row_rsrc(A.c + b * (int64_t)N * ldx, ldx), cw, lane);
+  if (A.use_mig) load_window<P, ST_AUX_LOAD>(row_rsrc(A.lapl_a + b * (int64_t)ldx, ldx), lw, lane);
+  load_window<P, ST_AUX_LOAD>(row_rsrc(A.c + b * (int64_t)N * ldx, ldx), cw, lane);
 
   for (; b < A.B; b += stride) {
     const int64_t bn = (b + stride < A.B) ? b + stride : b;      // next operating point of this wave (the last one re-reads itself)
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
         // fused launches: the next step re-reads rows this wave has just written; the charge window came over in registers
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        load_window<P>(row_rsrc(crow0, ldx), cw, lane_p);
+        load_window<P, ST_AUX_LOAD>(row_rsrc(crow0, ldx), cw, lane_p);
       }
       // ---- 1. lagged potential: v'' = lapl, v[0] = vw, v[nx-1] = vb  (calculator_old.py:716-730, :780-786) ----
       double gx[GL ? 1 : P + 3];   // grad_v[r0 - 1 + t]
@@ -292,10 +301,10 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
         }
         // ---- the windows are consumed: request the next ones into the registers they leave behind -----------------
         if (k + 1 < N) {
-          load_window<P>(row_rsrc(crow0 + (int64_t)(k + 1) * ldx, ldx), cw, lane_o);
+          load_window<P, ST_AUX_LOAD>(row_rsrc(crow0 + (int64_t)(k + 1) * ldx, ldx), cw, lane_o);
         } else if (last_step) {
-          if (A.use_mig) load_window<P>(row_rsrc(A.lapl_a + bn * (int64_t)ldx, ldx), lw, lane_o);
-          load_window<P>(row_rsrc(A.c + bn * (int64_t)N * ldx, ldx), cw, lane_o);
+          if (A.use_mig) load_window<P, ST_AUX_LOAD>(row_rsrc(A.lapl_a + bn * (int64_t)ldx, ldx), lw, lane_o);
+          load_window<P, ST_AUX_LOAD>(row_rsrc(A.c + bn * (int64_t)N * ldx, ldx), cw, lane_o);
         }
         // ... and pull the row(s) AFTER those from HBM into L2 with one dword per 64 bytes (one instruction covers a 4 KiB
         // row): under load an HBM miss takes longer than one row's solve, so the window request above hits L2 only if the row
@@ -348,7 +357,11 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
         }
         if (lane_o < ldx - nx) ROW[pidx<P>(nx + lane_o)] = 0.0;             // the pitch tail stays zero
         lds_sync();
-        store_row<P>(crow0 + (int64_t)k * ldx, ROW, ldx, lane_o);
+        // one launch per step on 16 points per lane: the rows written are not read again before they have left every cache -> nt
+        // (measured, one GPU's share of configs[3]: 0.597 -> 0.607 of the roofline per step; fused launches re-read them: 0.715 -> 0.664,
+        // and 8 points per lane loses 1.5 %, so only here)
+        if (GL == 2 && A.nsteps == 1) store_row<P, 2>(crow0 + (int64_t)k * ldx, ROW, ldx, lane_o);
+        else store_row<P, ST_AUX_STORE>(crow0 + (int64_t)k * ldx, ROW, ldx, lane_o);
         lds_sync();
         if (ST_TOUCH) asm volatile("" ::"v"(tp0), "v"(tp1));   // the touches of the PREVIOUS iteration retire here
       }
@@ -369,7 +382,8 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
         }
         if (lane_c < ldx - nx) ROW[pidx<P>(nx + lane_c)] = 0.0;
         lds_sync();
-        store_row<P>(lout, ROW, ldx, lane_c);
+        if (GL == 2 && A.nsteps == 1) store_row<P, 2>(lout, ROW, ldx, lane_c);
+        else store_row<P, ST_AUX_STORE>(lout, ROW, ldx, lane_c);
         lds_sync();
         if (!last_step) {   // the next step's lagged charge window from registers: own rows + one DPP hop for the halo
 #pragma unroll

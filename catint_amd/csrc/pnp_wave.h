@@ -118,7 +118,8 @@ __device__ __forceinline__ void load_row(const double* __restrict__ g, double* b
   load_row_commit<P>(rr, buf, lane);
 }
 
-template <int P>
+// AUX: cache-policy bits of the buffer instruction (0 default; 2 = nt: streamed, do not keep)
+template <int P, int AUX = 0>
 __device__ __forceinline__ void store_row(double* __restrict__ g, const double* buf, int ldx, int tid_) {
   const int ls = pidx<P>(2 * tid_);
   const __amdgpu_buffer_rsrc_t r = row_rsrc(g, ldx);
@@ -127,7 +128,7 @@ __device__ __forceinline__ void store_row(double* __restrict__ g, const double* 
     d2 t;
     t.x = buf[pair_slot<P>(ls, it)];
     t.y = buf[pair_slot<P>(ls, it) + PAIR_STEP<P>];
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), r, tid_ * 16 + it * 1024, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), r, tid_ * 16 + it * 1024, 0, AUX);
   }
 }
 
@@ -393,11 +394,11 @@ __device__ __forceinline__ double pick_blocked(const double (&a)[P], int r0, int
 }
 
 // window of P+2 doubles starting at element lane*P of a row (P even: 16-B aligned pieces)
-template <int P>
+template <int P, int AUX = 0>
 __device__ __forceinline__ void load_window(__amdgpu_buffer_rsrc_t r, double (&w)[P + 2], int lane) {
 #pragma unroll
   for (int q = 0; q < (P + 2) / 2; ++q) {
-    const d2 t = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, lane * (P * 8) + q * 16, 0, 0));
+    const d2 t = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, lane * (P * 8) + q * 16, 0, AUX));
     w[2 * q] = t.x;
     w[2 * q + 1] = t.y;
   }
