@@ -532,7 +532,9 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
     const int64_t tpw = 64 / (N + 1);
     const size_t per_block = newton_sweep_doubles(N + 1, nx) * (size_t)tpw * sizeof(double);
     if (!h->sweep) {
-      int64_t blocks = (h->cfg.batch_capacity + tpw - 1) / tpw;
+      // (two teams per operating point: twice the waves for the same batch; the records of a wave are sized for tpw points either way)
+      const int64_t per_wave = (N + 1 >= 6) ? tpw / 2 : tpw;
+      int64_t blocks = (h->cfg.batch_capacity + per_wave - 1) / per_wave;
       if (blocks > 4096) blocks = 4096;
       if (const char* e = getenv("CATINT_NEWTON_SWEEP_BLOCKS")) {      // tests: force several rounds per team
         const int v = atoi(e);

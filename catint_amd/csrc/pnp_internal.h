@@ -152,7 +152,8 @@ int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);
 size_t newton_team_doubles(int nb, int nx);      // row buffer of the lane-team kernel (N >= 5)
 size_t newton_sweep_doubles(int nb, int nx);     // records of one team of the sweep kernel (block Thomas, large batches)
-bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode);   // large blocks and enough lanes to fill the chip with teams (mode: 0 point ions, 1 steric, 2 + reactions)
+bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode);
+bool newton_sweep_two_sided(int nb, int nx, int64_t B, int mode);    // ... with two teams per operating point (elimination from both ends)   // large blocks and enough lanes to fill the chip with teams (mode: 0 point ions, 1 steric, 2 + reactions)
 bool newton_exchange_in_lds(int nb, int nx);
 int newton_pair_threads(int nb, int nx);   // threads of the pair kernel, 0 if the shape does not fit it
 int newton_pair_stride(int nb, int nx);    // its compile-time row stride (256 or 512)

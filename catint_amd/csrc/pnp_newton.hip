@@ -1649,7 +1649,11 @@ struct SweepLayout {
   static constexpr int TPW = 64 / NB;
   static constexpr int SL = ((NB + NB + NB + 1) + 1) / 2 * 2;      // strip: NB scalars + pivot row (NB of D, NB + 1 of X)
   static constexpr int TILE = NB * (NB + 1) + (NB * (NB + 1)) % 2; // [Ut | rt] of the previous row
-  static constexpr int PER_TEAM = SL + TILE + NB + NB % 2;         // + the solution vector of the row below (back-substitution)
+  static constexpr int BASE = SL + TILE + NB + NB % 2;             // + the solution vector of the row below (back-substitution)
+  // The teams of a wave read their tiles / strips at the SAME offset in the same instruction (one broadcast address per team).  LDS
+  // banks repeat every 16 doubles: with a team pitch that is a multiple of 16 (N = 8: 128 doubles) all teams hit the same banks and
+  // every such read is served team after team; a pitch of 2 (mod 16) doubles gives 8 teams disjoint banks even for 16-byte reads.
+  static constexpr int PER_TEAM = BASE + ((2 - BASE % 16) + 16) % 16;
 };
 size_t newton_sweep_doubles(int nb, int nx) { return (size_t)nx * nb * ((nb + 2) / 2 * 2); }
 
@@ -1899,6 +1903,277 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two-sided sweep ("burn at both ends", twisted block factorisation): TWO teams per operating point.  Team 0 eliminates upwards from
+// the wall (rows 0 .. m-1: D'_i = D_i - L_i Ut_{i-1}, [Ut_i | rt_i] = D'_i^-1 [U_i | r_i - L_i rt_{i-1}]), team 1 downwards from the
+// bulk (rows nx-1 .. m+1, the mirror image: D''_i = D_i - U_i Lt_{i+1}, [Lt_i | rt_i] = D''_i^-1 [L_i | r_i - U_i rt_{i+1}]); the
+// middle row m sees both: (D_m - L_m Ut_{m-1} - U_m Lt_{m+1}) x_m = r_m - L_m rt_{m-1} - U_m rt_{m+1}; then both teams substitute
+// outwards (x_i = rt_i - Ut_i x_{i+1} below m, x_i = rt_i - Lt_i x_{i-1} above).  The arithmetic is that of the one-sided sweep (no
+// fill-in, no interface system beyond the one middle block), the dependent chain of a Newton iteration is half as long and a batch
+// occupies twice the waves: for the batch sizes where the one-sided sweep leaves the SIMDs with one or two waves (B ~ 4-16 k at
+// N = 8) that is where the time goes (66 % of a wave's life parked).  Both teams of a pair sit in the same wave
+// and run the same instruction stream; which off-diagonal block is "behind" and which "ahead" is a per-lane select.  Everything
+// else -- assembly, damping, update, stopping rule, wave-uniform iteration engine -- is the one-sided kernel's.
+// ------------------------------------------------------------------------------------------------
+template <int NB, int MODE>
+__global__ __launch_bounds__(64, 2) void newton_sweep2_kernel(const NewtonArgs G) {
+  __shared__ NewtonArgs sA;
+  if (threadIdx.x == 0) sA = G;
+  __syncthreads();
+  using SL_ = SweepLayout<NB>;
+  constexpr int N = NB - 1, NW = SL_::NW, TPW = SL_::TPW, PPW = TPW / 2, NY = NB + 1;
+  constexpr bool MPB = MODE >= 1;
+  __shared__ double sweep_lds[(TPW + 2) * SL_::PER_TEAM];
+  const int lane = threadIdx.x;
+  const int tw = lane / NB;
+  const int r0_ = lane - tw * NB;
+  const bool real_team = tw < 2 * PPW;
+  const int side = tw & 1;            // 0: from the wall upwards, 1: from the bulk downwards
+  double* strip = sweep_lds + (size_t)tw * SL_::PER_TEAM;
+  double* tile = strip + SL_::SL;
+  double* xs = tile + SL_::TILE;
+  const int poff = side ? -SL_::PER_TEAM : SL_::PER_TEAM;      // the partner team's LDS block
+  const int64_t gteam = (int64_t)blockIdx.x * PPW + (real_team ? (tw >> 1) : 0);
+  const int64_t nteams = (int64_t)gridDim.x * PPW;
+  double* W = G.sweep + (size_t)gteam * G.sweep_stride;
+  const bool spec = r0_ < N;
+  const int nx = sA.nx, ldx = sA.ldx;
+  const int m = nx >> 1;              // middle row; team 0 owns rows [0, m), team 1 rows (m, nx)
+  const int n_up = nx - 1 - m;        // rows of team 1 (m or m - 1)
+  int64_t bnext = gteam;
+  int64_t b = 0;
+  bool have = false, fresh = false;
+  int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
+  double upd_prev = INFINITY;
+  for (;;) {      // CONTROL FLOW IS WAVE-UNIFORM, see newton_sweep_kernel
+    if (!have && real_team && bnext < G.B) {
+      b = bnext;
+      bnext += nteams;
+      have = !(G.lane_mask && !G.lane_mask[b]);
+      fresh = true;
+      step = 0;
+      total_it = 0;
+      st = PNP_STATUS_OK;
+    }
+    if (__ballot(have) == 0ull) {
+      if (__ballot(real_team && bnext < G.B) == 0ull) break;
+      continue;
+    }
+    const NewtonArgs& A = sA;
+    double* c = G.c + (size_t)b * N * ldx;
+    double* co = G.c_old + (size_t)b * N * ldx;
+    double* phi = G.phi + (size_t)b * ldx;
+    const double* cb = G.cbulk + (size_t)b * N;
+    const double* wk = G.wk_k + (size_t)b * PNP_MAX_WALL_REACTIONS;
+    const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
+    if (__ballot(have && fresh) != 0ull) {      // previous time level: each team of the pair copies every other stripe
+      for (int e = r0_ + side * NB; e < N * ldx; e += 2 * NB) {
+        const double v = c[e];
+        if (have && fresh) co[e] = v;
+      }
+      team_sync();
+    }
+    if (fresh) {
+      it = 0;
+      upd_prev = INFINITY;
+      fresh = false;
+    }
+    it += 1;
+    // ---- elimination from both ends ---------------------------------------------------------------------------------------------
+    for (int j = 0; j < m; ++j) {
+      int r = r0_;
+      const NewtonArgs* Ap = &sA;
+      asm volatile("" : "+v"(r), "+v"(Ap));
+      const NewtonArgs& A = *Ap;
+      const bool act = side == 0 || j < n_up;                        // (team 1 has one row less when nx is even: it runs along)
+      const int i = side == 0 ? j : nx - 1 - (act ? j : n_up - 1);
+      double Dr[NB], Xr[2 * NB + 1];
+      team_assemble_row<NB, MODE, false>(A, G, c, co, phi, cb, wk, phiM, phiB, b, i, r, spec, strip, Dr, Xr);
+      double Y[NY];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) Y[q] = side ? Xr[q] : Xr[NB + q];      // the block towards the middle
+      Y[NB] = Xr[2 * NB];
+      if (j > 0) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const double lq = side ? Xr[NB + q] : Xr[q];                    // the block towards the end already eliminated
+          const double* prev = tile + q * NY;
+#pragma unroll
+          for (int jj = 0; jj < NB; ++jj) Dr[jj] = __builtin_fma(-lq, prev[jj], Dr[jj]);
+          Y[NB] = __builtin_fma(-lq, prev[NB], Y[NB]);
+        }
+      }
+      team_sync();
+      int myk;
+      team_solve_n<NB, NY, (MODE != 0)>(Dr, Y, strip, r, myk);
+      myk = myk < 0 ? r : myk;
+      double* rec = W + ((size_t)i * NB + myk) * NW;
+#pragma unroll
+      for (int jj = 0; jj < NY; ++jj) {
+        if (act) tile[myk * NY + jj] = Y[jj];
+        if (real_team && act) rec[jj] = Y[jj];
+      }
+      team_sync();
+    }
+    // ---- the middle row: both neighbours eliminated; both teams solve it (same operands, same bits) -----------------------------
+    double mphi = 0.0, upd = 0.0;
+    {
+      int r = r0_;
+      const NewtonArgs* Ap = &sA;
+      asm volatile("" : "+v"(r), "+v"(Ap));
+      const NewtonArgs& A = *Ap;
+      double Dr[NB], Xr[2 * NB + 1];
+      team_assemble_row<NB, MODE, false>(A, G, c, co, phi, cb, wk, phiM, phiB, b, m, r, spec, strip, Dr, Xr);
+      const double* t_lo = side ? tile + poff : tile;       // [Ut | rt] of row m - 1
+      const double* t_hi = side ? tile : tile + poff;       // [Lt | rt] of row m + 1
+      double Y1[1] = {Xr[2 * NB]};
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const double lq = Xr[q], uq = Xr[NB + q];
+        const double* lo = t_lo + q * NY;
+        const double* hi = t_hi + q * NY;
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) Dr[jj] = __builtin_fma(-uq, hi[jj], __builtin_fma(-lq, lo[jj], Dr[jj]));
+        Y1[0] = __builtin_fma(-uq, hi[NB], __builtin_fma(-lq, lo[NB], Y1[0]));
+      }
+      team_sync();
+      int myk;
+      team_solve_n<NB, 1, (MODE != 0)>(Dr, Y1, strip, r, myk);
+      myk = myk < 0 ? r : myk;
+      team_sync();
+      xs[myk] = Y1[0];
+      if (real_team && side == 0) W[((size_t)m * NB + myk) * NW + NB] = Y1[0];
+      team_sync();
+      const double x = xs[r];
+      const double ck = c[(spec ? r : 0) * ldx + m];
+      const double rel = fabs(x) / (fabs(ck) + fabs(cb[spec ? r : 0]) + 1e-300);
+      const double a = fabs(x);
+      if (spec) {
+        upd = fmax(upd, rel);
+        if (!(x == x)) upd = INFINITY;
+      } else {
+        mphi = fmax(mphi, a);
+        if (!(a == a)) mphi = INFINITY;
+      }
+    }
+    // ---- substitution outwards from the middle ------------------------------------------------------------------------------------
+    {
+      const int r = r0_;
+      for (int j = m - 1; j >= 0; --j) {
+        const bool act = side == 0 || j < n_up;
+        const int i = side == 0 ? j : nx - 1 - (act ? j : 0);
+        double* rec = W + ((size_t)i * NB + r) * NW;
+        double x = rec[NB];
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) x = __builtin_fma(-rec[jj], xs[jj], x);
+        team_sync();
+        if (act) xs[r] = x;
+        if (real_team && act) rec[NB] = x;
+        team_sync();
+        const double ck = c[(spec ? r : 0) * ldx + i];
+        const double rel = fabs(x) / (fabs(ck) + fabs(cb[spec ? r : 0]) + 1e-300);
+        const double a = fabs(x);
+        if (act) {
+          if (spec) {
+            upd = fmax(upd, rel);
+            if (!(x == x)) upd = INFINITY;
+          } else {
+            mphi = fmax(mphi, a);
+            if (!(a == a)) mphi = INFINITY;
+          }
+        }
+      }
+    }
+    auto pair_max = [&](double v) {
+      strip[r0_] = v;
+      team_sync();
+      double mm = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) mm = fmax(mm, fmax(strip[jj], strip[poff + jj]));
+      team_sync();
+      return mm;
+    };
+    mphi = pair_max(mphi);
+    upd = pair_max(upd);
+    upd = fmax(upd, mphi * A.vt_inv);
+    double lam = 1.0;
+    if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+    // ---- damping, clips, update: team 0 rows [0, m), team 1 rows [m, nx) ------------------------------------------------------------
+    for (int idx = 0; idx < nx - m; ++idx) {
+      const int r = r0_;
+      const bool act = side ? true : idx < m;
+      const int i = side ? m + idx : (act ? idx : 0);
+      const double du = W[((size_t)i * NB + r) * NW + NB];
+      double cc_ = 0.0, cn = 0.0;
+      if (spec) {
+        cc_ = c[r * ldx + i];
+        const double t_ = __builtin_fma(lam, du, cc_);
+        const double lo = 0.1 * cc_;
+        cn = t_ < lo ? lo : t_;
+      }
+      if constexpr (MPB) {
+        strip[r] = cc_;
+        xs[r] = cn;
+        team_sync();
+        double f_old = 0.0, f_new = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          f_old = __builtin_fma(A.vol[k], strip[k], f_old);
+          f_new = __builtin_fma(A.vol[k], xs[k], f_new);
+        }
+        team_sync();
+        const double free_ = 1.0 - f_old;
+        const double target = fmax(0.1 * free_, 1e-12);
+        if ((1.0 - f_new) < target) {
+          const double theta = (free_ - target) / (f_new - f_old);
+          cn = __builtin_fma(theta, cn - cc_, cc_);
+        }
+      }
+      if (have && act) {
+        if (spec) c[r * ldx + i] = cn;
+        else phi[i] = __builtin_fma(lam, du, phi[i]);
+      }
+    }
+    team_sync();
+    bool finished = false;
+    if (have) {
+      bool accept = false;
+      if (lam == 1.0) {
+        accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol);
+        upd_prev = upd;
+      } else {
+        upd_prev = INFINITY;
+      }
+      if (accept || it >= A.maxit) {
+        total_it += accept ? it : A.maxit + 1;
+        if (!accept) st = PNP_STATUS_MAXIT;
+        step += 1;
+        fresh = true;
+        finished = step >= A.nsteps;
+      }
+    }
+    if (__ballot(finished) != 0ull) {
+      double bad = 0.0;
+      for (int e = r0_; e < nx; e += NB) {
+        double sacc = phi[e];
+#pragma unroll
+        for (int k = 0; k < N; ++k) sacc += c[k * ldx + e];
+        if (!(fabs(sacc) < INFINITY)) bad = 1.0;
+      }
+      strip[r0_] = bad;
+      team_sync();
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) bad = fmax(bad, strip[jj]);
+      if (finished && r0_ == 0 && side == 0) {
+        G.status[b] = bad > 0.0 ? PNP_STATUS_NAN : st;
+        G.iters[b] = total_it;
+      }
+      team_sync();
+    }
+    if (finished) have = false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static constexpr size_t kLdsBudget = 160 * 1024 - 512;
@@ -1999,10 +2274,38 @@ static hipError_t launch_sweep(const NewtonArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// two-sided sweep: one wave per workgroup, (64/NB)/2 operating points per wave
+template <int NB>
+static hipError_t launch_sweep2(const NewtonArgs& a, hipStream_t stream) {
+  constexpr int PPW = SweepLayout<NB>::TPW / 2;
+  int64_t blocks = (a.B + PPW - 1) / PPW;
+  if (blocks > a.sweep_blocks) blocks = a.sweep_blocks;
+  if (a.rt) hipLaunchKernelGGL((newton_sweep2_kernel<NB, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  else if (a.mpb) hipLaunchKernelGGL((newton_sweep2_kernel<NB, 1>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((newton_sweep2_kernel<NB, 0>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+// Two teams per operating point instead of one: when the one-sided sweep would leave the SIMDs with fewer than ~3 waves.
+bool newton_sweep_two_sided(int nb, int nx, int64_t B, int mode) {
+  if (nb < 6 || nx < 8) return false;
+  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 'b';      // "both ends" (tests, probes)
+  // with homogeneous reactions (the 4096-lane CO2R sweep: stationary solves along a continuation, 3...30 iterations per lane) the
+  // lane-team kernel stays ahead: 0.48 s against 0.52 s (one-sided sweep 0.83 s)
+  if (mode >= 2) return false;
+  // measured (tools/probe/sweep2_probe.py, profiles/r02_newton_two_sided_sweep.txt): ahead of both the lane-team kernel and the
+  // one-sided sweep while the latter would have less than one wave per SIMD (N = 8, nx = 512: B = 2048 1.67e5 against 1.37e5 / 0.99e5
+  // timesteps/s, B = 4096 2.77e5 against 1.40e5 / 1.90e5; N = 6, nx = 1024: B = 8192 2.64e5 against 1.07e5 / 2.05e5); level with the
+  // one-sided sweep from two waves per SIMD on, behind it in between (N = 8, B = 8192: 2.72e5 against 3.05e5)
+  const int64_t tpw = 64 / nb;
+  const int64_t waves1 = (B + tpw - 1) / tpw, waves2 = (B + tpw / 2 - 1) / (tpw / 2);
+  return waves1 < 1024 && waves2 >= 512;
+}
+
 // Large blocks and a batch that fills the chip with teams on its own (measured): the sweep kernel.
 bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode) {
-  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 's' && nb >= 3;
-  (void)nx;
+  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return (f[0] == 's' && nb >= 3) || (f[0] == 'b' && nb >= 6 && nx >= 8);
+  if (newton_sweep_two_sided(nb, nx, B, mode)) return true;
   // at least one wave of teams per SIMD (1024 SIMDs): below that the chip is not full and, with uniform control flow, a wave
   // waits for its slowest lane -- the CO2R example (7 species, 4096 lanes, iteration counts 3...30) took 0.84 s instead of 0.51 s
   const int64_t waves = (B + 64 / nb - 1) / (64 / nb);
@@ -2016,7 +2319,12 @@ static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t 
   const char* force = getenv("CATINT_NEWTON_KERNEL");     // "generic" forces the row-per-thread kernel (tests)
   const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
   if constexpr (NB >= 3) {
-    if (a.sweep && a.sweep_blocks > 0 && newton_sweep_preferred(NB, a.nx, a.B, a.rt ? 2 : (a.mpb ? 1 : 0))) return launch_sweep<NB>(a, stream);
+    if (a.sweep && a.sweep_blocks > 0 && newton_sweep_preferred(NB, a.nx, a.B, a.rt ? 2 : (a.mpb ? 1 : 0))) {
+      if constexpr (NB >= 6) {
+        if (newton_sweep_two_sided(NB, a.nx, a.B, a.rt ? 2 : (a.mpb ? 1 : 0))) return launch_sweep2<NB>(a, stream);
+      }
+      return launch_sweep<NB>(a, stream);
+    }
   }
   if constexpr (NB >= 3) {     // lane teams: every large block, and the N = 2..4 grids too long for the pair kernel
     if (a.work && !(force && force[0] == 'g') && (NB >= 6 || tp == 0 || (force && force[0] == 't'))) return launch_team<NB>(a, blocks, stream);

@@ -148,6 +148,44 @@ def test_sweep_kernel(N, nx, blocks, monkeypatch):
     assert_close(got, ref)
 
 
+@pytest.mark.parametrize("N,nx,blocks", [(5, 70, 0), (5, 71, 2), (6, 96, 1), (6, 9, 0), (7, 50, 2), (7, 51, 0), (8, 40, 1), (8, 129, 0)])
+def test_two_sided_sweep_kernel(N, nx, blocks, monkeypatch):
+    # elimination from both ends (two lane teams per operating point, the middle row joins them): even and odd row counts (the upper
+    # team has one row less when nx is even), very short grids, several operating points per pair one after the other
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'both')
+    if blocks:
+        monkeypatch.setenv('CATINT_NEWTON_SWEEP_BLOCKS', str(blocks))
+    kw = {'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * N} if N >= 6 else {}
+    got, ref = run_both(N, nx, B=23, seed=N * 31 + nx, newton_kw=kw)
+    assert_close(got, ref)
+
+
+def test_two_sided_sweep_with_reactions_wall_kinetics_and_transient_steps(monkeypatch):
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'both')
+    rx = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [0, 2, 2], 'rhs': [4, 5], 'kf': 5.0, 'kr': 1e2}]
+    got, ref = run_both(6, 64, B=11, seed=41, reactions=rx, dt=1e-7, nsteps=3, stationary=False)
+    assert_close(got, ref)
+    B = 9
+    rng = np.random.default_rng(3)
+    wk = [{'species': 2, 'k': rng.uniform(0.05, 1.0, B), 'nu': [0.0, 0.0, -1.0, 1.0, 0.0, 0.0], 'alpha': -6.0, 'saturation': 0.05},
+          {'species': -1, 'k': rng.uniform(1e-6, 1e-5, B), 'nu': [0.0, 1.0, 0.0, 0.0, 0.0, 0.0], 'alpha': -4.0}]
+    got, ref = run_both(6, 96, B=B, seed=29, wall_kinetics=wk,
+                        newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, phi_pzc=0.05, mpb_radius=[4.1e-10] + [0.0] * 5))
+    assert_close(got, ref)
+
+
+def test_two_sided_sweep_equals_the_one_sided_sweep(monkeypatch):
+    """Same linear systems, different elimination order: states to rounding, identical iteration counts, lane by lane."""
+    outs = []
+    for kern in ('sweep', 'both'):
+        monkeypatch.setenv('CATINT_NEWTON_KERNEL', kern)
+        got, _ = run_both(8, 128, B=40, seed=5, newton_kw={'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 8})
+        outs.append(got)
+    (c1, p1, it1, st1), (c2, p2, it2, st2) = outs
+    assert np.array_equal(it1, it2) and np.array_equal(st1, st2)
+    assert np.abs(c1 - c2).max() <= 1e-10 * np.abs(c1).max() and np.abs(p1 - p2).max() <= 1e-11
+
+
 def test_sweep_kernel_is_the_default_for_large_batches_of_large_blocks(monkeypatch):
     # N >= 5 species and at least 1024 waves of lane teams (10 operating points per wave at N = 5) take the sweep kernel: same
     # answers and iteration counts as the lane-team kernel
