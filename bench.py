@@ -500,8 +500,8 @@ def main():
         timed loop brings them back up, as the settling loop does for the headline."""
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < seconds:
-            for _ in range(4):
-                solver.step(256, 256)
+            for _ in range(8):                        # (launches of the timed length, like the settling loop: the rocprofv3 --stats
+                solver.step(args.steps, args.steps_per_launch)     # average of the headline kernel stays its per-launch time)
             solver.synchronize()
 
     large = None
