@@ -196,6 +196,17 @@ def test_sweep_kernel_is_the_default_for_large_batches_of_large_blocks(monkeypat
     assert np.abs(a[0] - b[0]).max() <= 1e-9 * np.abs(b[0]).max() and np.abs(a[1] - b[1]).max() <= 1e-10
     assert np.array_equal(a[2], b[2]) and (a[2] <= 50).all()
     assert not np.array_equal(a[0], b[0])            # (two different linear solvers: not the same bits)
+    # half that batch (512 waves of teams one-sided, 1024 waves of team pairs): the two-sided sweep is the default
+    monkeypatch.delenv('CATINT_NEWTON_KERNEL')
+    B2 = 5120
+    a2 = run_gpu_only(N, nx, B2, 6)
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'both')
+    forced = run_gpu_only(N, nx, B2, 6)
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'team')
+    b2 = run_gpu_only(N, nx, B2, 6)
+    assert np.array_equal(a2[0], forced[0]) and np.array_equal(a2[1], forced[1])      # default == forced two-sided, bit for bit
+    assert np.abs(a2[0] - b2[0]).max() <= 1e-9 * np.abs(b2[0]).max() and np.array_equal(a2[2], b2[2])
+    assert not np.array_equal(a2[0], b2[0])
 
 
 @pytest.mark.parametrize("N,nx", [(3, 513), (2, 1030), (3, 1200)])
