@@ -11,6 +11,8 @@ bad = 0
 t0 = time.time()
 for case in range(ncase):
     N = int(rng.integers(1, 9))
+    if os.environ.get('FUZZ_NMIN'):
+        N = int(rng.integers(int(os.environ['FUZZ_NMIN']), 9))
     nx = int(rng.choice([8, 17, 33, 64, 65, 100, 129, 200, 257, 400, 513, 700]))
     B = int(rng.integers(1, 4))
     kw = {}
@@ -30,6 +32,10 @@ for case in range(ncase):
     if rng.random() < 0.4:
         nu = [float(v) for v in rng.choice([-1.0, 0.0, 1.0, 0.5], N)]
         wk = [{'species': int(rng.integers(-1, N)), 'k': rng.uniform(1e-4, 1e-1, B) * (1e-4 if rng.random() < 0.3 else 1.0), 'nu': nu}]
+        if rng.random() < 0.5:          # rate law beyond first order (pnp_set_wall_rate_law)
+            wk[0]['alpha'] = float(rng.uniform(-8, 8))
+            if wk[0]['species'] >= 0 and rng.random() < 0.5:
+                wk[0]['saturation'] = float(rng.uniform(0.0, 0.5))
     flux = rng.uniform(-1e-4, 1e-4, (B, N)) if rng.random() < 0.5 else None
     x = graded_mesh(float(rng.uniform(3, 30)) * nx, 1.0, nx) if rng.random() < 0.4 else None
     stationary = rng.random() < 0.6
