@@ -141,7 +141,7 @@ int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt);
  * stiffness detection); every lane runs it with its own step size, no host round trip per right-hand side.  Defaults (fields left
  * at 0) are scipy's: rtol 1e-6, atol 1e-12, nsteps 500, safety 0.9, ifactor 10, dfactor 0.2, beta 0 (-> 0.04), max_step 0 (-> the
  * interval), first_step 0 (-> HINIT), nstiff 1000. */
-typedef struct {
+typedef struct pnp_ode_params {
   int32_t struct_size;   /* sizeof(pnp_ode_params) */
   int32_t nsteps;        /* NMAX: attempted steps per interval */
   double rtol, atol;
