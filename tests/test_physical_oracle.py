@@ -333,3 +333,33 @@ def test_reaction_source_equals_the_expressions_the_reference_emits():
             ref = eval(tds['R_cp%d' % (k + 1)], {'__builtins__': {}}, env)
             scale = max(abs(ref), max(abs(env['k5r'] * env['ap6'] * env['ap7']), 1e-300) * 1e-3)
             assert abs(R[k, i] - ref) <= 1e-12 * scale, (k, i, R[k, i], ref)
+
+
+def test_newton_solution_is_the_root_an_independent_solver_finds():
+    """The oracle's damped Newton (its own Jacobian, its own block solver) against scipy.optimize.root (MINPACK hybrd with a
+    finite-difference Jacobian) on the same discrete residual: Stern wall, steric ions, a buffer reaction, Butler-Volmer / Langmuir
+    wall kinetics, graded grid, stationary and one backward-Euler step."""
+    from scipy.optimize import root
+    from catint_amd.host import graded_mesh
+    nx = 20
+    dx = 2.5e-10
+    x = graded_mesh(60.0 * nx * dx, dx, nx)
+    wk = [{'species': 2, 'k': 4e-3, 'nu': [0.0, 1.0, -1.0], 'alpha': -9.0, 'saturation': 0.05}]
+    p = PH.PhysicalProblem(D=[1.957e-9, 1.185e-9, 1.91e-9], charges=[F, -F, 0.0], beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=[100.0, 100.0, 34.0],
+                           phiM=-0.35, stern_capacitance=0.2, phi_pzc=0.05, mpb_radius=[4.1e-10, 2e-10, 0.0],
+                           reactions=[{'lhs': [2], 'rhs': [1, 1], 'kf': 3e2, 'kr': 1e-1}], wall_kinetics=wk, x=x)
+    c0 = np.repeat(np.array(p.c_bulk)[:, None], nx, axis=1)
+    for dt in (np.inf, 2e-7):
+        c, phi, it, _ = PH.newton_step(p, c0, np.zeros(nx), c0, dt, tol=1e-12, maxit=80)
+        assert it <= 80
+
+        def fun(u):
+            u = u.reshape(4, nx)
+            return PH.residual(p, u[:3], u[3], c0, dt).reshape(-1)
+        # start the independent solver near (not at) the oracle's answer: hybrd is a local method and the double layer is stiff
+        u0 = np.concatenate([c * (1 + 1e-3 * np.sin(np.arange(nx))), (phi + 1e-4)[None]], 0).reshape(-1)
+        sol = root(fun, u0, method='hybr', tol=1e-13, options={'maxfev': 40000})
+        assert sol.success, sol.message
+        u = sol.x.reshape(4, nx)
+        assert np.abs(u[:3] - c).max() <= 1e-8 * np.abs(c).max() and np.abs(u[3] - phi).max() <= 1e-9
+        assert np.abs(fun(np.concatenate([c, phi[None]], 0).reshape(-1))).max() <= 1e-9 * max(1.0, np.abs(fun(u0)).max())
