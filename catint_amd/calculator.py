@@ -25,6 +25,7 @@ MOL_CALCS = ('odeint', 'lsoda', 'dopri5', 'dop853')   # method of lines: RHS on 
 # physical mode: what run_single_step asks COMSOL for (calculator.py:408-535, comsol_wrapper.py:145,158) solved on the
 # GPU by the fully implicit coupled Newton kernel; 'comsol' is accepted as its name so reference scripts keep working
 PHYSICAL_CALCS = ('comsol', 'Newton')
+DEVICE_ODE_CALCS = ('dopri5', 'dop853')     # explicit Runge-Kutta integrators that run on the device (pnp_ode.hip)
 
 
 class CalculatorError(ValueError):
@@ -142,16 +143,17 @@ class Calculator(object):
         modes = {pb_mode_from_bound(p) for p in pb}
         if len(modes) != 1:
             raise CalculatorError('all lanes of a batch must use the same pb_bound combination')
-        if self.calc in MOL_CALCS and self.calc != 'dopri5':
-            raise CalculatorError("descriptor sweeps along the method of lines run with calc='dopri5' (integrator on the device); "
+        if self.calc in MOL_CALCS and self.calc not in DEVICE_ODE_CALCS:
+            raise CalculatorError("descriptor sweeps along the method of lines run with calc='dopri5' / 'dop853' (integrator on the device); "
                                   "'%s' is driven by scipy, one operating point at a time (integrate_pnp)" % self.calc)
         with self._solver(B, modes.pop(), dx, nx, dt) as s:
             s.set_batch(c0, pb, vzeta, flux)
-            if self.calc == 'dopri5':
-                # every lane its own adaptive DOPRI5 (pnp_integrate_dopri5); output n = state at (n+1) dt (calculator_old.py:959-969);
+            if self.calc in DEVICE_ODE_CALCS:
+                # every lane its own adaptive DOPRI5 / DOP853 (pnp_integrate_dopri5 / _dop853); output n = state at (n+1) dt (calculator_old.py:959-969);
                 # status: 0 ok, 1 = the integrator gave up on the lane (nsteps / step size / stiffness: self.ode_idid)
                 out = [int(n) for n in itout if n < nt]
-                cout, idid, self.ode_stats, _ = s.integrate_dopri5(nt, out, nsteps=10000, **getattr(self, 'ode_options', {}))
+                rk = s.integrate_dopri5 if self.calc == 'dopri5' else s.integrate_dop853
+                cout, idid, self.ode_stats, _ = rk(nt, out, nsteps=10000, **getattr(self, 'ode_options', {}))
                 self.ode_idid = idid
                 status = (idid < 0).astype(np.int32)
             else:
@@ -188,9 +190,10 @@ class Calculator(object):
         pb = tp.pb_array()[None, :]
         with self._solver(1, pb_mode_from_bound(pb[0]), dx, nx, dt) as s:
             s.set_batch(tp.c0[None, :], pb, [tp.system['vzeta']], tp.flux_bound[None, :, 0])
-            if self.calc == 'dopri5' and getattr(self, 'ode_on_device', True):
+            if self.calc in DEVICE_ODE_CALCS and getattr(self, 'ode_on_device', True):
                 out = [n for n in range(nt) if n in tp.itout]
-                cout, idid, stats, t_end = s.integrate_dopri5(nt, out, nsteps=10000, **getattr(self, 'ode_options', {}))
+                rk = s.integrate_dopri5 if self.calc == 'dopri5' else s.integrate_dop853
+                cout, idid, stats, t_end = rk(nt, out, nsteps=10000, **getattr(self, 'ode_options', {}))
                 self.status = 0
                 self.ode_idid, self.ode_stats = int(idid[0]), stats[0].copy()
                 # a failed call ends the reference's loop after appending its result (:959-963): sol stops at that interval

@@ -29,7 +29,8 @@ struct pnp_handle {
   double *pb = nullptr, *vzeta = nullptr, *flux = nullptr, *cbulk = nullptr, *csurf = nullptr;
   double *ytmp = nullptr, *ftmp = nullptr;   // method-of-lines scratch: state in, derivative out
   double* mol_lapl = nullptr;                // ... and its charge row for grids beyond one wave
-  double* ode_buf = nullptr;                 // pnp_integrate_dopri5: k1..k6, y1, ysti ([cap][N][ldx] each) + per-lane reals
+  double* ode_buf = nullptr;                 // pnp_integrate_dopri5 / _dop853: k buffers, y1, ysti ([cap][N][ldx] each) + per-lane reals
+  int ode_nbuf = 0;                          // state-sized buffers in ode_buf (8 DOPRI5, 12 DOP853)
   int32_t* ode_int = nullptr;                // ... per-lane integers + 64 counters
   double* stage = nullptr;                   // upload staging [B][N][nx] (pnp_set_batch)
   SpecConst* spec = nullptr;
@@ -964,28 +965,38 @@ int pnp_mol_rhs(pnp_handle* h, const double* c, double* dcdt) {
   return PNP_OK;
 }
 
-int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
-                         int32_t* idid, int64_t* stats, double* t_end) {
-  if (!h || !p) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: null argument");
-  if (h->newton) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: not part of the physical mode");
-  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_integrate_dopri5: call pnp_set_batch first");
-  if (p->struct_size != (int32_t)sizeof(pnp_ode_params)) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: struct_size mismatch (ABI)");
-  if (nt < 0 || n_out < 0 || (n_out > 0 && (!itout || !cout))) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: bad output request");
+// DOPRI5 (order 5) and DOP853 (order 8) share the call structure: per interval a fresh call (begin, k1, HINIT in the first one),
+// then attempted steps in groups of `every` until the counter of lanes still inside the interval reads zero
+static int integrate_explicit_rk(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
+                                 int32_t* idid, int64_t* stats, double* t_end, int order) {
+  const bool o8 = order == 8;
+  const int nbuf = o8 ? 12 : 8;
+  if (!h || !p) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5 / _dop853: null argument");
+  if (h->newton) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5 / _dop853: not part of the physical mode");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_integrate_dopri5 / _dop853: call pnp_set_batch first");
+  if (p->struct_size != (int32_t)sizeof(pnp_ode_params)) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5 / _dop853: struct_size mismatch (ABI)");
+  if (nt < 0 || n_out < 0 || (n_out > 0 && (!itout || !cout))) return fail(h, PNP_EINVAL, "pnp_integrate_dopri5 / _dop853: bad output request");
   for (int j = 0; j < n_out; ++j)
     if (itout[j] < 0 || itout[j] >= nt || (j > 0 && itout[j] <= itout[j - 1]))
-      return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: itout must be ascending and inside [0, nt)");
+      return fail(h, PNP_EINVAL, "pnp_integrate_dopri5 / _dop853: itout must be ascending and inside [0, nt)");
   if (p->rtol < 0.0 || p->atol < 0.0 || p->first_step < 0.0 || p->max_step < 0.0 || p->nsteps < 0 || p->nstiff < 0)
-    return fail(h, PNP_EINVAL, "pnp_integrate_dopri5: negative parameter");
+    return fail(h, PNP_EINVAL, "pnp_integrate_dopri5 / _dop853: negative parameter");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
   const int64_t B = h->B, cap = h->cfg.batch_capacity;
   const size_t cnt = (size_t)cap * N * ldx;
   hipStream_t st = h->stream;
-  if (!h->ode_buf) {
-    HIP_TRY(h, dev_alloc(h, &h->ode_buf, 8 * cnt + (size_t)cap * ODE_ND));
-    HIP_TRY(h, dev_alloc(h, &h->ode_int, (size_t)cap * ODE_NI + 64));
-    HIP_TRY(h, hipMemsetAsync(h->ode_buf, 0, (8 * cnt + (size_t)cap * ODE_ND) * sizeof(double), st));   // pads of the rows stay zero
+  if (h->ode_buf && h->ode_nbuf < nbuf) {      // a DOPRI5 workspace cannot hold DOP853's twelve buffers
+    HIP_TRY(h, hipStreamSynchronize(st));
+    (void)hipFree(h->ode_buf);
+    h->ode_buf = nullptr;
   }
+  if (!h->ode_buf) {
+    HIP_TRY(h, dev_alloc(h, &h->ode_buf, (size_t)nbuf * cnt + (size_t)cap * ODE_ND));
+    h->ode_nbuf = nbuf;
+    HIP_TRY(h, hipMemsetAsync(h->ode_buf, 0, ((size_t)nbuf * cnt + (size_t)cap * ODE_ND) * sizeof(double), st));   // pads of the rows stay zero
+  }
+  if (!h->ode_int) HIP_TRY(h, dev_alloc(h, &h->ode_int, (size_t)cap * ODE_NI + 64));
   OdeArgs a;
   memset(&a, 0, sizeof(a));
   a.N = N; a.nx = nx; a.ldx = ldx; a.B = B;
@@ -994,17 +1005,20 @@ int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, con
   a.rtol = p->rtol > 0.0 ? p->rtol : 1e-6;
   a.atol = p->atol > 0.0 ? p->atol : 1e-12;
   a.safe = p->safety > 0.0 ? p->safety : 0.9;
-  a.facc1 = 1.0 / (p->dfactor > 0.0 ? p->dfactor : 0.2);
-  a.facc2 = 1.0 / (p->ifactor > 0.0 ? p->ifactor : 10.0);
-  a.beta = p->beta == 0.0 ? 0.04 : (p->beta < 0.0 ? 0.0 : p->beta);     // DOPRI5: WORK(5) = 0 -> 0.04, < 0 -> 0
-  a.expo1 = 0.2 - a.beta * 0.75;
+  // scipy's defaults: dopri5 dfactor 0.2 / ifactor 10 / beta 0 -> DOPRI5's 0.04 (< 0: none); dop853 dfactor 0.3 / ifactor 6 / beta 0
+  a.facc1 = 1.0 / (p->dfactor > 0.0 ? p->dfactor : (o8 ? 0.3 : 0.2));
+  a.facc2 = 1.0 / (p->ifactor > 0.0 ? p->ifactor : (o8 ? 6.0 : 10.0));
+  a.beta = o8 ? (p->beta <= 0.0 ? 0.0 : p->beta) : (p->beta == 0.0 ? 0.04 : (p->beta < 0.0 ? 0.0 : p->beta));
+  a.expo1 = o8 ? 1.0 / 8.0 - a.beta * 0.2 : 0.2 - a.beta * 0.75;
+  a.hinit_expo = o8 ? 1.0 / 8.0 : 1.0 / 5.0;
   a.max_step = p->max_step;
   a.dt = h->a.dt;
   a.y = h->c;
-  for (int j = 0; j < 6; ++j) a.k[j] = h->ode_buf + (size_t)j * cnt;
-  a.y1 = h->ode_buf + 6 * cnt;
-  a.ysti = h->ode_buf + 7 * cnt;
-  a.d = h->ode_buf + 8 * cnt;
+  const int nk = o8 ? 10 : 6;
+  for (int j = 0; j < nk; ++j) a.k[j] = h->ode_buf + (size_t)j * cnt;
+  a.y1 = h->ode_buf + (size_t)nk * cnt;
+  a.ysti = h->ode_buf + (size_t)(nk + 1) * cnt;
+  a.d = h->ode_buf + (size_t)nbuf * cnt;
   a.i = h->ode_int;
   a.counters = h->ode_int + (size_t)cap * ODE_NI;
   {   // t = 0, h = first_step, IDID = 1, counters zero
@@ -1039,15 +1053,28 @@ int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, con
     // a lane needs at most nmax + 1 attempted steps per interval; the counter is read every `every` steps
     for (int64_t tries = 0; left != 0 && tries <= (int64_t)a.nmax + 1; tries += every) {
       for (int e = 0; e < every; ++e) {
-        static const int dst[6] = {1, 2, 3, 4, 5, 1};      // k2..k6, then k7 into k2's buffer
-        for (int sgi = 2; sgi <= 7; ++sgi) {
-          HIP_TRY(h, launch_ode_stage(a, sgi, st));
-          rc = eval_mol_rhs(h, sgi == 6 ? a.ysti : a.y1, a.k[dst[sgi - 2]]);
-          if (rc != PNP_OK) return rc;
-        }
         a.slot = (int32_t)(step++ & 63);
-        HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
-        HIP_TRY(h, launch_ode_control(a, st));
+        if (o8) {
+          for (int sgi = 2; sgi <= 12; ++sgi) {
+            HIP_TRY(h, launch_ode853_stage(a, sgi, st));
+            rc = eval_mol_rhs(h, a.y1, a.k[ode853_stage_dst(sgi)]);
+            if (rc != PNP_OK) return rc;
+          }
+          HIP_TRY(h, launch_ode853_control(a, 0, st));
+          rc = eval_mol_rhs(h, a.ysti, a.k[3]);               // f(new state): CALL FCN(N,XPH,K5,K4) of an accepted step
+          if (rc != PNP_OK) return rc;
+          HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
+          HIP_TRY(h, launch_ode853_control(a, 1, st));
+        } else {
+          static const int dst[6] = {1, 2, 3, 4, 5, 1};      // k2..k6, then k7 into k2's buffer
+          for (int sgi = 2; sgi <= 7; ++sgi) {
+            HIP_TRY(h, launch_ode_stage(a, sgi, st));
+            rc = eval_mol_rhs(h, sgi == 6 ? a.ysti : a.y1, a.k[dst[sgi - 2]]);
+            if (rc != PNP_OK) return rc;
+          }
+          HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
+          HIP_TRY(h, launch_ode_control(a, st));
+        }
       }
       HIP_TRY(h, hipMemcpyAsync(&left, a.counters + a.slot, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(h, hipStreamSynchronize(st));
@@ -1080,6 +1107,16 @@ int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, con
     }
   }
   return PNP_OK;
+}
+
+int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
+                         int32_t* idid, int64_t* stats, double* t_end) {
+  return integrate_explicit_rk(h, p, nt, itout, n_out, cout, idid, stats, t_end, 5);
+}
+
+int pnp_integrate_dop853(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
+                         int32_t* idid, int64_t* stats, double* t_end) {
+  return integrate_explicit_rk(h, p, nt, itout, n_out, cout, idid, stats, t_end, 8);
 }
 
 int pnp_get_state(pnp_handle* h, double* c, double* v, double* grad_v, double* lapl_v) {

@@ -186,18 +186,19 @@ hipError_t launch_scf_keep(const ScfArgs& a, hipStream_t stream);    // converge
 hipError_t launch_scf_post(const ScfArgs& a, hipStream_t stream);    // surface state, accuracy, convergence flags
 
 // ---- method-of-lines integrator on the device (pnp_ode.hip; scipy 'dopri5' = Hairer's DOPRI5, calculator_old.py:955-963) ----
-enum { ODE_X = 0, ODE_H, ODE_XEND, ODE_FACOLD, ODE_HLAMB, ODE_HMAX, ODE_ERR, ODE_HTRY, ODE_DNF, ODE_ND = 10 };
+enum { ODE_X = 0, ODE_H, ODE_XEND, ODE_FACOLD, ODE_HLAMB, ODE_HMAX, ODE_ERR, ODE_HTRY, ODE_DNF, ODE_HNEW, ODE_ND = 10 };
 enum { ODE_ACTIVE = 0, ODE_LAST, ODE_REJECT, ODE_NSTEP, ODE_NACCPT, ODE_IASTI, ODE_NONSTI, ODE_IDID, ODE_INTERVAL,
-       ODE_TOT_NSTEP, ODE_TOT_NACCPT, ODE_TOT_NREJCT, ODE_TOT_NFCN, ODE_NI = 14 };
+       ODE_TOT_NSTEP, ODE_TOT_NACCPT, ODE_TOT_NREJCT, ODE_TOT_NFCN, ODE_PENDING, ODE_NI = 14 };
 struct OdeArgs {
   int32_t N, nx, ldx, nmax;
   int32_t nstiff, slot, interval, pad_;
   int64_t B;
   double rtol, atol, safe, facc1, facc2, beta, expo1, max_step, dt;
+  double hinit_expo;  // HINIT: 1/IORD (1/5 DOPRI5, 1/8 DOP853)
   double* y;          // [B][N][ldx] the state (the handle's c)
-  double* k[6];       // k1..k6; k7 = f(y1) lands in k[1] (a_72 = e_2 = 0)
-  double* y1;         // stage argument / new state
-  double* ysti;       // argument of stage 6 (stiffness detection)
+  double* k[10];      // DOPRI5: k1..k6, k7 = f(y1) lands in k[1] (a_72 = e_2 = 0).  DOP853: k1..k10, k11 -> k[1], k12 -> k[2], f(ynew) -> k[3]
+  double* y1;         // stage argument / (DOPRI5) new state
+  double* ysti;       // DOPRI5: argument of stage 6 (stiffness detection); DOP853: the new state (K5 of dop853.f)
   double* d;          // [B][ODE_ND] per-lane reals
   int32_t* i;         // [B][ODE_NI] per-lane integers
   int32_t* counters;  // [64] lanes still inside the interval after a step (slot = step & 63)
@@ -207,5 +208,10 @@ hipError_t launch_ode_hinit(const OdeArgs& a, int half, hipStream_t stream);
 hipError_t launch_ode_open(const OdeArgs& a, hipStream_t stream);
 hipError_t launch_ode_stage(const OdeArgs& a, int stage, hipStream_t stream);     // stage 2..7
 hipError_t launch_ode_control(const OdeArgs& a, hipStream_t stream);
+// DOP853 (scipy 'dop853'): stage s = 2..12 of dop853.f, then control A (8th-order combination, new state, error estimate, accept /
+// reject + controller), the right-hand side at the new state, control B (stiffness detection, commit, next step)
+hipError_t launch_ode853_stage(const OdeArgs& a, int stage, hipStream_t stream);
+int ode853_stage_dst(int stage);     // k buffer that receives f(stage argument)
+hipError_t launch_ode853_control(const OdeArgs& a, int half, hipStream_t stream);
 
 }  // namespace pnp

@@ -20,6 +20,7 @@
 #include <cmath>
 
 #include "pnp_internal.h"
+#include "pnp_dop853_coeffs.h"
 
 namespace pnp {
 
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(TPB) void ode_begin_kernel(const OdeArgs A) {
   s[ODE_NSTEP] = 0;
   s[ODE_NACCPT] = 0;
   s[ODE_ACTIVE] = 1;
+  s[ODE_PENDING] = 0;
   s[ODE_TOT_NFCN] += 2;
   s[ODE_INTERVAL] = A.interval;
 }
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(TPB) void ode_hinit_b_kernel(const OdeArgs A) {
     const double h = d[ODE_HTRY];
     der2 = sqrt(der2) / h;
     const double der12 = fmax(fabs(der2), sqrt(d[ODE_DNF]));
-    const double h1 = der12 <= 1e-15 ? fmax(1.0e-6, fabs(h) * 1.0e-3) : pow(0.01 / der12, 1.0 / 5.0);
+    const double h1 = der12 <= 1e-15 ? fmax(1.0e-6, fabs(h) * 1.0e-3) : pow(0.01 / der12, A.hinit_expo);
     d[ODE_H] = fmin(fmin(100 * fabs(h), h1), d[ODE_HMAX]);
   }
 }
@@ -306,6 +308,167 @@ __global__ __launch_bounds__(TPB) void ode_control_kernel(const OdeArgs A) {
   if (s[ODE_ACTIVE]) atomicAdd(&A.counters[A.slot], 1);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// DOP853 (scipy's 'dop853' = Hairer's dop853.f, restated and pinned against scipy in oracle/dop853.py): 12 stages of order 8, error
+// estimate from the embedded 5th- and 3rd-order formulas, otherwise DOPRI5's machinery (open_step, HINIT, controller).  Per attempted
+// step: 11 x (stage kernel + right-hand side), control A, the right-hand side at the new state (used only if the step was accepted:
+// the accepted step's k1 of the next one and the stiffness test), control B.
+// ------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void ode853_stage_kernel(const OdeArgs A, const dop853::Stage S) {
+  const int64_t row = blockIdx.x;
+  const int64_t b = row / A.N;
+  if (!A.i[b * ODE_NI + ODE_ACTIVE]) return;
+  const double h = A.d[b * ODE_ND + ODE_H];
+  const size_t base = (size_t)row * A.ldx;
+  double* out = A.y1 + base;
+  const double* y = A.y + base;
+  for (int x = threadIdx.x; x < A.nx; x += TPB) {
+    double v;
+    if (S.n == 1) {
+      v = mul(mul(h, S.coef[0]), A.k[S.buf[0]][base + x]);      // Y+H*A21*K1
+    } else {
+      double acc = mul(S.coef[0], A.k[S.buf[0]][base + x]);
+      for (int j = 1; j < S.n; ++j) acc = add(acc, mul(S.coef[j], A.k[S.buf[j]][base + x]));
+      v = mul(h, acc);
+    }
+    out[x] = add(y[x], v);
+  }
+}
+
+// control A: K4 = sum b_j k_j, new state K5 = y + h K4 (-> ysti), both error norms, decision, controller (dop853.f labels 35 ... 41)
+__global__ __launch_bounds__(TPB) void ode853_control_a_kernel(const OdeArgs A) {
+  __shared__ double red[3 * TPB];
+  const int64_t b = blockIdx.x;
+  double* d = A.d + b * ODE_ND;
+  int32_t* s = A.i + b * ODE_NI;
+  if (!s[ODE_ACTIVE]) return;
+  const double h = d[ODE_H];
+  const size_t base = (size_t)b * A.N * A.ldx;
+  const int n = A.N * A.nx;
+  double err = 0.0, err2 = 0.0, zero = 0.0;
+  for (int e = threadIdx.x; e < n; e += TPB) {
+    const size_t o = base + (size_t)(e / A.nx) * A.ldx + (e % A.nx);
+    double kk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kk[j] = A.k[dop853::kBBuf[j]][o];
+    double k4 = mul(dop853::kB[0], kk[0]);
+    double e5 = mul(dop853::kER[0], kk[0]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      k4 = add(k4, mul(dop853::kB[j], kk[j]));
+      e5 = add(e5, mul(dop853::kER[j], kk[j]));
+    }
+    const double yo = A.y[o];
+    const double k5 = add(yo, mul(h, k4));
+    A.ysti[o] = k5;
+    const double sk = add(A.atol, mul(A.rtol, fmax(fabs(yo), fabs(k5))));
+    // ERRI = K4 - BHH1*K1 - BHH2*K9 - BHH3*K12 (k9 = kk[4], k12 = kk[7])
+    const double e3 = add(add(add(k4, -mul(dop853::kBHH1, kk[0])), -mul(dop853::kBHH2, kk[4])), -mul(dop853::kBHH3, kk[7]));
+    const double q3 = e3 / sk, q5 = e5 / sk;
+    err2 += q3 * q3;
+    err += q5 * q5;
+  }
+  block_sum3(err, err2, zero, red);
+  if (threadIdx.x != 0) return;
+  double deno = err + 0.01 * err2;
+  if (deno <= 0.0) deno = 1.0;
+  err = fabs(h) * err * sqrt(1.0 / (n * deno));
+  d[ODE_ERR] = err;
+  const double fac11 = pow(err, A.expo1);
+  double fac = fac11 / pow(d[ODE_FACOLD], A.beta);
+  fac = fmax(A.facc2, fmin(A.facc1, fac / A.safe));
+  double hnew = h / fac;
+  s[ODE_TOT_NFCN] += 11;
+  if (err <= 1.0) {
+    d[ODE_FACOLD] = fmax(err, 1.0e-4);
+    s[ODE_NACCPT] += 1;
+    s[ODE_TOT_NACCPT] += 1;
+    s[ODE_TOT_NFCN] += 1;          // f(new state), evaluated between the two control kernels
+    d[ODE_HNEW] = hnew;
+    s[ODE_PENDING] = 1;
+  } else {
+    hnew = h / fmin(A.facc1, fac11 / A.safe);
+    s[ODE_REJECT] = 1;
+    if (s[ODE_NACCPT] >= 1) s[ODE_TOT_NREJCT] += 1;
+    s[ODE_LAST] = 0;
+    s[ODE_PENDING] = 0;
+    d[ODE_H] = hnew;
+    open_step(A, b);
+  }
+}
+
+// control B: an accepted step -- stiffness detection with f(new state) in k[3] (K4 of dop853.f) against k12 and the argument of stage
+// 12, commit (k1 <- f(new state), y <- new state), end of the interval or the next step; counts the lanes still inside the interval
+__global__ __launch_bounds__(TPB) void ode853_control_b_kernel(const OdeArgs A) {
+  __shared__ double red[3 * TPB];
+  __shared__ int go_s;
+  const int64_t b = blockIdx.x;
+  double* d = A.d + b * ODE_ND;
+  int32_t* s = A.i + b * ODE_NI;
+  if (!s[ODE_ACTIVE]) return;
+  if (!s[ODE_PENDING]) {       // rejected in control A: the next attempt is already open
+    if (threadIdx.x == 0) atomicAdd(&A.counters[A.slot], 1);
+    return;
+  }
+  const double h = d[ODE_H];
+  const size_t base = (size_t)b * A.N * A.ldx;
+  const int n = A.N * A.nx;
+  const bool stiff_check = (s[ODE_NACCPT] % A.nstiff == 0) || s[ODE_IASTI] > 0;
+  double stnum = 0.0, stden = 0.0, zero = 0.0;
+  if (stiff_check) {
+    for (int e = threadIdx.x; e < n; e += TPB) {
+      const size_t o = base + (size_t)(e / A.nx) * A.ldx + (e % A.nx);
+      const double a = add(A.k[3][o], -A.k[2][o]), c = add(A.ysti[o], -A.y1[o]);
+      stnum += a * a;
+      stden += c * c;
+    }
+  }
+  block_sum3(stnum, stden, zero, red);
+  if (threadIdx.x == 0) {
+    int go = 1;
+    if (stiff_check) {
+      if (stden > 0.0) d[ODE_HLAMB] = fabs(h) * sqrt(stnum / stden);
+      if (d[ODE_HLAMB] > 6.1) {
+        s[ODE_NONSTI] = 0;
+        s[ODE_IASTI] += 1;
+        if (s[ODE_IASTI] == 15) {
+          s[ODE_IDID] = -4;
+          s[ODE_ACTIVE] = 0;
+          go = 0;
+        }
+      } else {
+        s[ODE_NONSTI] += 1;
+        if (s[ODE_NONSTI] == 6) s[ODE_IASTI] = 0;
+      }
+    }
+    s[ODE_PENDING] = 0;
+    go_s = go;
+  }
+  __syncthreads();
+  if (!go_s) return;
+  for (int e = threadIdx.x; e < n; e += TPB) {
+    const size_t o = base + (size_t)(e / A.nx) * A.ldx + (e % A.nx);
+    A.k[0][o] = A.k[3][o];
+    A.y[o] = A.ysti[o];
+  }
+  if (threadIdx.x != 0) return;
+  double hnew = d[ODE_HNEW];
+  d[ODE_X] = add(d[ODE_X], h);
+  if (s[ODE_LAST]) {
+    d[ODE_H] = hnew;
+    s[ODE_IDID] = 1;
+    s[ODE_ACTIVE] = 0;
+    return;
+  }
+  if (fabs(hnew) > d[ODE_HMAX]) hnew = d[ODE_HMAX];
+  if (s[ODE_REJECT]) hnew = fmin(fabs(hnew), fabs(h));
+  s[ODE_REJECT] = 0;
+  d[ODE_H] = hnew;
+  open_step(A, b);
+  if (s[ODE_ACTIVE]) atomicAdd(&A.counters[A.slot], 1);
+}
+
 hipError_t launch_ode_begin(const OdeArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(ode_begin_kernel, dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(TPB), 0, stream, a);
   return hipGetLastError();
@@ -338,6 +501,20 @@ hipError_t launch_ode_stage(const OdeArgs& a, int stage, hipStream_t stream) {
 
 hipError_t launch_ode_control(const OdeArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(ode_control_kernel, dim3((unsigned)a.B), dim3(TPB), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_ode853_stage(const OdeArgs& a, int stage, hipStream_t stream) {
+  if (stage < 2 || stage > 12) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ode853_stage_kernel, dim3((unsigned)(a.B * a.N)), dim3(TPB), 0, stream, a, dop853::kStages[stage - 2]);
+  return hipGetLastError();
+}
+
+int ode853_stage_dst(int stage) { return dop853::kStages[stage - 2].dst; }
+
+hipError_t launch_ode853_control(const OdeArgs& a, int half, hipStream_t stream) {
+  if (half == 0) hipLaunchKernelGGL(ode853_control_a_kernel, dim3((unsigned)a.B), dim3(TPB), 0, stream, a);
+  else hipLaunchKernelGGL(ode853_control_b_kernel, dim3((unsigned)a.B), dim3(TPB), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -157,6 +157,12 @@ typedef struct pnp_ode_params {
  * steps, accepted, rejected, right-hand-side evaluations, interval of the last call; t_end[B] (nullable): time reached. */
 int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
                          int32_t* idid, int64_t* stats, double* t_end);
+/* The same for calc='dop853' (scipy's 'dop853' = Hairer's DOP853: 12 stages of order 8, error estimate from the embedded 5th- and
+ * 3rd-order formulas): same arguments; the defaults are scipy's for this integrator (dfactor 0.3, ifactor 6, no Lund stabilisation).
+ * scipy's build evaluates f(x, y) once more at the start of every step (same operands, same result); that evaluation is not done
+ * and not counted here: stats[3] = 2 per interval + 11 per attempted step + 1 per accepted step. */
+int pnp_integrate_dop853(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
+                         int32_t* idid, int64_t* stats, double* t_end);
 
 /* ---- physical mode (PNP_METHOD_NEWTON) -------------------------------------------------------------- */
 typedef struct pnp_newton_params {

@@ -11,6 +11,7 @@ import pytest
 
 from oracle import pnp_ref as R
 from oracle.dopri5 import Dopri5
+from oracle.dop853 import Dop853
 from catint_amd.host import solver_from_problem
 from catint_amd.calculator import Calculator, make_itout
 from tests.test_host_transport import transport_from_fixture
@@ -32,14 +33,15 @@ def golden_problem(name='dopri5_dd_n2_nx50', interval=1):
     return d, p, c0, nt, itout
 
 
-def oracle_run(s, lane_state, B, lane, nt, **kw):
-    """oracle/dopri5.py on lane `lane` with the device right-hand side (all lanes evaluated, one kept)."""
+def oracle_run(s, lane_state, B, lane, nt, order=5, **kw):
+    """oracle/dopri5.py (order=8: oracle/dop853.py without scipy's redundant evaluation) on lane `lane` with the device right-hand side
+    (all lanes evaluated, one kept)."""
     state = np.array(lane_state, float)
 
     def f(t, y):
         state[lane] = y
         return s.mol_rhs(state)[lane]
-    o = Dopri5(f, **kw).set_initial_value(lane_state[lane].copy())
+    o = (Dopri5(f, **kw) if order == 5 else Dop853(f, recompute_k1=False, **kw)).set_initial_value(lane_state[lane].copy())
     dt = s.dt_ode
     out = []
     for _ in range(nt):
@@ -199,3 +201,70 @@ def test_descriptor_sweep_with_the_integrator_on_the_device():
         v = R.poisson(ref[-1].reshape(tp.nspecies, tp.nx), p, solver='banded')[0]
         if out[-1] == tp.nt - 1:
             assert np.abs(tp.alldata[i]['system']['potential'] - v).max() / max(np.abs(v).max(), 1e-3) < 1e-9
+
+
+@pytest.mark.parametrize('kw', [{}, {'rtol': 1e-9, 'atol': 1e-10}, {'first_step': 1e-11, 'max_step': 4e-10, 'safety': 0.8, 'ifactor': 4.0,
+                                                                       'dfactor': 0.4, 'beta': 0.08}])
+def test_dop853_same_step_sequence_as_the_pinned_oracle(kw):
+    """pnp_integrate_dop853 against oracle/dop853.py (pinned bit for bit against scipy.integrate.ode('dop853')) driving the same device
+    right-hand side: same attempted / accepted / rejected steps and evaluation count, trajectories equal to rounding."""
+    d, p, c0, nt, itout = golden_problem(interval=300)      # 3 ns intervals: the 8th-order method takes long steps
+    nt = 5
+    with solver_from_problem(p, 'FTCS', batch_capacity=1) as s:
+        s.set_batch(c0[None, :], p.pb[None, :], [p.vzeta], p.flux_bound[None, :])
+        o, ref = oracle_run(s, c0[None, :].copy(), 1, 0, nt, order=8, nsteps=10000, **kw)
+        s.set_batch(c0[None, :], p.pb[None, :], [p.vzeta], p.flux_bound[None, :])
+        cout, idid, stats, t_end = s.integrate_dop853(nt, list(range(nt)), nsteps=10000, **kw)
+        c_end = s.get_state()[0]
+    assert idid[0] == 1 and o.idid == 1 and len(o.log) > 2 * nt
+    acc = sum(1 for e in o.log if e[3])
+    assert list(stats[0][:2]) == [len(o.log), acc] and stats[0][3] == o.nfcn and stats[0][4] == nt - 1
+    assert stats[0][3] == 2 * nt + 11 * len(o.log) + acc
+    assert abs(t_end[0] - o.t) <= 1e-13 * o.t
+    for n in range(nt):      # (step sizes differ in the last bits -- tree sums in the norms -- and the steps sit at the stability limit,
+        assert relerr(cout[n, 0], ref[n]) < 1e-9      # where rounding differences are amplified; the integrator's own tolerance is 1e-6)
+    assert np.array_equal(c_end[0].reshape(-1), cout[-1, 0])
+
+
+def test_dop853_against_scipy_lanes_and_failures():
+    """scipy.integrate.ode('dop853') itself driving the device right-hand side (the reference's arrangement) against the device
+    integrator; lanes of a batch are independent (bitwise) and adapt separately; NMAX exit per lane; Calculator(calc='dop853')."""
+    import scipy.integrate as si
+    d, p, c0, nt, itout = golden_problem(interval=300)
+    B, nt = 4, 3
+    rng = np.random.default_rng(5)
+    cs = np.stack([c0 * rng.uniform(0.5, 1.5) for _ in range(B)])
+    pb = np.stack([p.pb] * B); pb[:, 0] = np.linspace(-0.02, 0.05, B)
+    flux = np.stack([p.flux_bound] * B)
+    with solver_from_problem(p, 'FTCS', batch_capacity=B) as s:
+        s.set_batch(cs, pb, [p.vzeta] * B, flux)
+        cout, idid, stats, t_end = s.integrate_dop853(nt, [nt - 1], nsteps=10000)
+        assert (idid == 1).all() and len(set(stats[:, 0])) > 1
+        state = cs.copy()
+
+        def f(t, y):
+            state[2] = y
+            return s.mol_rhs(state)[2]
+        r = si.ode(f).set_integrator('dop853', nsteps=10000)
+        r.set_initial_value(cs[2].copy())
+        for _ in range(nt):
+            r.integrate(r.t + p.dt)
+        assert r.successful() and relerr(cout[0, 2], r.y) < 1e-9
+        s.set_batch(cs, pb, [p.vzeta] * B, flux)
+        c2, idid2, stats2, _ = s.integrate_dop853(nt, [nt - 1], nsteps=2)        # NMAX + 1 = 3 attempted steps, then IDID = -2
+        assert (idid2 == -2).all() and (stats2[:, 0] == 3).all() and (stats2[:, 4] == 0).all()
+    with solver_from_problem(p, 'FTCS', batch_capacity=1) as s1:
+        s1.set_batch(cs[2:3], pb[2:3], [p.vzeta], flux[2:3])
+        c1, _, st1, _ = s1.integrate_dop853(nt, [nt - 1], nsteps=10000)
+    assert np.array_equal(c1[0, 0], cout[0, 2]) and np.array_equal(st1[0], stats[2])
+    # the Calculator seam: calc='dop853' integrates on the device, ode_on_device=False hands the same RHS to scipy
+    tp = transport_from_fixture(d)
+    tp.c0 = d['c0'].copy(); tp.flux_bound = d['flux_bound'].copy(); tp.system['vzeta'] = float(d['vzeta'])
+    outs = []
+    for on_device in (True, False):
+        calc = Calculator(transport=tp, calc='dop853', dt=float(d['dt']), tmax=float(d['tmax']), ntout=2)
+        calc.ode_on_device = on_device
+        outs.append(calc.integrate_pnp(tp.dx, tp.nx, tp.dt, tp.nt, tp.ntout, 'dop853'))
+    assert len(outs[0]) == len(outs[1]) > 0
+    for a, b in zip(*outs):
+        assert relerr(a, b) < 1e-9

@@ -8,6 +8,7 @@ import pytest
 import scipy.integrate as si
 
 from oracle.dopri5 import Dopri5
+from oracle.dop853 import Dop853
 
 
 def logged(fun):
@@ -79,3 +80,45 @@ def test_step_size_is_carried_between_calls_but_the_controller_memory_is_not():
     # second call: one evaluation for k1 (no HINIT), first attempted step = the carried prediction
     assert calls[n1] == 0.7 and o.log[nlog][1] == h_carried and h_carried < 0.7
     assert (len(calls) - n1 - 1) % 6 == 0
+
+
+@pytest.mark.parametrize('fun,y0,dt,nt,kw', [
+    (oscillator, [1.0, 0.0, 0.3], 0.7, 30, {}),
+    (oscillator, [1.0, 0.0, 0.3], 0.05, 40, {'rtol': 1e-9, 'atol': 1e-10}),
+    (diffusion, list(np.sin(np.linspace(0, np.pi, 24)) ** 2), 0.01, 25, {}),
+    (diffusion, list(np.sin(np.linspace(0, np.pi, 24)) ** 2), 0.01, 10, {'first_step': 1e-4, 'max_step': 2e-3, 'safety': 0.8, 'ifactor': 5.0,
+                                                                         'dfactor': 0.3, 'beta': 0.08}),
+])
+def test_dop853_restatement_equals_scipy_bit_for_bit(fun, y0, dt, nt, kw):
+    """oracle/dop853.py against scipy.integrate.ode('dop853'): same evaluation times (including scipy's redundant f(x, y) at the start
+    of every step), same trajectory, rejected steps included."""
+    f, ca = logged(fun)
+    g, cb = logged(fun)
+    r = si.ode(f).set_integrator('dop853', nsteps=10000, **kw)
+    r.set_initial_value(y0)
+    o = Dop853(g, nsteps=10000, **kw).set_initial_value(y0)
+    for _ in range(nt):
+        a = r.integrate(r.t + dt)
+        b = o.integrate(o.t + dt)
+        assert np.array_equal(a, b) and r.t == o.t
+    assert np.array_equal(ca, cb)
+    # without the redundant evaluation (what the device integrator does): the same trajectory, one evaluation less per attempted step
+    g2, cc = logged(fun)
+    o2 = Dop853(g2, nsteps=10000, recompute_k1=False, **kw).set_initial_value(y0)
+    for _ in range(nt):
+        b2 = o2.integrate(o2.t + dt)
+    assert np.array_equal(b2, b) and len(cc) == len(cb) - len(o.log) and len(o2.log) == len(o.log)
+    assert len(cc) == o2.nfcn - nt + (0 if kw.get('first_step') else 1)
+
+
+@pytest.mark.parametrize('nsteps,idid,msg', [(100000, -4, 'stiff'), (50, -2, 'larger nsteps')])
+def test_dop853_failure_exits_match_scipy(nsteps, idid, msg):
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        r = si.ode(stiff).set_integrator('dop853', nsteps=nsteps)
+        r.set_initial_value([1.0, 1.0])
+        a = r.integrate(5.0)
+    assert not r.successful() and msg in str(w[0].message)
+    o = Dop853(stiff, nsteps=nsteps).set_initial_value([1.0, 1.0])
+    b = o.integrate(5.0)
+    assert o.idid == idid and o.t == r.t and np.array_equal(a, b)
