@@ -562,7 +562,7 @@ __device__ __forceinline__ double wave_max(double v) {
 // History: an early version of this kernel (ping-pong PCR through LDS / device memory) gave run-to-run different results when
 // built for 512 registers; the present one (in-place cyclic reduction) does not -- its 512-register builds (256 VGPRs + 74...166
 // accumulator registers as spill space, no scratch) are bitwise reproducible, equal to the 256-register builds bit for bit and
-// unchanged under -ftrivial-auto-var-init=zero / =pattern (no uninitialised local reaches a result; tools/probe/trap_repro.py,
+// unchanged under -ftrivial-auto-var-init=zero / =pattern (no uninitialised local reaches a result; tests/fuzz/trap_repro.py,
 // gpurun_out/trap_repro.txt).  The register budget is an occupancy choice, not a correctness requirement; both builds of
 // NB = 6, 7 are kept and compared by tests/test_gpu_newton.py::test_register_budget_does_not_change_results.
 template <int NB, int TMAX, int MODE>
