@@ -164,13 +164,13 @@ def test_method_of_lines_rhs_on_grids_beyond_one_wave(nx, pbv, lf):
 
 
 def test_randomised_compat_configurations_follow_the_oracle():
-    """tools/probe/fuzz_compat.py at test size: random species counts (1..16), grid lengths (5..4098), Poisson branches, CN/FTCS,
+    """tests/fuzz/fuzz_compat.py at test size: random species counts (1..16), grid lengths (5..4098), Poisson branches, CN/FTCS,
     --LF, migration off, fluxes, fused and per-step launches against the C oracle (rtol 1e-9)."""
     import os
     import subprocess
     import sys
     env = dict(os.environ, FUZZ_SEED='5', FUZZ_CASES='40')
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), '..', 'tools', 'probe', 'fuzz_compat.py')], env=env,
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'fuzz', 'fuzz_compat.py')], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert '40 cases, 0 bad' in r.stdout, r.stdout[-3000:]

@@ -483,12 +483,12 @@ def test_surface_observables():
 
 
 def test_randomised_configurations_follow_the_oracle():
-    """tools/probe/fuzz_newton.py at test size: random species counts, grids, boundary models, reactions, kinetics, fluxes,
+    """tests/fuzz/fuzz_newton.py at test size: random species counts, grids, boundary models, reactions, kinetics, fluxes,
     stationary or transient -- converged lanes equal the oracle, every lane takes the oracle's number of Newton iterations."""
     import subprocess
     import sys
     env = dict(os.environ, FUZZ_SEED='3', FUZZ_CASES='30')
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), '..', 'tools', 'probe', 'fuzz_newton.py')], env=env,
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'fuzz', 'fuzz_newton.py')], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert '30 cases, 0 bad' in r.stdout, r.stdout[-3000:]
