@@ -70,6 +70,43 @@ def test_config5_share_physical_mode_sweep_kernel_8192_lanes():
     assert np.abs(full[0][1] - rc).max() <= 2e-9 * np.abs(rc).max() and np.abs(full[1][1] - rphi).max() <= 2e-9 * 0.2
 
 
+def test_half_size_batch_of_large_blocks_takes_the_two_sided_sweep():
+    """4096 lanes x 8 size-modified species x 512 points (585 waves of lane teams one-sided, 1366 waves of team pairs): the library's
+    choice is the two-sided sweep -- lane permutation property, sampled lanes against the oracle incl. iteration counts, and the
+    same lanes through the one-sided sweep."""
+    B, N, nx = 4096, 8, 512
+    prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=18, phi_max=0.2, dt_factor=0.1)
+    pb = np.nan_to_num(pb)
+    kw = dict(wall_bc='stern', stern_capacitance=0.2, tol=1e-9, mpb_radius=RADII8)
+
+    def solve(idx, steps):
+        with _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton',
+                             batch_capacity=len(idx)) as s:
+            s.set_newton(**kw)
+            s.set_batch(c0[idx], pb[idx], vz[idx], fl[idx])
+            s.step(steps)
+            cs, vs, es = s.get_surface()
+            return cs, vs, s.newton_iterations(), s.get_status()
+
+    cs, vs, its, st = solve(np.arange(B), 3)
+    assert np.all(st == 0) and cs.min() > 0 and its.min() >= 6
+    perm = np.random.default_rng(4).permutation(B)
+    cs2, vs2, its2, st2 = solve(perm, 3)
+    assert np.array_equal(its2, its[perm]) and np.array_equal(cs2, cs[perm]) and np.array_equal(vs2, vs[perm])
+    for b in (0, 777, 4095):
+        p = PH.PhysicalProblem(D=prob.D, charges=prob.charges, beta=prob.beta, eps=prob.eps, dx=prob.dx, nx=nx,
+                               c_bulk=c0[b].reshape(N, nx)[:, -1], phiM=pb[b, 0], stern_capacitance=0.2, mpb_radius=RADII8)
+        rc, rphi, rit = PH.integrate(p, c0[b].reshape(N, nx), np.zeros(nx), prob.dt, 3, tol=1e-9)
+        assert sum(rit) == its[b], (b, rit, its[b])
+        assert np.abs(cs[b] - rc[:, 0]).max() <= 2e-9 * np.abs(rc).max() and abs(vs[b] - rphi[0]) <= 2e-9 * 0.2
+    os.environ['CATINT_NEWTON_KERNEL'] = 'sweep'
+    try:
+        cs1, vs1, its1, st1 = solve(np.arange(B), 3)
+    finally:
+        del os.environ['CATINT_NEWTON_KERNEL']
+    assert np.array_equal(its1, its) and np.abs(cs1 - cs).max() <= 1e-10 * np.abs(cs).max() and not np.array_equal(cs1, cs)
+
+
 def test_config5_share_compat_mode_8192_lanes():
     B, N, nx = 8192, 8, 4096
     p, c0, pb, vz, fl = make_batch(B, N, nx, seed=9, phi_max=0.02, dt_factor=1e-4)
