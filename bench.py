@@ -404,9 +404,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # the cpu_baseline leg's checker library: loaded (and, if stale, rebuilt by `make`) BEFORE this process initialises the GPU --
+    # no child process may be started afterwards on the GPU box
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle as _co
+        _co.load()
     # counters first: the child processes must be started before this process initialises the GPU
     pmc = {'error': 'skipped'}
-    if rank == 0 and world == 1 and not args.no_pmc:
+    # (not when this process is itself being profiled -- `rocprofv3 ... -- python3 bench.py`: the profiler's preloaded library has
+    # initialised the GPU already, starting child processes from here is off limits on the GPU box, and nested profilers collide)
+    profiled = any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
+    if profiled:
+        pmc = {'error': 'this process runs under rocprofv3: no nested counter collection'}
+    elif rank == 0 and world == 1 and not args.no_pmc:
         pmc = collect_pmc(args)
     import torch
     dist = None

@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_sessionstart(session):
+    """The checker library (C oracle) is built by `make` when it is missing or stale.  Do that now, before any test initialises the
+    GPU: on the GPU box a process that has touched the GPU must not start child processes.  (The product library is never built from
+    here: __graft_entry__.build() does that; catint_amd._capi fails loudly if it is missing.)"""
+    try:
+        from oracle import c_oracle
+        c_oracle.load()
+    except Exception as e:      # no compiler: the tests that need the C oracle will say so themselves
+        sys.stderr.write('conftest: C oracle not available (%s)\n' % e)
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
