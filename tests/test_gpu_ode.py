@@ -268,3 +268,15 @@ def test_dop853_against_scipy_lanes_and_failures():
     assert len(outs[0]) == len(outs[1]) > 0
     for a, b in zip(*outs):
         assert relerr(a, b) < 1e-9
+
+
+@pytest.mark.parametrize('calc', ['dopri5', 'dop853'])
+def test_adaptive_sweep_example_runs(calc):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('mol_adaptive_sweep', os.path.join(os.path.dirname(GOLDEN), '..', 'examples', 'mol_adaptive_sweep.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(['--lanes', '9', '--calc', calc, '--tmax', '2e-9'])
+    assert (out['idid'] == 1).all() and out['stats'][:, 0].min() >= 4
+    k = out['surface_K']
+    assert np.all(np.diff(k) < 0) and k[0] > 30.0 > k[-1]       # cations pile up at negative wall potentials, deplete at positive ones
