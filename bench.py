@@ -382,6 +382,19 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
                 roof['hbm_bytes_per_lane_iteration'] = roof['hbm_bytes_per_launch'] / max(it2, 1.0)
             rec['roofline'] = roof
         out['large_batch_8_species'] = rec
+        # half that batch: the two-sided sweep (two lane teams per operating point) is the library's choice
+        s8, inp = newton_solver(SB // 2, 8, 512, 4445, device, steric=True)
+        s8.set_batch(*inp[1:])
+        s8.step(1)
+        s8.synchronize()
+        warm()
+        ms4 = timed_steps(s8, 4, 0)
+        it4 = s8.newton_iterations()
+        ok4 = int((s8.get_status() == 0).sum())
+        s8.close()
+        out['mid_batch_8_species'] = {'workload': 'batch=%d, 8 species size-modified, 512 points, Stern wall (two-sided sweep kernel)' % (SB // 2),
+                                      'timesteps_per_s': (SB // 2) * 4 / (ms4 * 1e-3), 'newton_iterations_per_s': float(it4.sum()) / (ms4 * 1e-3),
+                                      'lanes_ok': ok4}
     except Exception as e:
         out['large_batch_8_species'] = {'error': str(e)}
     if with_cpu:
