@@ -42,6 +42,17 @@ for case in range(ncase):
     c0 = np.repeat(cb[:, :, None], nx, axis=2) * rng.uniform(0.9, 1.1, (B, N, nx))
     p = R.Problem(D=D, charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, dt=dt, pb=pbv[0], vzeta=float(vz[0]), flux_bound=fl[0],
                   lax_friedrich=lf, use_migration=mig)
+    if os.environ.get('FUZZ_ONLY') and case != int(os.environ['FUZZ_ONLY']):
+        continue
+    if os.environ.get('FUZZ_GROWTH'):       # one case, error against the oracle step by step: rounding amplification or a discrepancy?
+        for ns in (1, 2, 3, 5, 8, nsteps):
+            with solver_from_problem(p, method, batch_capacity=B) as s:
+                s.set_batch(c0.reshape(B, N * nx), pbv, vz, fl)
+                s.step(ns, spl)
+                c = s.get_state()[0]
+            ref = np.ascontiguousarray(c0.copy())
+            CO.steps(p, method, ref, pbv, vz, fl, ns)
+            print('  steps %2d: max rel diff %.2e   (max |c| %.3e, dt %.2e, dx %.2e)' % (ns, np.abs(c - ref).max() / np.abs(ref).max(), np.abs(ref).max(), dt, dx))
     try:
         with solver_from_problem(p, method, batch_capacity=B) as s:
             s.set_batch(c0.reshape(B, N * nx), pbv, vz, fl)
