@@ -509,6 +509,28 @@ class Calculator(object):
             phiM[i] = system['phiM']
         return pb, vz, phiM
 
+    def initialize_surface_concentrations_from_file(self, fname, desc=None):
+        """calculator.py:242-258: start the SCF loop from the surface concentrations of an earlier results folder (nine pickles,
+        results_io.save_all; same descriptor list).  desc = a phiM value: that descriptor point's surface state becomes
+        tp.species[sp]['surface_concentration'] -- the reference's behaviour, every lane starts there.  desc = None (batched
+        extension): every lane starts from ITS OWN descriptor point of the folder."""
+        from .results_io import read_all
+        tp = self.tp
+        holder = type('_Holder', (), {})()
+        read_all(holder, fname, only=['alldata'])
+        names = list(tp.species.keys())
+        if desc is not None:
+            inx = list(tp.descriptors['phiM']).index(desc)
+            for sp in names:
+                tp.species[sp]['surface_concentration'] = float(holder.alldata[inx]['species'][sp]['surface_concentration'])
+            self.surface_init = None
+        else:
+            if len(holder.alldata) != len(tp.alldata_names):
+                raise CalculatorError('initialize_surface_concentrations_from_file: %d descriptor points in %s, %d here'
+                                      % (len(holder.alldata), fname, len(tp.alldata_names)))
+            self.surface_init = np.array([[float(holder.alldata[i]['species'][sp]['surface_concentration']) for sp in names]
+                                          for i in range(len(tp.alldata_names))])
+
     def run_scf_cycle(self, flux_callback=None, nel=None, nprod=None, max_iter=1000, transport_fn=None, label=''):
         """Batched counterpart of the reference's SCF outer loop (catint/calculator.py:294-406): kinetics
         (`flux_callback`, the seam where CatMAP sat, catmap_wrapper.py:106) <-> transport, once per iteration, for
@@ -546,7 +568,13 @@ class Calculator(object):
         B = len(phiM)
         nel = np.ones(N) if nel is None else np.asarray(nel, float)
         nprod = np.ones(N) if nprod is None else np.asarray(nprod, float)
+        if tp.system.get('init_folder') is not None:       # calculator.py:303-309: surface state of a COMSOL(-layout) results folder
+            from .results_io import read_surface_concentrations
+            for sp, v in zip(names, read_surface_concentrations(tp, tp.system['init_folder'])):
+                tp.species[sp]['surface_concentration'] = float(v)
         sc = np.repeat(np.array([[tp.species[sp]['surface_concentration'] for sp in names]], float), B, axis=0)
+        if getattr(self, 'surface_init', None) is not None:      # per-lane start (initialize_surface_concentrations_from_file)
+            sc = np.array(self.surface_init, float).reshape(B, N)
         flux = np.repeat(tp.flux_bound[None, :, 0], B, axis=0).astype(float)
         mix = np.full(B, float(self.mix_scf))
         acc = np.full(B, np.inf)

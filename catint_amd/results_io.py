@@ -106,3 +106,34 @@ def export_comsol_text(tp, index, folder, par_name='flux_factor', par_value=1.0)
     _comsol_table(os.path.join(folder, 'electrode_flux.txt'), [0.0, float(x[-1])], [[f, 0.0] for f in flux],
                   ['j%d' % (k + 1) for k in range(len(names))], ['mol/m^2/s'] * len(names), par_name, par_value, 2, 'Electrode flux')
     return folder
+
+
+def read_comsol_text(path):
+    """One COMSOL text table (the layout _comsol_table writes and the reference's comsol_reader.py:125-196 parses): comment lines start
+    with '%', the last of them names the columns `<variable> (<unit>) @ <parameter>=<value>`; rows are `x value value ...`.
+    Returns (x [n], {variable: column [n]})."""
+    names, rows = [], []
+    with open(path) as f:
+        header = None
+        for line in f:
+            if line.startswith('%'):
+                header = line
+                continue
+            vals = line.split()
+            if vals:
+                rows.append([float(v) for v in vals])
+    if header is not None:
+        import re
+        names = re.findall(r'([A-Za-z_][\w.]*)\s*\([^)]*\)\s*@', header)
+    a = np.array(rows, float)
+    if a.ndim != 2 or a.shape[1] != len(names) + 1:
+        raise ValueError('%s: %d data columns for the variables %s' % (path, a.shape[1] - 1 if a.ndim == 2 else 0, names))
+    return a[:, 0], {n: a[:, j + 1] for j, n in enumerate(names)}
+
+
+def read_surface_concentrations(tp, folder):
+    """Surface concentrations c_k(x = 0) [N] from the concentrations.txt of a COMSOL(-layout) results folder -- what the reference's
+    system['init_folder'] start-up takes from comsol_reader.Reader.read_all (calculator.py:303-309)."""
+    x, cols = read_comsol_text(os.path.join(folder, 'concentrations.txt'))
+    names = list(tp.species.keys())
+    return np.array([cols['cp%d' % (k + 1)][0] for k in range(len(names))])
