@@ -260,10 +260,11 @@ class Calculator(object):
                 raise CalculatorError('surface kinetics: saturation needs a species')
         self.surface_kinetics = list(reactions)
 
-    def _apply_surface_kinetics(self, solver, phiM):
+    def _apply_surface_kinetics(self, solver, phiM, lanes=None):
         rx = getattr(self, 'surface_kinetics', None)
         if not rx:
             return
+        del lanes      # (rate functions take the lanes' potentials; nothing else is per lane)
         names = list(self.tp.species.keys())
         species = [names.index(r['species']) if r.get('species') is not None else -1 for r in rx]
         nu = np.zeros((len(rx), len(names)))
@@ -335,6 +336,38 @@ class Calculator(object):
                 return st
         nst = max(int(nramp), int(np.ceil(span / nk.get('dphi_stage', 0.2))))
         self.continuation_stages = nst
+        st = self._continuation(solver, c0, pb, vz, flux, phiM, start, nst)
+        # Lanes that still fail: the reference reruns COMSOL up to 25 times with a load / non-linearity ramp half as coarse each time
+        # (and a finer boundary mesh, which a handle cannot change: refine with tp.set_graded_mesh) -- calculator.py:455-531.  Here
+        # only the failed lanes walk the path again, as a batch of their own, with 2, 4, 8 x the stages; what converges is patched
+        # into the state of the main handle.
+        self.retry_log = []
+        rungs = int(nk.get('retry_rungs', 3))
+        for rung in range(1, rungs + 1):
+            bad = np.flatnonzero(st != 0)
+            if len(bad) == 0:
+                break
+            with self._physical_solver(len(bad)) as sub:
+                st_sub = self._continuation(sub, np.asarray(c0)[bad], pb[bad], vz[bad], np.asarray(flux)[bad], phiM[bad], start, nst * 2 ** rung,
+                                            lanes=bad)
+                c_sub, phi_sub = sub.get_state()[:2]
+            good = st_sub == 0
+            self.retry_log.append({'rung': rung, 'stages': nst * 2 ** rung, 'lanes': bad.tolist(), 'recovered': bad[good].tolist()})
+            if good.any():
+                c_all, phi_all = solver.get_state()[:2]
+                c_all[bad[good]] = c_sub[good]
+                phi_all[bad[good]] = phi_sub[good]
+                solver.set_batch(c_all.reshape(B, -1), pb, vz, flux)
+                solver.set_potential(phi_all)
+                self._apply_surface_kinetics(solver, phiM)
+                st = st.copy()
+                st[bad[good]] = 0
+        return st
+
+    def _continuation(self, solver, c0, pb, vz, flux, phiM, start, nst, lanes=None):
+        """nst stages from the uncharged interface to the operating point (wall potential, prescribed fluxes, rate constants), each
+        warm-started from the previous one; lanes: indices of these lanes in the full batch (per-lane rate constants)."""
+        st = None
         for j in range(1, nst + 1):
             w = j / float(nst)
             pbj = pb.copy(); pbj[:, 0] = start + (phiM - start) * w
@@ -343,7 +376,7 @@ class Calculator(object):
             else:
                 solver.set_pb(pbj, vz)
                 solver.set_flux(flux * w)
-            self._apply_surface_kinetics(solver, pbj[:, 0])
+            self._apply_surface_kinetics(solver, pbj[:, 0], lanes=lanes)
             st = solver.solve_stationary()
         return st
 
@@ -364,6 +397,9 @@ class Calculator(object):
             tp.alldata = [{'species': {}, 'system': {}}]
             # symbolic fluxes ('catmap', equations: transport.py:938-947) carry no number of their own -- the kinetics callback /
             # the implicit wall kinetics supply it; the prescribed part is zero
+            if self.flux_sign_error():        # calculator.py:435-442
+                self.change_flux_sign()
+                self.flux_signs_changed = True
             tp.flux_bound[:, 0] = [0.0 if isinstance(tp.species[sp].get('flux', 0.0), str) else float(tp.species[sp].get('flux', 0.0))
                                    for sp in tp.species]
             self.run()
@@ -375,6 +411,47 @@ class Calculator(object):
         tp.system.update({k: v for k, v in d['system'].items() if k not in keys and k != 'status'})
         self.last_label = label
         return int(np.atleast_1d(self.status)[0]) == 0
+
+    def flux_sign_error(self):
+        """err_in_flux of the reference's run_single_step (calculator.py:415-432): an educt of an electrode reaction with a flux that
+        is not negative, or a product with a positive flux whose sign is not +1 (never true -- kept as written).  Species in
+        system['exclude species'] other than H+ / OH- are skipped; symbolic fluxes (strings) count as zero."""
+        tp = self.tp
+        excl = tp.system.get('exclude species', [])
+
+        def num(sp):
+            f = tp.species[sp].get('flux', 0.0)
+            return 0.0 if isinstance(f, str) else float(f)
+        error = False
+        for name in getattr(tp, 'electrode_reactions', {}) or {}:
+            educts, products = tp.electrode_reactions[name]['reaction'][0], tp.electrode_reactions[name]['reaction'][1]
+            for educt in educts:
+                if (educt in excl and educt not in ['H+', 'OH-']) or educt not in tp.species:
+                    continue
+                if num(educt) != 0.0 and num(educt) / abs(num(educt)) != -1:
+                    error = True
+            for prod in products:
+                if (prod in excl and prod not in ['H+', 'OH-']) or prod not in tp.species:
+                    continue
+                if num(prod) > 0.0 and num(prod) / abs(num(prod)) != 1:
+                    error = True
+        return error
+
+    def change_flux_sign(self):
+        """change_flux_sign (calculator.py:433-446): every educt and product of the electrode reactions (outside the excluded species)
+        gets the opposite flux, each species once."""
+        tp = self.tp
+        excl = tp.system.get('exclude species', [])
+        done = []
+        for name in getattr(tp, 'electrode_reactions', {}) or {}:
+            for side in (0, 1):
+                for sp in tp.electrode_reactions[name]['reaction'][side]:
+                    if sp in excl or sp in done or sp not in tp.species:
+                        continue
+                    f = tp.species[sp].get('flux', 0.0)
+                    if not isinstance(f, str):
+                        tp.species[sp]['flux'] = -1.0 * f
+                    done.append(sp)
 
     # ------------------------------------------------------------------------------------------
     def run(self):

@@ -485,3 +485,33 @@ def test_gpu_sweep_results_folder_matches_the_reference_reader_manifest(tmp_path
     names = list(tp.species.keys())
     j = calc.kinetic_flux[:, names.index('CO')]
     assert np.allclose([tp.alldata[i]['species']['CO']['electrode_current_density'] for i in range(3)], j * 2 * 96485.33289 / 1 / 10.)
+
+
+def test_failed_lanes_recover_on_a_finer_ramp():
+    """The per-lane convergence ladder of solve_physical (the reference's rerun-with-half-the-ramp loop, calculator.py:455-531): with a
+    Newton budget too small for the default stages the far lanes fail; they walk 2, 4, ... x the stages as their own batch, converge,
+    and end on the same state as a run that was given enough iterations in the first place."""
+    phis = [-0.4, -0.9, -1.5, -1.9]
+    ref_tp = _physical_transport(phis)
+    ref = Calculator(transport=ref_tp, calc='comsol')
+    ref.run()
+    assert np.all(ref.status == 0) and not ref.retry_log
+    tp = _physical_transport(phis)
+    tp.newton = {'maxit': 4, 'dphi_stage': 0.5, 'retry_rungs': 4}
+    calc = Calculator(transport=tp, calc='comsol')
+    calc.run()
+    assert calc.retry_log and calc.retry_log[0]['lanes'], calc.retry_log
+    assert np.all(calc.status == 0), (calc.status, calc.retry_log)
+    recovered = sorted(set(sum((r['recovered'] for r in calc.retry_log), [])))
+    assert recovered == sorted(calc.retry_log[0]['lanes'])
+    for i in range(len(phis)):
+        a = np.array([tp.alldata[i]['species'][sp]['concentration'] for sp in tp.species])
+        b = np.array([ref_tp.alldata[i]['species'][sp]['concentration'] for sp in ref_tp.species])
+        assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max()
+        assert np.abs(np.array(tp.alldata[i]['system']['potential']) - np.array(ref_tp.alldata[i]['system']['potential'])).max() <= 1e-7
+    # without the ladder the same budget leaves those lanes unconverged (and says so)
+    tp0 = _physical_transport(phis)
+    tp0.newton = {'maxit': 4, 'dphi_stage': 0.5, 'retry_rungs': 0}
+    c0 = Calculator(transport=tp0, calc='comsol')
+    c0.run()
+    assert (c0.status != 0).any() and sorted(np.flatnonzero(c0.status != 0).tolist()) == sorted(calc.retry_log[0]['lanes'])

@@ -169,3 +169,90 @@ def test_booth_stern_field():
         assert abs(E - e_out * 78.36 / booth_permittivity(E, 78.36)) <= 1e-9 * abs(E)       # displacement continuity
         assert np.isclose(eps, booth_permittivity(E, 78.36))
     assert booth_stern_field(0.0, 78.36) == (0.0, 78.36)
+
+
+class LadderSolver(FakeSolver):
+    """A fake whose lanes `stuck` never converge while the handle walks fewer than `need` stages; get_state / set_potential record
+    the patching of recovered lanes."""
+
+    def __init__(self, B, nx, N, stuck=(), need=10 ** 9):
+        FakeSolver.__init__(self)
+        self.B, self.nx, self.N, self.stuck, self.need = B, nx, N, list(stuck), need
+        self.stages = 0
+        self.c = np.zeros((B, N, nx)); self.phi = np.zeros((B, nx))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def set_batch(self, c0, pb, vz, flux):
+        FakeSolver.set_batch(self, c0, pb, vz, flux)
+        self.c = np.array(c0, float).reshape(self.B, self.N, self.nx).copy()
+
+    def set_potential(self, phi):
+        self.phi = np.array(phi, float).copy()
+        self.calls.append(('set_potential',))
+
+    def get_state(self):
+        return self.c.copy(), self.phi.copy(), None, None
+
+    def solve_stationary(self):
+        self.stages += 1
+        self.calls.append(('solve',))
+        st = np.zeros(self.B, np.int32)
+        if self.stages < self.need:
+            st[self.stuck] = 1
+        self.c[:] = 7.0 + self.stages           # a recognisable state: the stage count
+        self.phi[:] = -self.stages
+        return st
+
+
+def test_failed_lanes_walk_finer_ramps_and_are_patched_back(monkeypatch):
+    """The reference's convergence ladder (calculator.py:455-531: rerun with the ramp interval halved, ...) per lane: only the failed
+    lanes go again, as their own batch, with 2, 4, 8 x the stages; what converges replaces those lanes' state in the main handle."""
+    phis = np.linspace(-0.5, -2.0, 4)
+    tp = make_tp(phis)
+    tp.newton = {'retry_rungs': 3}
+    calc = Calculator(transport=tp, calc='comsol')
+    main = LadderSolver(4, tp.nx, 3, stuck=[1, 3])
+    subs = []
+
+    def fake_sub(B, **kw):
+        # rung 1 (22 stages): both failed lanes stay stuck; rung 2 (44): the first of the two converges; rung 3 (88): the other one
+        k = len(subs)
+        s = LadderSolver(B, tp.nx, 3, stuck=[[0, 1], [1], [0]][k], need=[10 ** 9, 10 ** 9, 88][k])
+        subs.append(s)
+        return s
+    monkeypatch.setattr(calc, '_physical_solver', fake_sub)
+    st = calc.solve_physical(main, np.ones((4, 3 * tp.nx)), phis, np.zeros((4, 3)))
+    assert calc.continuation_stages == 11
+    assert [r['stages'] for r in calc.retry_log] == [22, 44, 88] and [r['lanes'] for r in calc.retry_log] == [[1, 3], [1, 3], [3]]
+    assert [r['recovered'] for r in calc.retry_log] == [[], [1], [3]]
+    assert list(st) == [0, 0, 0, 0]
+    # the recovered lanes carry the sub-batches' states, the others the main handle's
+    assert (main.c[1] == 7.0 + 44).all() and (main.phi[1] == -44).all() and (main.c[3] == 7.0 + 88).all() and (main.c[0] == 7.0 + 11).all()
+    assert [c[0] for c in main.calls].count('set_potential') == 2
+
+
+def test_flux_sign_repair_of_run_single_step():
+    """err_in_flux / change_flux_sign of the reference's run_single_step (calculator.py:415-446)."""
+    import collections
+    species = collections.OrderedDict([('K+', {'bulk_concentration': 100.0}), ('HCO3-', {'bulk_concentration': 100.0}),
+                                       ('CO2', {'bulk_concentration': 34.0}), ('CO', {'bulk_concentration': 0.0, 'flux': 1e-5}), ('OH-', {'bulk_concentration': 1e-4})])
+    er = {'CO': {'reaction': 'CO2 + H2O + 2 e- -> CO + 2 OH-', 'nel': 2}}
+    tp = Transport(species=species, electrode_reactions=er, system={'phiM': -0.8, 'boundary thickness': 4e-8, 'exclude species': ['H2O', 'e-']},
+                   nx=32, descriptors={'phiM': [-0.8]})
+    calc = Calculator(transport=tp, calc='comsol')
+    assert tp.electrode_reactions['CO']['reaction'][0][0] == 'CO2' and 'CO' in tp.electrode_reactions['CO']['reaction'][1]
+    # the flux closure of Transport (transport.py:929-1095) has filled in the educt and the co-product: -1e-5, +1e-5, +2e-5
+    assert np.allclose([tp.species[sp]['flux'] for sp in ('CO2', 'CO', 'OH-')], [-1e-5, 1e-5, 2e-5], rtol=1e-12)
+    assert not calc.flux_sign_error()
+    tp.species['CO2']['flux'] = 1e-5                      # an educt that is produced: the reference flips every electrode flux
+    assert calc.flux_sign_error()
+    calc.change_flux_sign()
+    assert np.allclose([tp.species[sp]['flux'] for sp in ('CO2', 'CO', 'OH-')], [-1e-5, -1e-5, -2e-5], rtol=1e-12)
+    assert tp.species['K+'].get('flux', 0.0) in (0.0, '0.0', 0)           # species outside the electrode reactions are not touched
+    tp.species['CO2']['flux'] = 0.0                       # zero fluxes carry no sign
+    assert not calc.flux_sign_error()
