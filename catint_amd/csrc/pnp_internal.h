@@ -147,6 +147,12 @@ struct NewtonArgs {
   double* sweep;                         // sweep kernel (one team per operating point): records, sweep_stride doubles per team
   int64_t sweep_stride;
   int32_t sweep_blocks, pad2_;           // workgroups (= waves) the sweep workspace was sized for; 0: no workspace
+  // lane kernel (pnp_lane.hip: one operating point per lane): batch-innermost copies of the state and the block-Thomas records
+  double* lane_ts;                       // [groups][N+1][nx][32] concentrations + potential of 32 operating points
+  double* lane_tco;                      // [groups][N][nx][32]   previous time level
+  double* lane_rec;                      // [groups][nx][(N+1)^2 + (N+1)][32]
+  int64_t lane_groups;                   // groups (of 32 operating points) the three buffers hold
+  int64_t lane_group0;                   // first group of this launch (the batch is walked in chunks of lane_groups)
 };
 int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);
@@ -158,6 +164,13 @@ bool newton_exchange_in_lds(int nb, int nx);
 int newton_pair_threads(int nb, int nx);   // threads of the pair kernel, 0 if the shape does not fit it
 int newton_pair_stride(int nb, int nx);    // its compile-time row stride (256 or 512)
 hipError_t launch_newton(const NewtonArgs& a, int blocks, hipStream_t stream);
+// lane kernel (pnp_lane.hip): one operating point per lane, block Thomas from both ends in registers; point / steric ions without
+// homogeneous reactions
+bool newton_lane_supported(int nb, int nx, int mode);
+bool newton_lane_preferred(int nb, int nx, int64_t B, int mode);
+size_t newton_lane_rec_doubles(int nb, int nx);       // records of one group of 32 operating points
+size_t newton_lane_state_doubles(int nb, int nx);     // transposed state + previous time level of one group
+hipError_t launch_newton_lane(const NewtonArgs& a, hipStream_t stream);
 
 // ---- kinetics <-> transport SCF loop on the device (pnp_scf.hip; Calculator.run_scf_cycle, calculator.py:294-406) ----
 struct ScfArgs {

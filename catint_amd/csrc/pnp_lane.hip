@@ -1,0 +1,621 @@
+// Physical mode, large batches: the LANE kernel -- one operating point per LANE (and per sweep direction), every block
+// operation of the block-tridiagonal Newton solve in that lane's own registers.
+//
+// Why (measured on the lane-team / sweep kernels of pnp_newton.hip): with N+1 lanes sharing a block row,
+// every Gauss-Jordan pivot is a write -> wave barrier -> read round trip through LDS and most instructions of a row are
+// pivot search, selects and broadcasts executed by 7 operating points per wave: ~1 100 wave instructions per grid row for 7
+// points, 65 % of a wave's life parked.  Here a wave instruction advances 32 operating points by the same amount of block
+// algebra, nothing is exchanged between lanes inside a row and the dependent chain of a row is plain fp64 arithmetic.
+//
+// What it solves: the same Newton system as the other kernels of the physical mode (comsol_model.py:465-516 asks COMSOL for a
+// fully coupled Newton with a direct linear solve; physics as restated in pnp_newton.hip / oracle/pnp_physical.py), point ions
+// or steric (MPB) ions, Dirichlet or Stern wall, prescribed wall fluxes, implicit wall kinetics, uniform or graded grid,
+// stationary or backward-Euler steps; homogeneous reactions stay with the pivoting kernels.
+//
+// Algorithm: block Thomas from BOTH ends (twisted factorisation, as newton_sweep2_kernel).  Lanes 0..31 of a wave walk 32
+// operating points from the wall upwards (rows 0 .. m-1), lanes 32..63 walk the SAME 32 points from the bulk downwards (rows
+// nx-1 .. m+1); the middle row m sees both eliminations and both halves substitute outwards.  With "behind" = the neighbour
+// already eliminated and "ahead" = the one not yet, both directions run one instruction stream:
+//     D'_i = D_i - Bk_i T_b ,   T_i = D'_i^-1 Ah_i ,   t_i = D'_i^-1 (r_i - Bk_i t_b) ;    x_i = t_i - T_i x_ahead .
+// The off-diagonal blocks are never formed: a species row couples to its own species, to the potential and (steric ions) to a
+// rank-one term, so Bk T costs 3 fused multiply-adds per element instead of N+1.  D' is factorised in place (LU without row
+// exchanges: the species block is a positive diagonal plus a positive rank-one matrix, the potential column only deepens the
+// Poisson pivot -- see block_solve in pnp_newton.hip; a pivot monitor flags lanes where that assumption fails) and the N+2
+// columns of [Ah | r'] are solved one by one, each leaving for device memory as soon as it is complete.
+//
+// Layout in HBM: batch-innermost.  The handle's state c[b][k][i] (x fastest, made for one-grid-per-wave kernels) would make
+// every lane touch its own 64-byte line, so a launch first transposes the state of each group of 32 operating points into
+// ts[group][variable][i][32] (pack kernel), works there, and transposes back (unpack kernel, which also raises the NaN
+// status).  Records rec[group][i][(N+1)^2 + (N+1)][32].  Every wave instruction then moves two contiguous 256-byte pieces.
+// Algorithmic traffic of one Newton iteration and operating point, in doubles per grid row: forward 2N+1 read (c, phi, c_old),
+// (N+1)(N+2) written; backward (N+1)(N+2) read, N+1 written; update 2(N+1) read, N+1 written.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "pnp_internal.h"
+#include "pnp_math.h"
+
+namespace pnp {
+
+namespace {
+
+struct LEdge {
+  double Bp, Bm, J, Ju;
+};
+
+// Scharfetter-Gummel edge flux, the formulas of edge_flux in pnp_newton.hip (oracle/pnp_physical.py: bernoulli)
+__device__ __forceinline__ LEdge lane_edge_flux(double u, double cl, double cr, double w) {
+  double B, dB;
+  if (fabs(u) < 0.05) {
+    double k12 = 1.0 / 12.0, k720 = -1.0 / 720.0, k30240 = 1.0 / 30240.0, k6 = 1.0 / 6.0, k180 = -1.0 / 180.0, k5040 = 1.0 / 5040.0;
+    asm volatile("" : "+s"(k12), "+s"(k720), "+s"(k30240), "+s"(k6), "+s"(k180), "+s"(k5040));
+    const double u2 = u * u;
+    B = 1.0 - 0.5 * u + u2 * (k12 + u2 * (k720 + u2 * k30240));
+    dB = -0.5 + u * (k6 + u2 * (k180 + u2 * k5040));
+  } else {
+    const double rE = nrcp(expm1_sc(u));
+    B = u * rE;
+    dB = (1.0 - B - u) * rE;
+  }
+  LEdge e;
+  e.Bp = w * B;
+  e.Bm = w * (B + u);
+  e.J = -(e.Bm * cr - e.Bp * cl);
+  e.Ju = -w * ((dB + 1.0) * cr - dB * cl);
+  return e;
+}
+
+__device__ __forceinline__ double partner(double v) { return __shfl_xor(v, 32, 64); }   // the same operating point, other direction
+
+constexpr int LG = 32;      // operating points per wave (two lanes each)
+
+}  // namespace
+
+size_t newton_lane_rec_doubles(int nb, int nx) { return (size_t)nx * (size_t)(nb * nb + nb) * LG; }
+size_t newton_lane_state_doubles(int nb, int nx) { return (size_t)nx * (size_t)(2 * nb - 1) * LG; }    // ts (N+1 rows) + tco (N rows)
+
+// ---- state transposition: c[b][k][ldx], phi[b][ldx]  <->  ts[group][v][i][32] (v = N: potential); tco = c on the way in -----------
+template <bool IN>
+__global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G) {
+  __shared__ double tile[LG][65];
+  const int N = G.N, nx = G.nx, ldx = G.ldx;
+  const int64_t g = blockIdx.x;
+  const int i0 = blockIdx.y * 64;
+  const int t = threadIdx.x;
+  double* ts = G.lane_ts + (size_t)g * (size_t)(N + 1) * nx * LG;
+  double* tco = G.lane_tco + (size_t)g * (size_t)N * nx * LG;
+  const int64_t b0 = (G.lane_group0 + g) * LG;
+  bool bad = false;
+  for (int v = 0; v <= N; ++v) {
+    if constexpr (IN) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int op = rr * 4 + (t >> 6), ii = t & 63;
+        const int64_t b = b0 + op;
+        double val = 0.0;
+        if (b < G.B && i0 + ii < nx) val = v < N ? G.c[((size_t)b * N + v) * ldx + i0 + ii] : G.phi[(size_t)b * ldx + i0 + ii];
+        tile[op][ii] = val;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int ii = rr * 8 + (t >> 5), op = t & 31;
+        if (i0 + ii < nx) {
+          const double val = tile[op][ii];
+          ts[((size_t)v * nx + i0 + ii) * LG + op] = val;
+          if (v < N) tco[((size_t)v * nx + i0 + ii) * LG + op] = val;
+        }
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int ii = rr * 8 + (t >> 5), op = t & 31;
+        double val = 0.0;
+        if (i0 + ii < nx) val = ts[((size_t)v * nx + i0 + ii) * LG + op];
+        if (!(fabs(val) < INFINITY)) bad = true;
+        tile[op][ii] = val;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int op = rr * 4 + (t >> 6), ii = t & 63;
+        const int64_t b = b0 + op;
+        if (b < G.B && i0 + ii < nx && !(G.lane_mask && !G.lane_mask[b])) {
+          if (v < N) G.c[((size_t)b * N + v) * ldx + i0 + ii] = tile[op][ii];
+          else G.phi[(size_t)b * ldx + i0 + ii] = tile[op][ii];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if constexpr (!IN) {
+    const int64_t b = b0 + (t & 31);
+    if (bad && b < G.B && !(G.lane_mask && !G.lane_mask[b])) atomicMax(&G.status[b], (int32_t)PNP_STATUS_NAN);
+  }
+}
+
+// ---- the solver ---------------------------------------------------------------------------------------------------------------
+template <int NB, int MODE>
+__global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
+  constexpr int N = NB - 1, NREC = NB * NB + NB;
+  constexpr bool MPB = MODE >= 1;
+  __shared__ double s_cb[N][LG];             // bulk concentrations of the wave's operating points
+  __shared__ double s_rec[NREC][LG];         // the downward half's last record, handed to the upward half for the middle row
+  // largest blocks: what a row only hands to the next one (concentrations of the point ahead, two of the four edge quantities) waits in
+  // LDS while the factorisation and the column solves need every register
+  constexpr bool STASH = NB >= 9;
+  __shared__ double s_car[STASH ? 3 * N : 1][64];
+  const int lane = threadIdx.x, o = lane & 31;
+  const bool side = lane >= 32;              // false: from the wall upwards; true: from the bulk downwards
+  const double sgn = side ? -1.0 : 1.0;
+  const int nx = G.nx;
+  const int m = (nx - 1) >> 1;               // middle row
+  const int n_dn = nx - 1 - m;               // rows of the downward half (nx-1 .. m+1); the upward half has m (0 .. m-1)
+  const int64_t g = blockIdx.x;
+  const int64_t b_raw = (G.lane_group0 + g) * LG + o;
+  const bool valid = b_raw < G.B && !(G.lane_mask && !G.lane_mask[b_raw < G.B ? b_raw : 0]);
+  const int64_t b = b_raw < G.B ? b_raw : G.B - 1;      // (parameter loads of the padding lanes stay in range)
+  double* ts = G.lane_ts + (size_t)g * (size_t)NB * nx * LG + o;
+  double* tco = G.lane_tco + (size_t)g * (size_t)N * nx * LG + o;
+  double* rec = G.lane_rec + (size_t)g * (size_t)nx * NREC * LG + o;
+  auto TS = [&](int v, int i) -> double& { return ts[((size_t)v * nx + i) * LG]; };
+  auto CO = [&](int k, int i) -> double& { return tco[((size_t)k * nx + i) * LG]; };
+  auto REC = [&](int i, int e) -> double& { return rec[((size_t)i * NREC + e) * LG]; };
+  const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
+  if (!side) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) s_cb[k][o] = G.cbulk[(size_t)b * N + k];
+  }
+  __syncthreads();
+
+  bool have = valid, fresh = true;
+  int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
+  double upd_prev = INFINITY;
+
+  for (;;) {
+    if (__ballot(have) == 0ull) break;
+    const NewtonArgs& A = G;
+    const bool first = fresh;          // first iteration of a timestep: the previous time level is the state itself
+    if (fresh) {
+      it = 0;
+      upd_prev = INFINITY;
+      fresh = false;
+    }
+    it += 1;
+    // =========================== forward: both halves eliminate towards the middle ======================================
+    double hc[N], hphi, hw = 0.0, hinv = 1.0;             // the point "here"
+    double bphi = 0.0, binv = 1.0;                        // behind: potential, 1/(1 - phi0)
+    double eJ[N], eBd[N], eBn[N], eJu[N];                 // behind edge as the point here sees it: outflow, own / neighbour weight, dJ/du
+    double T[NB][NB], t[NB];                              // behind record: T[j][r] = element (r, j) of D'^-1 Ah, t = D'^-1 r'
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      t[j] = 0.0;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) T[j][r] = 0.0;
+    }
+    {
+      const int i = side ? nx - 1 : 0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        hc[k] = TS(k, i);
+        eJ[k] = 0.0;
+        eBd[k] = 0.0;
+        eBn[k] = 0.0;
+        eJu[k] = 0.0;
+      }
+      hphi = TS(N, i);
+      if constexpr (MPB) {
+        double f = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) f = __builtin_fma(A.vol[k], hc[k], f);
+        hw = -log1p_sc(-f);
+        hinv = 1.0 / (1.0 - f);
+      }
+    }
+    const int S = n_dn + 1;             // n_dn row steps (the upward half rests in the last one when nx is even), then the middle row
+    for (int s = 0; s < S; ++s) {
+      const bool last = s == S - 1;     // the middle row: upward half only
+      const bool act = last ? !side : (side || s < m);
+      if (last) {
+        // the downward half's final record travels through LDS (written in its last active row below)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      if (act) {
+        const int i = side ? nx - 1 - s : (last ? m : s);
+        const int ia = side ? i - 1 : i + 1;                        // ahead (always inside the grid: 0 < m < nx-1 ... see launcher)
+        const bool firstrow = s == 0;
+        const bool wall = firstrow && !side, bulk = firstrow && side;
+        // ---- the point ahead and the edge towards it --------------------------------------------------------------------
+        double ac[N], aphi, aw = 0.0, ainv = 1.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) ac[k] = TS(k, ia);
+        aphi = TS(N, ia);
+        if constexpr (MPB) {
+          double f = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) f = __builtin_fma(A.vol[k], ac[k], f);
+          aw = -log1p_sc(-f);
+          ainv = 1.0 / (1.0 - f);
+        }
+        const double wa = bulk ? 0.0 : 1.0, wb = firstrow ? 0.0 : 1.0;
+        const double vi = G.gv[i];
+        const double ws = bulk ? 0.0 : vi;
+        const double wea = G.gw[side ? i - 1 : i], web = firstrow ? 0.0 : G.gw[side ? i : i - 1];
+        double aJ[N], aBd[N], aBn[N], aJu[N];
+        {
+          const double dphi = aphi - hphi, dw = aw - hw;
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            // the edge is evaluated in its left -> right orientation whichever way the lane walks
+            const double u = sgn * __builtin_fma(A.qb[k], dphi, dw);
+            double h_ = hc[k];              // (opaque: a select between elements of two arrays is otherwise turned into one
+            asm volatile("" : "+v"(h_));    //  dynamically indexed stack array)
+            const double cl = side ? ac[k] : h_, cr = side ? h_ : ac[k];
+            const LEdge e = lane_edge_flux(u, cl, cr, wea);
+            aJ[k] = sgn * e.J;                    // (unweighted: the same edge is the next row's behind edge)
+            aBd[k] = side ? e.Bm : e.Bp;
+            aBn[k] = side ? e.Bp : e.Bm;
+            aJu[k] = e.Ju;
+            if constexpr (STASH) {
+              s_car[k][lane] = ac[k];
+              s_car[N + k][lane] = aJ[k];
+              s_car[2 * N + k][lane] = aBd[k];
+            }
+          }
+        }
+        // ---- right-hand side and the diagonal block's ingredients ---------------------------------------------------------
+        double rhs[NB], diag[N], Js[N];
+        double rho = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          double co = hc[k];
+          if (!first) co = CO(k, i);
+          else CO(k, i) = hc[k];
+          const double sg = ws * A.sig[k];
+          rho = __builtin_fma(A.peq[k], hc[k], rho);
+          double F = sg * (hc[k] - co) + wa * aJ[k] + wb * eJ[k];
+          if (wall) F -= G.flux[(size_t)b * N + k] * A.fl[k];
+          if (bulk) F = hc[k] - s_cb[k][o];
+          rhs[k] = -F;
+          diag[k] = sg + wa * aBd[k] + wb * eBd[k] + (bulk ? 1.0 : 0.0);
+          Js[k] = wa * aJu[k] + wb * eJu[k];
+        }
+        double dNN, ahNN;           // Poisson row: diagonal entry, entry of the ahead block
+        if (bulk) {
+          rhs[N] = -(hphi - phiB);
+          dNN = 1.0;
+          ahNN = 0.0;
+        } else if (wall) {
+          if (A.wall_bc == 0) {
+            rhs[N] = -(hphi - phiM);
+            dNN = 1.0;
+            ahNN = 0.0;
+          } else {
+            rhs[N] = -(wea * (aphi - hphi) + A.stern * (phiM - A.phi_pzc - hphi));
+            dNN = -wea - A.stern;
+            ahNN = wea;
+          }
+        } else {
+          rhs[N] = -((wea * (aphi - hphi) + web * (bphi - hphi)) + vi * rho);
+          dNN = -(wea + web);
+          ahNN = wea;
+        }
+        const double pq = (wall || bulk) ? 0.0 : vi;          // charge term of the Poisson row (interior rows only)
+        // ---- D' = D - Bk T, r' = r - Bk t: column by column, the behind record is consumed on the way -------------------------
+        // Bk[k][j] = -bb_k [j == k] + Jb_k (qb_k [j == N] + vol_j binv) (k < N), bb = wb eBn, Jb = wb eJu;  Bk[N][N] = web
+        // (Bk T)[k][j] = -bb_k T[k][j] + Jb_k (qb_k T[N][j] + binv sum_q vol_q T[q][j])
+        double D[NB][NB];           // D[r][c], row-major
+#pragma unroll
+        for (int j = 0; j <= NB; ++j) {         // j == NB: the right-hand side, with t for T[j]
+          double col[NB];
+#pragma unroll
+          for (int r = 0; r < NB; ++r) col[r] = j < NB ? T[j < NB ? j : 0][r] : t[r];
+          double sj = 0.0;
+          if constexpr (MPB) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) sj = __builtin_fma(A.vol[q], col[q], sj);
+            sj *= binv;
+          }
+          const double tN = col[N];
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            double v;
+            if (j == NB) v = rhs[k];
+            else if (j == N) v = -A.qb[k] * Js[k];
+            else v = (MPB ? -Js[k] * (A.vol[j < N ? j : 0] * hinv) : 0.0) + (j == k ? diag[k] : 0.0);
+            v = __builtin_fma(wb * eBn[k], col[k], v);
+            v = __builtin_fma(-(wb * eJu[k]), __builtin_fma(A.qb[k], tN, sj), v);
+            if (j == NB) rhs[k] = v;
+            else D[k][j < NB ? j : 0] = v;
+          }
+          if (j == NB) rhs[N] = __builtin_fma(-web, tN, rhs[N]);
+          else D[N][j < NB ? j : 0] = __builtin_fma(-web, tN, j == N ? dNN : pq * A.peq[j < N ? j : 0]);
+        }
+        // ---- implicit wall kinetics (fill_row in pnp_newton.hip): rate K g(c_s) E joins the wall flux -------------------------
+        if (wall && A.n_wk > 0) {
+          for (int q = 0; q < A.n_wk; ++q) {
+            const int sp = A.wk_species[q];
+            double cs = 1.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) cs = (k == sp) ? hc[k] : cs;
+            const double kr = G.wk_k[(size_t)b * PNP_MAX_WALL_REACTIONS + q];
+            const double al = A.wk_alpha[q], den = 1.0 / (1.0 + A.wk_sat[q] * cs);
+            const double E = al != 0.0 ? exp(al * (phiM - hphi)) : 1.0;
+            const double gq = cs * den * E, dg = den * den * E;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              const double a = A.wk_nu[q][k] * kr * A.fl[k];
+              rhs[k] += a * gq;
+#pragma unroll
+              for (int j = 0; j < N; ++j) D[k][j] -= (j == sp) ? a * dg : 0.0;
+              if (al != 0.0) D[k][N] += a * al * gq;
+            }
+          }
+        }
+        // ahead block Ah[k][j] = wa (-aBn_k [j == k] + aJu_k (qb_k [j == N] + vol_j ainv)) (k < N);  Ah[N][N] = ahNN
+        if (last) {
+          // ---- middle row: the downward half's record (row m+1) enters the same way -------------------------------------------
+#pragma unroll
+          for (int j = 0; j <= NB; ++j) {
+            double col[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) col[r] = s_rec[j * NB + r][o];
+            double sj = 0.0;
+            if constexpr (MPB) {
+#pragma unroll
+              for (int q = 0; q < N; ++q) sj = __builtin_fma(A.vol[q], col[q], sj);
+              sj *= ainv;
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              double v = j == NB ? rhs[k] : D[k][j < NB ? j : 0];
+              v = __builtin_fma(aBn[k], col[k], v);
+              v = __builtin_fma(-aJu[k], __builtin_fma(A.qb[k], col[N], sj), v);
+              if (j == NB) rhs[k] = v;
+              else D[k][j < NB ? j : 0] = v;
+            }
+            if (j == NB) rhs[N] = __builtin_fma(-ahNN, col[N], rhs[N]);
+            else D[N][j < NB ? j : 0] = __builtin_fma(-ahNN, col[N], D[N][j < NB ? j : 0]);
+          }
+        }
+        // ---- LU in place, no row exchanges; reciprocal pivots on the diagonal ----------------------------------------------
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          const double inv = nrcp(D[k][k]);
+          D[k][k] = inv;
+#pragma unroll
+          for (int r = k + 1; r < NB; ++r) {
+            const double l = D[r][k] * inv;
+            D[r][k] = l;
+#pragma unroll
+            for (int cc = k + 1; cc < NB; ++cc) D[r][cc] = __builtin_fma(-l, D[k][cc], D[r][cc]);
+          }
+        }
+        auto solve = [&](double (&y)[NB], const int start) {     // rows < start of y are zero
+#pragma unroll
+          for (int k = 0; k < NB; ++k) {
+            if (k < start) continue;
+#pragma unroll
+            for (int r = k + 1; r < NB; ++r) y[r] = __builtin_fma(-D[r][k], y[k], y[r]);
+          }
+#pragma unroll
+          for (int k = NB - 1; k >= 0; --k) {
+            double acc = y[k];
+#pragma unroll
+            for (int cc = k + 1; cc < NB; ++cc) acc = __builtin_fma(-D[k][cc], y[cc], acc);
+            y[k] = acc * D[k][k];
+          }
+        };
+        solve(rhs, 0);
+        const bool handoff = side && s == n_dn - 1;       // the downward half's last row: its record also goes to LDS
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+          t[r] = rhs[r];                                    // (middle row: the solution x_m itself)
+          REC(i, NB * NB + r) = rhs[r];
+          if (handoff) s_rec[NB * NB + r][o] = rhs[r];
+        }
+        if (!last) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            double y[NB];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              double v;
+              if (j == N) v = aJu[k] * A.qb[k];
+              else v = (MPB ? aJu[k] * (A.vol[j] * ainv) : 0.0) - (j == k ? aBn[k] : 0.0);
+              y[k] = wa * v;
+            }
+            y[N] = j == N ? ahNN : 0.0;
+            solve(y, (MPB || j == N) ? 0 : j);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+              T[j][r] = y[r];
+              REC(i, j * NB + r) = y[r];
+              if (handoff) s_rec[j * NB + r][o] = y[r];
+            }
+          }
+        } else {
+          // (nothing is carried out of the middle row: fresh definitions end the live ranges of the old record here)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < NB; ++r) T[j][r] = 0.0;
+        }
+        // ---- the point ahead becomes the point here; its edge is seen from the other end -----------------------------------
+        bphi = hphi;
+        binv = hinv;
+        hphi = aphi;
+        hw = aw;
+        hinv = ainv;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          if constexpr (STASH) {
+            hc[k] = s_car[k][lane];
+            eJ[k] = -s_car[N + k][lane];
+            eBn[k] = s_car[2 * N + k][lane];
+          } else {
+            hc[k] = ac[k];
+            eJ[k] = -aJ[k];
+            eBn[k] = aBd[k];
+          }
+          eBd[k] = aBn[k];
+          eJu[k] = aJu[k];
+        }
+      }
+    }
+    // =========================== backward: x_i = t_i - T_i x_ahead-of-the-elimination, outwards from the middle ============
+    double xm[NB];      // solution of the middle row (the upward half computed and recorded it), start of both back-substitutions
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const double own = side ? 0.0 : REC(m, NB * NB + r);
+      const double other = partner(own);          // (cross-lane: every lane takes part, the select comes afterwards)
+      xm[r] = side ? other : own;
+    }
+    double mphi = side ? 0.0 : fabs(xm[N]);
+    if (!(mphi == mphi)) mphi = INFINITY;
+    {
+      double x[NB];
+#pragma unroll
+      for (int r = 0; r < NB; ++r) x[r] = xm[r];
+      for (int s = 0; s < n_dn; ++s) {
+        const bool act = side || s < m;
+        if (act) {
+          const int i = side ? m + 1 + s : m - 1 - s;
+          double y[NB];
+#pragma unroll
+          for (int r = 0; r < NB; ++r) y[r] = REC(i, NB * NB + r);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            double col[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) col[r] = REC(i, j * NB + r);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) y[r] = __builtin_fma(-col[r], x[j], y[r]);
+          }
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+            x[r] = y[r];
+            REC(i, NB * NB + r) = y[r];
+          }
+          const double a = fabs(y[N]);
+          mphi = fmax(mphi, a);
+          if (!(a == a)) mphi = INFINITY;
+        }
+      }
+    }
+    mphi = fmax(mphi, partner(mphi));
+    double lam = 1.0;
+    if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+    // =========================== damping, clips, update (oracle/pnp_physical.py: newton_step) ================================
+    double upd = 0.0;
+    for (int s = 0; s <= m; ++s) {
+      const bool act = side ? s < n_dn : true;
+      if (act) {
+        const int i = side ? m + 1 + s : s;
+        double du[NB], cc_[N], cn[N];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) du[r] = REC(i, NB * NB + r);
+        double f_old = 0.0, f_new = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          cc_[k] = TS(k, i);
+          const double rel = fabs(du[k]) / (fabs(cc_[k]) + fabs(s_cb[k][o]) + 1e-300);
+          upd = fmax(upd, rel);
+          if (!(du[k] == du[k])) upd = INFINITY;
+          const double t_ = __builtin_fma(lam, du[k], cc_[k]);
+          const double lo = 0.1 * cc_[k];
+          cn[k] = t_ < lo ? lo : t_;
+          if constexpr (MPB) {
+            f_old = __builtin_fma(A.vol[k], cc_[k], f_old);
+            f_new = __builtin_fma(A.vol[k], cn[k], f_new);
+          }
+        }
+        if constexpr (MPB) {
+          const double free_ = 1.0 - f_old;
+          const double target = fmax(0.1 * free_, 1e-12);
+          if ((1.0 - f_new) < target) {
+            const double theta = (free_ - target) / (f_new - f_old);
+#pragma unroll
+            for (int k = 0; k < N; ++k) cn[k] = __builtin_fma(theta, cn[k] - cc_[k], cc_[k]);
+          }
+        }
+        if (have) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) TS(k, i) = cn[k];
+          TS(N, i) = __builtin_fma(lam, du[N], TS(N, i));
+        }
+      }
+    }
+    upd = fmax(upd, partner(upd));
+    upd = fmax(upd, mphi * A.vt_inv);
+    // =========================== bookkeeping of the lane's operating point (identical in both halves) ========================
+    if (have) {
+      bool accept = false;
+      if (lam == 1.0) {
+        accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol);
+        upd_prev = upd;
+      } else {
+        upd_prev = INFINITY;
+      }
+      if (accept || it >= A.maxit) {
+        total_it += accept ? it : A.maxit + 1;
+        if (!accept) st = PNP_STATUS_MAXIT;
+        step += 1;
+        fresh = true;
+        if (step >= A.nsteps) {
+          have = false;
+          if (!side) {
+            G.status[b] = st;
+            G.iters[b] = total_it;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+bool newton_lane_supported(int nb, int nx, int mode) { return nb >= 2 && nb <= 9 && nx >= 5 && mode <= 1; }
+
+bool newton_lane_preferred(int nb, int nx, int64_t B, int mode) {
+  if (!newton_lane_supported(nb, nx, mode)) return false;
+  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 'l';
+  return false;
+}
+
+template <int NB>
+static hipError_t launch_lane_nb(const NewtonArgs& a0, hipStream_t stream) {
+  const int64_t groups = (a0.B + LG - 1) / LG;
+  const int64_t cap = a0.lane_groups > 0 ? a0.lane_groups : 1;
+  for (int64_t g0 = 0; g0 < groups; g0 += cap) {
+    NewtonArgs a = a0;
+    a.lane_group0 = g0;
+    const int64_t ng = groups - g0 < cap ? groups - g0 : cap;
+    const dim3 tg((unsigned)ng, (unsigned)((a.nx + 63) / 64));
+    hipLaunchKernelGGL((lane_transpose_kernel<true>), tg, dim3(256), 0, stream, a);
+    if (a.mpb) hipLaunchKernelGGL((newton_lane_kernel<NB, 1>), dim3((unsigned)ng), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((newton_lane_kernel<NB, 0>), dim3((unsigned)ng), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((lane_transpose_kernel<false>), tg, dim3(256), 0, stream, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_newton_lane(const NewtonArgs& a, hipStream_t stream) {
+  switch (a.N + 1) {
+    case 2: return launch_lane_nb<2>(a, stream);
+    case 3: return launch_lane_nb<3>(a, stream);
+    case 4: return launch_lane_nb<4>(a, stream);
+    case 5: return launch_lane_nb<5>(a, stream);
+    case 6: return launch_lane_nb<6>(a, stream);
+    case 7: return launch_lane_nb<7>(a, stream);
+    case 8: return launch_lane_nb<8>(a, stream);
+    case 9: return launch_lane_nb<9>(a, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace pnp

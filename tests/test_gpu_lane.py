@@ -1,0 +1,144 @@
+"""GPU parity of the lane kernel (catint_amd/csrc/pnp_lane.hip: one operating point per lane, block Thomas from both ends in
+registers, batch-innermost state and records) against the CPU oracle oracle/pnp_physical.py and against the lane-team kernels,
+through the C-ABI.  Same bar as tests/test_gpu_newton.py: states to 2e-9 of the profile's scale and IDENTICAL Newton
+iteration counts per operating point (both sides run the same damping and stopping rules).
+
+The reference hands this solve to COMSOL (catint/comsol_model.py:465-516: fully coupled Newton, direct linear solver); parity
+with COMSOL itself is unpinned, the oracle is pinned by analytic answers (tests/test_physical_oracle.py).
+"""
+import numpy as np
+import pytest
+
+from catint_amd import _capi
+from tests.test_gpu_newton import BETA, EPS, assert_close, make_lanes, run_both, run_gpu_only
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def lane_kernel(monkeypatch):
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'lane')
+
+
+@pytest.mark.parametrize("N,nx", [(1, 33), (2, 64), (2, 201), (3, 128), (3, 513), (4, 100), (5, 70), (5, 71), (6, 96), (6, 9), (7, 50),
+                                  (7, 51), (8, 40), (8, 129)])
+def test_stationary_matches_oracle(N, nx):
+    # even and odd row counts (the upward half rests for one row when nx is even), very short grids, a batch that is not a
+    # multiple of the 32 operating points of a wave
+    kw = {'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * N} if N >= 6 else {}
+    got, ref = run_both(N, nx, B=37, seed=N * 31 + nx, newton_kw=kw)
+    assert_close(got, ref)
+
+
+@pytest.mark.parametrize("nx", [5, 6, 7, 8])
+def test_shortest_grids(nx):
+    got, ref = run_both(3, nx, B=5, seed=nx)
+    assert_close(got, ref)
+
+
+def test_several_chunks(monkeypatch):
+    # the workspace holds one group of 32 operating points: the launcher walks the batch in five chunks
+    monkeypatch.setenv('CATINT_NEWTON_LANE_GROUPS', '1')
+    got, ref = run_both(4, 48, B=133, seed=3)
+    assert_close(got, ref)
+
+
+def test_transient_steps_match_oracle():
+    N, nx = 3, 160
+    D, q, cb, dx, phiM = make_lanes(N, nx, 4, 7)
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    got, ref = run_both(N, nx, B=40, seed=7, dt=dt, nsteps=6, stationary=False)
+    assert_close(got, ref)
+    assert got[2].min() >= 6 * 2          # at least two Newton iterations per step
+
+
+def test_transient_steric_eight_species():
+    got, ref = run_both(8, 96, B=35, seed=5, dt=2e-8, nsteps=4, stationary=False,
+                        newton_kw={'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 8})
+    assert_close(got, ref)
+
+
+def test_stern_layer_and_steric_ions():
+    a = [4.1e-10, 3.1e-10, 3.5e-10]
+    got, ref = run_both(3, 240, B=6, seed=11, phi_lo=-1.5, phi_hi=1.0, cref=100.0,
+                        newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, phi_pzc=0.05, mpb_radius=a, maxit=60))
+    assert_close(got, ref)
+
+
+def test_wall_fluxes():
+    rng = np.random.default_rng(5)
+    B, N = 4, 3
+    flux = rng.uniform(-2e-4, 2e-4, (B, N))
+    got, ref = run_both(N, 96, B=B, seed=13, flux=flux)
+    assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx,B", [(4, 150, 5), (3, 128, 4), (6, 96, 4), (8, 64, 3)])
+def test_butler_volmer_and_langmuir_wall_kinetics(N, nx, B):
+    rng = np.random.default_rng(N * 100 + nx)
+    wk = [{'species': 2, 'k': rng.uniform(0.05, 1.0, B), 'nu': [0.0, 0.0, -1.0] + [1.0] * (N > 3) + [0.0] * max(N - 4, 0), 'alpha': -6.0,
+           'saturation': 0.05},
+          {'species': 0, 'k': rng.uniform(1e-4, 1e-3, B), 'nu': [-1.0, 0.0, 0.5] + [0.0] * (N - 3), 'alpha': 3.0},
+          {'species': -1, 'k': rng.uniform(1e-6, 1e-5, B), 'nu': [0.0, 1.0, 0.0] + [0.0] * (N - 3), 'alpha': -4.0},
+          {'species': 1, 'k': rng.uniform(1e-4, 1e-3, B), 'nu': [0.0, -1.0, 0.0] + [0.0] * (N - 3), 'saturation': 0.2}]
+    got, ref = run_both(N, nx, B=B, seed=23 + N, wall_kinetics=wk,
+                        newton_kw=dict(wall_bc='stern', stern_capacitance=0.2, phi_pzc=0.05, mpb_radius=[4.1e-10] + [0.0] * (N - 1)))
+    assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx,kw", [(3, 96, {}), (3, 257, dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=[4.1e-10, 3e-10, 0.0])),
+                                     (6, 80, {})])
+def test_graded_grid(N, nx, kw):
+    from catint_amd.host import graded_mesh
+    x = graded_mesh(4000.0, 1.0, nx)
+    got, ref = run_both(N, nx, B=3, seed=nx, x=x, newton_kw=kw, points_per_debye=8.0)
+    assert_close(got, ref)
+    got, ref = run_both(N, nx, B=3, seed=nx + 1, x=x, newton_kw=kw, points_per_debye=8.0, dt=1e-7, nsteps=3, stationary=False)
+    assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx", [(3, 512), (6, 96), (8, 40)])
+def test_bitwise_reproducible(N, nx):
+    a = run_gpu_only(N, nx, 70, 99)
+    b = run_gpu_only(N, nx, 70, 99)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_lane_kernel_equals_the_lane_team_kernels(monkeypatch):
+    """Same Newton systems, another elimination (LU without row exchanges in one lane against Gauss-Jordan across a team):
+    states to rounding and identical iteration counts on a batch of 300 operating points, steric ions, Stern wall."""
+    outs = []
+    for kern in ('lane', 'team'):
+        monkeypatch.setenv('CATINT_NEWTON_KERNEL', kern)
+        N, nx, B = 8, 128, 300
+        D, q, cb, dx, phiM = make_lanes(N, nx, B, 5)
+        c0 = np.repeat(cb[:, :, None], nx, axis=2)
+        pb = np.zeros((B, 4))
+        pb[:, 0] = phiM
+        with _capi.PnpSolver(N, nx, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+            s.set_newton(stern_capacitance=0.25, wall_bc='stern', mpb_radius=[3.5e-10] * N)
+            s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+            st = s.solve_stationary()
+            c, phi, _, _ = s.get_state()
+            outs.append((c, phi, s.newton_iterations(), st))
+    (c1, p1, it1, st1), (c2, p2, it2, st2) = outs
+    assert np.array_equal(it1, it2) and np.array_equal(st1, st2) and (st1 == 0).all()
+    assert np.abs(c1 - c2).max() <= 1e-9 * np.abs(c1).max() and np.abs(p1 - p2).max() <= 1e-10
+
+
+def test_not_converged_and_nan_are_reported_per_lane():
+    N, nx, B = 3, 64, 40
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 3, phi_lo=-0.6, phi_hi=0.6)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    c0[7, 1, 5] = np.nan
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    with _capi.PnpSolver(N, nx, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+        s.set_newton(maxit=3)
+        s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+        st = s.solve_stationary()
+        its = s.newton_iterations()
+    assert st[7] == 2                                    # NaN lane
+    others = np.delete(np.arange(B), 7)
+    assert set(np.unique(st[others])) <= {0, 1} and (st[others] == 1).any()
+    assert (its[st == 1] == 4).all()                     # maxit + 1 marks a failed solve
