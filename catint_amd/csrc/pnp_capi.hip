@@ -547,9 +547,11 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
       h->lane_groups = groups;
     }
     a.lane_groups = h->lane_groups;
+    const size_t vp2 = (size_t)((N + 2) / 2 * 2), cp2 = (size_t)((N + 1) / 2 * 2);
     a.lane_ts = h->lane_buf;
-    a.lane_tco = a.lane_ts + (size_t)h->lane_groups * (size_t)(N + 1) * nx * 32;
-    a.lane_rec = a.lane_tco + (size_t)h->lane_groups * (size_t)N * nx * 32;
+    a.lane_xs = a.lane_ts + (size_t)h->lane_groups * vp2 * nx * 32;
+    a.lane_tco = a.lane_xs + (size_t)h->lane_groups * vp2 * nx * 32;
+    a.lane_rec = a.lane_tco + (size_t)h->lane_groups * cp2 * nx * 32;
   } else if (newton_sweep_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0))) {
     // one team (N+1 lanes) per operating point, 64/(N+1) per wave; the workspace holds the records of the resident waves: at
     // most four per SIMD, all of the batch capacity, and 32 GiB

@@ -148,9 +148,10 @@ struct NewtonArgs {
   int64_t sweep_stride;
   int32_t sweep_blocks, pad2_;           // workgroups (= waves) the sweep workspace was sized for; 0: no workspace
   // lane kernel (pnp_lane.hip: one operating point per lane): batch-innermost copies of the state and the block-Thomas records
-  double* lane_ts;                       // [groups][N+1][nx][32] concentrations + potential of 32 operating points
-  double* lane_tco;                      // [groups][N][nx][32]   previous time level
-  double* lane_rec;                      // [groups][nx][(N+1)^2 + (N+1)][32]
+  double* lane_ts;                       // [groups][nx][(N+2)/2][32][2] concentrations + potential of 32 operating points
+  double* lane_xs;                       // [groups][nx][(N+2)/2][32][2] Newton update
+  double* lane_tco;                      // [groups][nx][(N+1)/2][32][2] previous time level
+  double* lane_rec;                      // [groups][nx][((N+1)^2 + (N+1))/2][32][2]
   int64_t lane_groups;                   // groups (of 32 operating points) the three buffers hold
   int64_t lane_group0;                   // first group of this launch (the batch is walked in chunks of lane_groups)
 };

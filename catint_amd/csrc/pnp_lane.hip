@@ -23,12 +23,16 @@
 // Poisson pivot -- see block_solve in pnp_newton.hip; a pivot monitor flags lanes where that assumption fails) and the N+2
 // columns of [Ah | r'] are solved one by one, each leaving for device memory as soon as it is complete.
 //
-// Layout in HBM: batch-innermost.  The handle's state c[b][k][i] (x fastest, made for one-grid-per-wave kernels) would make
-// every lane touch its own 64-byte line, so a launch first transposes the state of each group of 32 operating points into
-// ts[group][variable][i][32] (pack kernel), works there, and transposes back (unpack kernel, which also raises the NaN
-// status).  Records rec[group][i][(N+1)^2 + (N+1)][32].  Every wave instruction then moves two contiguous 256-byte pieces.
+// Layout in HBM: batch-innermost, 16 bytes per lane.  The handle's state c[b][k][i] (x fastest, made for one-grid-per-wave kernels)
+// would make every lane touch its own 64-byte line, so a launch first transposes the state of each group of 32 operating points
+// into ts[group][i][variable pair][32][2] (pack kernel), works there, and transposes back (unpack kernel, which also raises the
+// NaN status).  Records rec[group][i][pair][32][2] in the order they are produced (t, then the columns of T), the Newton update
+// xs[group][i][pair][32][2].  Every wave instruction moves two contiguous 512-byte pieces (one per sweep direction), and a wave
+// keeps twice the bytes in flight that 8-byte accesses would allow (at most 64 vector-memory instructions are outstanding).
+// One wave per SIMD leaves nobody to hide memory latency behind, and loads complete in order BEHIND older stores (one vmcnt
+// counter): every pass therefore requests the next row's inputs before it starts on the current row (software pipeline).
 // Algorithmic traffic of one Newton iteration and operating point, in doubles per grid row: forward 2N+1 read (c, phi, c_old),
-// (N+1)(N+2) written; backward (N+1)(N+2) read, N+1 written; update 2(N+1) read, N+1 written.
+// (N+1)(N+2) written; backward (N+1)(N+2) read, N+1 written; update 2(N+1) read, N+1 written  =  2 (N+1)(N+2) + 6N + 5.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -70,21 +74,25 @@ __device__ __forceinline__ double partner(double v) { return __shfl_xor(v, 32, 6
 
 constexpr int LG = 32;      // operating points per wave (two lanes each)
 
+typedef double d2 __attribute__((ext_vector_type(2)));
+
 }  // namespace
 
 size_t newton_lane_rec_doubles(int nb, int nx) { return (size_t)nx * (size_t)(nb * nb + nb) * LG; }
-size_t newton_lane_state_doubles(int nb, int nx) { return (size_t)nx * (size_t)(2 * nb - 1) * LG; }    // ts (N+1 rows) + tco (N rows)
+// ts + xs ((N+1) variables each, padded to pairs) + tco (N, padded)
+size_t newton_lane_state_doubles(int nb, int nx) { return (size_t)nx * (size_t)(2 * ((nb + 1) / 2 * 2) + nb / 2 * 2) * LG; }
 
-// ---- state transposition: c[b][k][ldx], phi[b][ldx]  <->  ts[group][v][i][32] (v = N: potential); tco = c on the way in -----------
+// ---- state transposition: c[b][k][ldx], phi[b][ldx]  <->  ts[group][i][pair][32][2] (variable N: potential); tco = c on the way in ----
 template <bool IN>
 __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G) {
   __shared__ double tile[LG][65];
   const int N = G.N, nx = G.nx, ldx = G.ldx;
+  const int VP = (N + 2) / 2, CP = (N + 1) / 2;
   const int64_t g = blockIdx.x;
   const int i0 = blockIdx.y * 64;
   const int t = threadIdx.x;
-  double* ts = G.lane_ts + (size_t)g * (size_t)(N + 1) * nx * LG;
-  double* tco = G.lane_tco + (size_t)g * (size_t)N * nx * LG;
+  double* ts = G.lane_ts + (size_t)g * (size_t)nx * VP * LG * 2;
+  double* tco = G.lane_tco + (size_t)g * (size_t)nx * CP * LG * 2;
   const int64_t b0 = (G.lane_group0 + g) * LG;
   bool bad = false;
   for (int v = 0; v <= N; ++v) {
@@ -103,8 +111,8 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
         const int ii = rr * 8 + (t >> 5), op = t & 31;
         if (i0 + ii < nx) {
           const double val = tile[op][ii];
-          ts[((size_t)v * nx + i0 + ii) * LG + op] = val;
-          if (v < N) tco[((size_t)v * nx + i0 + ii) * LG + op] = val;
+          ts[(((size_t)(i0 + ii) * VP + (v >> 1)) * LG + op) * 2 + (v & 1)] = val;
+          if (v < N) tco[(((size_t)(i0 + ii) * CP + (v >> 1)) * LG + op) * 2 + (v & 1)] = val;
         }
       }
       __syncthreads();
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
       for (int rr = 0; rr < 8; ++rr) {
         const int ii = rr * 8 + (t >> 5), op = t & 31;
         double val = 0.0;
-        if (i0 + ii < nx) val = ts[((size_t)v * nx + i0 + ii) * LG + op];
+        if (i0 + ii < nx) val = ts[(((size_t)(i0 + ii) * VP + (v >> 1)) * LG + op) * 2 + (v & 1)];
         if (!(fabs(val) < INFINITY)) bad = true;
         tile[op][ii] = val;
       }
@@ -140,13 +148,15 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
 template <int NB, int MODE>
 __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   constexpr int N = NB - 1, NREC = NB * NB + NB;
+  constexpr int VP = (NB + 1) / 2, CP = (N + 1) / 2, RP = NREC / 2;     // 16-byte pairs per row: state / previous level / record
   constexpr bool MPB = MODE >= 1;
   __shared__ double s_cb[N][LG];             // bulk concentrations of the wave's operating points
-  __shared__ double s_rec[NREC][LG];         // the downward half's last record, handed to the upward half for the middle row
-  // largest blocks: what a row only hands to the next one (concentrations of the point ahead, two of the four edge quantities) waits in
-  // LDS while the factorisation and the column solves need every register
-  constexpr bool STASH = NB >= 9;
-  __shared__ double s_car[STASH ? 3 * N : 1][64];
+  // The record a row hands to the next one (T, t) and the LU factors of D' do not both fit the register file next to everything
+  // else once the blocks are 8 x 8 or 9 x 9: the first TL columns of T then live in LDS (written as they are solved, read back
+  // column by column when the next row forms D'), the rest and t stay in registers.  4 waves per CU: at most 40 KiB each.
+  constexpr int TL = NB >= 9 ? 8 : (NB >= 8 ? 5 : 0);
+  constexpr int TR = NB - TL;                // columns of T in registers
+  __shared__ double s_T[TL > 0 ? TL * NB : 1][64];
   const int lane = threadIdx.x, o = lane & 31;
   const bool side = lane >= 32;              // false: from the wall upwards; true: from the bulk downwards
   const double sgn = side ? -1.0 : 1.0;
@@ -157,18 +167,22 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   const int64_t b_raw = (G.lane_group0 + g) * LG + o;
   const bool valid = b_raw < G.B && !(G.lane_mask && !G.lane_mask[b_raw < G.B ? b_raw : 0]);
   const int64_t b = b_raw < G.B ? b_raw : G.B - 1;      // (parameter loads of the padding lanes stay in range)
-  double* ts = G.lane_ts + (size_t)g * (size_t)NB * nx * LG + o;
-  double* tco = G.lane_tco + (size_t)g * (size_t)N * nx * LG + o;
-  double* rec = G.lane_rec + (size_t)g * (size_t)nx * NREC * LG + o;
-  auto TS = [&](int v, int i) -> double& { return ts[((size_t)v * nx + i) * LG]; };
-  auto CO = [&](int k, int i) -> double& { return tco[((size_t)k * nx + i) * LG]; };
-  auto REC = [&](int i, int e) -> double& { return rec[((size_t)i * NREC + e) * LG]; };
+  d2* ts = (d2*)G.lane_ts + (size_t)g * (size_t)nx * VP * LG + o;
+  d2* xs = (d2*)G.lane_xs + (size_t)g * (size_t)nx * VP * LG + o;
+  d2* tco = (d2*)G.lane_tco + (size_t)g * (size_t)nx * CP * LG + o;
+  d2* rec = (d2*)G.lane_rec + (size_t)g * (size_t)nx * RP * LG + o;
+  auto TS = [&](int i, int p) -> d2& { return ts[((size_t)i * VP + p) * LG]; };
+  auto XS = [&](int i, int p) -> d2& { return xs[((size_t)i * VP + p) * LG]; };
+  auto CO = [&](int i, int p) -> d2& { return tco[((size_t)i * CP + p) * LG]; };
+  auto REC = [&](int i, int p) -> d2& { return rec[((size_t)i * RP + p) * LG]; };
   const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
   if (!side) {
 #pragma unroll
     for (int k = 0; k < N; ++k) s_cb[k][o] = G.cbulk[(size_t)b * N + k];
   }
   __syncthreads();
+  // row visited by the lane in forward step s (clamped to a valid row where the lane rests)
+  auto fwd_row = [&](int s) { return side ? (s < n_dn ? nx - 1 - s : m + 1) : (s < m ? s : m); };
 
   bool have = valid, fresh = true;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
@@ -188,24 +202,47 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     double hc[N], hphi, hw = 0.0, hinv = 1.0;             // the point "here"
     double bphi = 0.0, binv = 1.0;                        // behind: potential, 1/(1 - phi0)
     double eJ[N], eBd[N], eBn[N], eJu[N];                 // behind edge as the point here sees it: outflow, own / neighbour weight, dJ/du
-    double T[NB][NB], t[NB];                              // behind record: T[j][r] = element (r, j) of D'^-1 Ah, t = D'^-1 r'
+    double Tr[TR][NB], t[NB];                             // behind record: T[j][r] = element (r, j) of D'^-1 Ah, t = D'^-1 r'
+    auto Tget = [&](const int j, const int r) { return j < TL ? s_T[(j < TL ? j : 0) * NB + r][lane] : Tr[j >= TL ? j - TL : 0][r]; };
+    auto Tset = [&](const int j, const int r, double v) {
+      if (j < TL) s_T[(j < TL ? j : 0) * NB + r][lane] = v;
+      else Tr[j >= TL ? j - TL : 0][r] = v;
+    };
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       t[j] = 0.0;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) T[j][r] = 0.0;
+      for (int r = 0; r < NB; ++r) Tset(j, r, 0.0);
     }
+    // inputs of the next row, requested one row ahead: the point ahead, the previous time level, the grid weights
+    d2 p_a[VP], p_co[CP];
+    double p_vi, p_wea, p_web;
+    auto request = [&](int s) {
+      const int i = fwd_row(s);
+      const int ia = side ? i - 1 : i + 1;
+#pragma unroll
+      for (int p = 0; p < VP; ++p) p_a[p] = TS(ia, p);
+#pragma unroll
+      for (int p = 0; p < CP; ++p) p_co[p] = CO(i, p);
+      p_vi = G.gv[i];
+      p_wea = G.gw[side ? i - 1 : i];
+      p_web = G.gw[side ? i : (i > 0 ? i - 1 : 0)];
+    };
     {
       const int i = side ? nx - 1 : 0;
+      d2 h2[VP];
+#pragma unroll
+      for (int p = 0; p < VP; ++p) h2[p] = TS(i, p);
+      request(0);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
-        hc[k] = TS(k, i);
+        hc[k] = h2[k >> 1][k & 1];
         eJ[k] = 0.0;
         eBd[k] = 0.0;
         eBn[k] = 0.0;
         eJu[k] = 0.0;
       }
-      hphi = TS(N, i);
+      hphi = h2[N >> 1][N & 1];
       if constexpr (MPB) {
         double f = 0.0;
 #pragma unroll
@@ -218,22 +255,30 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     for (int s = 0; s < S; ++s) {
       const bool last = s == S - 1;     // the middle row: upward half only
       const bool act = last ? !side : (side || s < m);
+      // this row's inputs have arrived during the previous row; the next row's are requested before this row's stores are issued
+      double ac[N], aphi, co[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        ac[k] = p_a[k >> 1][k & 1];
+        co[k] = p_co[k >> 1][k & 1];
+      }
+      aphi = p_a[N >> 1][N & 1];
+      const double vi = p_vi, wea = p_wea, web_ = p_web;
+      if (!last) request(s + 1);
+      // middle row: the upward half needs the downward half's final record (row m+1).  The columns kept in LDS it reads from its
+      // partner lane's slots; the rest it reads back from the record in device memory, which the same wave has just written: the
+      // release makes those stores visible at the L2, the reads are agent-scope loads that do not look into this CU's L1 (which may
+      // hold the previous iteration's lines of that row)
       if (last) {
-        // the downward half's final record travels through LDS (written in its last active row below)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       if (act) {
-        const int i = side ? nx - 1 - s : (last ? m : s);
-        const int ia = side ? i - 1 : i + 1;                        // ahead (always inside the grid: 0 < m < nx-1 ... see launcher)
+        const int i = fwd_row(s);
         const bool firstrow = s == 0;
         const bool wall = firstrow && !side, bulk = firstrow && side;
         // ---- the point ahead and the edge towards it --------------------------------------------------------------------
-        double ac[N], aphi, aw = 0.0, ainv = 1.0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) ac[k] = TS(k, ia);
-        aphi = TS(N, ia);
+        double aw = 0.0, ainv = 1.0;
         if constexpr (MPB) {
           double f = 0.0;
 #pragma unroll
@@ -242,9 +287,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           ainv = 1.0 / (1.0 - f);
         }
         const double wa = bulk ? 0.0 : 1.0, wb = firstrow ? 0.0 : 1.0;
-        const double vi = G.gv[i];
         const double ws = bulk ? 0.0 : vi;
-        const double wea = G.gw[side ? i - 1 : i], web = firstrow ? 0.0 : G.gw[side ? i : i - 1];
+        const double web = firstrow ? 0.0 : web_;
         double aJ[N], aBd[N], aBn[N], aJu[N];
         {
           const double dphi = aphi - hphi, dw = aw - hw;
@@ -260,24 +304,26 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             aBd[k] = side ? e.Bm : e.Bp;
             aBn[k] = side ? e.Bp : e.Bm;
             aJu[k] = e.Ju;
-            if constexpr (STASH) {
-              s_car[k][lane] = ac[k];
-              s_car[N + k][lane] = aJ[k];
-              s_car[2 * N + k][lane] = aBd[k];
-            }
           }
         }
         // ---- right-hand side and the diagonal block's ingredients ---------------------------------------------------------
         double rhs[NB], diag[N], Js[N];
         double rho = 0.0;
+        if (first) {
+#pragma unroll
+          for (int p = 0; p < CP; ++p) {
+            d2 v;
+            v[0] = hc[2 * p];
+            v[1] = 2 * p + 1 < N ? hc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
+            CO(i, p) = v;
+          }
+        }
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-          double co = hc[k];
-          if (!first) co = CO(k, i);
-          else CO(k, i) = hc[k];
+          const double cok = first ? hc[k] : co[k];
           const double sg = ws * A.sig[k];
           rho = __builtin_fma(A.peq[k], hc[k], rho);
-          double F = sg * (hc[k] - co) + wa * aJ[k] + wb * eJ[k];
+          double F = sg * (hc[k] - cok) + wa * aJ[k] + wb * eJ[k];
           if (wall) F -= G.flux[(size_t)b * N + k] * A.fl[k];
           if (bulk) F = hc[k] - s_cb[k][o];
           rhs[k] = -F;
@@ -313,7 +359,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         for (int j = 0; j <= NB; ++j) {         // j == NB: the right-hand side, with t for T[j]
           double col[NB];
 #pragma unroll
-          for (int r = 0; r < NB; ++r) col[r] = j < NB ? T[j < NB ? j : 0][r] : t[r];
+          for (int r = 0; r < NB; ++r) col[r] = j < NB ? Tget(j < NB ? j : 0, r) : t[r];
           double sj = 0.0;
           if constexpr (MPB) {
 #pragma unroll
@@ -363,7 +409,10 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           for (int j = 0; j <= NB; ++j) {
             double col[NB];
 #pragma unroll
-            for (int r = 0; r < NB; ++r) col[r] = s_rec[j * NB + r][o];
+            for (int r = 0; r < NB; ++r)
+              col[r] = j < TL ? s_T[(j < TL ? j : 0) * NB + r][lane + 32]
+                              : __hip_atomic_load((const double*)&REC(m + 1, ((j < NB ? NB + j * NB : 0) + r) >> 1) + (((j < NB ? NB + j * NB : 0) + r) & 1),
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (j == NB: the partner's t)
             double sj = 0.0;
             if constexpr (MPB) {
 #pragma unroll
@@ -410,13 +459,24 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             y[k] = acc * D[k][k];
           }
         };
+        // the record leaves in the order it is produced -- t, then the columns of T -- as 16-byte pairs: an element with an even
+        // index waits for its odd neighbour
+        double held = 0.0;
+        auto put = [&](const int e, double v) {
+          if ((e & 1) == 0) {
+            held = v;
+          } else {
+            d2 pr;
+            pr[0] = held;
+            pr[1] = v;
+            REC(i, e >> 1) = pr;
+          }
+        };
         solve(rhs, 0);
-        const bool handoff = side && s == n_dn - 1;       // the downward half's last row: its record also goes to LDS
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
           t[r] = rhs[r];                                    // (middle row: the solution x_m itself)
-          REC(i, NB * NB + r) = rhs[r];
-          if (handoff) s_rec[NB * NB + r][o] = rhs[r];
+          put(r, rhs[r]);
         }
         if (!last) {
 #pragma unroll
@@ -433,17 +493,24 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             solve(y, (MPB || j == N) ? 0 : j);
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-              T[j][r] = y[r];
-              REC(i, j * NB + r) = y[r];
-              if (handoff) s_rec[j * NB + r][o] = y[r];
+              Tset(j, r, y[r]);
+              put(NB + j * NB + r, y[r]);
             }
           }
         } else {
-          // (nothing is carried out of the middle row: fresh definitions end the live ranges of the old record here)
+          // the middle row's solution goes where the update pass looks for it; nothing is carried out of this row (fresh
+          // definitions end the live ranges of the old record here)
 #pragma unroll
-          for (int j = 0; j < NB; ++j)
+          for (int p = 0; p < VP; ++p) {
+            d2 v;
+            v[0] = rhs[2 * p];
+            v[1] = 2 * p + 1 < NB ? rhs[2 * p + 1 < NB ? 2 * p + 1 : 0] : 0.0;
+            XS(i, p) = v;
+          }
 #pragma unroll
-            for (int r = 0; r < NB; ++r) T[j][r] = 0.0;
+          for (int j = TL; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < NB; ++r) Tset(j, r, 0.0);
         }
         // ---- the point ahead becomes the point here; its edge is seen from the other end -----------------------------------
         bphi = hphi;
@@ -453,53 +520,60 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         hinv = ainv;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-          if constexpr (STASH) {
-            hc[k] = s_car[k][lane];
-            eJ[k] = -s_car[N + k][lane];
-            eBn[k] = s_car[2 * N + k][lane];
-          } else {
-            hc[k] = ac[k];
-            eJ[k] = -aJ[k];
-            eBn[k] = aBd[k];
-          }
+          hc[k] = ac[k];
+          eJ[k] = -aJ[k];
+          eBn[k] = aBd[k];
           eBd[k] = aBn[k];
           eJu[k] = aJu[k];
         }
       }
     }
     // =========================== backward: x_i = t_i - T_i x_ahead-of-the-elimination, outwards from the middle ============
-    double xm[NB];      // solution of the middle row (the upward half computed and recorded it), start of both back-substitutions
+    // (t of the middle row IS x_m; the upward half holds it, the downward half gets it from its partner lane)
+    double x[NB];
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      const double own = side ? 0.0 : REC(m, NB * NB + r);
+      const double own = side ? 0.0 : t[r];
       const double other = partner(own);          // (cross-lane: every lane takes part, the select comes afterwards)
-      xm[r] = side ? other : own;
+      x[r] = side ? other : own;
     }
-    double mphi = side ? 0.0 : fabs(xm[N]);
+    double mphi = side ? 0.0 : fabs(x[N]);
     if (!(mphi == mphi)) mphi = INFINITY;
     {
-      double x[NB];
+      auto bwd_row = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 1) : (s < m ? m - 1 - s : 0); };
+      d2 Rn[RP];
+      {
+        const int i = bwd_row(0);
 #pragma unroll
-      for (int r = 0; r < NB; ++r) x[r] = xm[r];
+        for (int p = 0; p < RP; ++p) Rn[p] = REC(i, p);
+      }
       for (int s = 0; s < n_dn; ++s) {
         const bool act = side || s < m;
+        const int i = bwd_row(s);
+        d2 R[RP];
+#pragma unroll
+        for (int p = 0; p < RP; ++p) R[p] = Rn[p];
+        if (s + 1 < n_dn) {
+          const int in = bwd_row(s + 1);
+#pragma unroll
+          for (int p = 0; p < RP; ++p) Rn[p] = REC(in, p);
+        }
         if (act) {
-          const int i = side ? m + 1 + s : m - 1 - s;
           double y[NB];
 #pragma unroll
-          for (int r = 0; r < NB; ++r) y[r] = REC(i, NB * NB + r);
+          for (int r = 0; r < NB; ++r) y[r] = R[r >> 1][r & 1];
 #pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            double col[NB];
+          for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int r = 0; r < NB; ++r) col[r] = REC(i, j * NB + r);
+            for (int r = 0; r < NB; ++r) y[r] = __builtin_fma(-R[(NB + j * NB + r) >> 1][(NB + j * NB + r) & 1], x[j], y[r]);
 #pragma unroll
-            for (int r = 0; r < NB; ++r) y[r] = __builtin_fma(-col[r], x[j], y[r]);
-          }
+          for (int r = 0; r < NB; ++r) x[r] = y[r];
 #pragma unroll
-          for (int r = 0; r < NB; ++r) {
-            x[r] = y[r];
-            REC(i, NB * NB + r) = y[r];
+          for (int p = 0; p < VP; ++p) {
+            d2 v;
+            v[0] = y[2 * p];
+            v[1] = 2 * p + 1 < NB ? y[2 * p + 1 < NB ? 2 * p + 1 : 0] : 0.0;
+            XS(i, p) = v;
           }
           const double a = fabs(y[N]);
           mphi = fmax(mphi, a);
@@ -512,41 +586,76 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
     // =========================== damping, clips, update (oracle/pnp_physical.py: newton_step) ================================
     double upd = 0.0;
-    for (int s = 0; s <= m; ++s) {
-      const bool act = side ? s < n_dn : true;
-      if (act) {
-        const int i = side ? m + 1 + s : s;
-        double du[NB], cc_[N], cn[N];
+    {
+      auto upd_row = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 1) : s; };
+      d2 xn[VP], cn2[VP];
+      {
+        const int i = upd_row(0);
 #pragma unroll
-        for (int r = 0; r < NB; ++r) du[r] = REC(i, NB * NB + r);
-        double f_old = 0.0, f_new = 0.0;
+        for (int p = 0; p < VP; ++p) {
+          xn[p] = XS(i, p);
+          cn2[p] = TS(i, p);
+        }
+      }
+      for (int s = 0; s <= m; ++s) {
+        const bool act = side ? s < n_dn : true;
+        const int i = upd_row(s);
+        d2 x2[VP], c2[VP];
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-          cc_[k] = TS(k, i);
-          const double rel = fabs(du[k]) / (fabs(cc_[k]) + fabs(s_cb[k][o]) + 1e-300);
-          upd = fmax(upd, rel);
-          if (!(du[k] == du[k])) upd = INFINITY;
-          const double t_ = __builtin_fma(lam, du[k], cc_[k]);
-          const double lo = 0.1 * cc_[k];
-          cn[k] = t_ < lo ? lo : t_;
+        for (int p = 0; p < VP; ++p) {
+          x2[p] = xn[p];
+          c2[p] = cn2[p];
+        }
+        if (s < m) {
+          const int in = upd_row(s + 1);
+#pragma unroll
+          for (int p = 0; p < VP; ++p) {
+            xn[p] = XS(in, p);
+            cn2[p] = TS(in, p);
+          }
+        }
+        if (act) {
+          double du[NB], cc_[N], cn[N];
+#pragma unroll
+          for (int r = 0; r < NB; ++r) du[r] = x2[r >> 1][r & 1];
+          double f_old = 0.0, f_new = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            cc_[k] = c2[k >> 1][k & 1];
+            const double rel = fabs(du[k]) / (fabs(cc_[k]) + fabs(s_cb[k][o]) + 1e-300);
+            upd = fmax(upd, rel);
+            if (!(du[k] == du[k])) upd = INFINITY;
+            const double t_ = __builtin_fma(lam, du[k], cc_[k]);
+            const double lo = 0.1 * cc_[k];
+            cn[k] = t_ < lo ? lo : t_;
+            if constexpr (MPB) {
+              f_old = __builtin_fma(A.vol[k], cc_[k], f_old);
+              f_new = __builtin_fma(A.vol[k], cn[k], f_new);
+            }
+          }
           if constexpr (MPB) {
-            f_old = __builtin_fma(A.vol[k], cc_[k], f_old);
-            f_new = __builtin_fma(A.vol[k], cn[k], f_new);
-          }
-        }
-        if constexpr (MPB) {
-          const double free_ = 1.0 - f_old;
-          const double target = fmax(0.1 * free_, 1e-12);
-          if ((1.0 - f_new) < target) {
-            const double theta = (free_ - target) / (f_new - f_old);
+            const double free_ = 1.0 - f_old;
+            const double target = fmax(0.1 * free_, 1e-12);
+            if ((1.0 - f_new) < target) {
+              const double theta = (free_ - target) / (f_new - f_old);
 #pragma unroll
-            for (int k = 0; k < N; ++k) cn[k] = __builtin_fma(theta, cn[k] - cc_[k], cc_[k]);
+              for (int k = 0; k < N; ++k) cn[k] = __builtin_fma(theta, cn[k] - cc_[k], cc_[k]);
+            }
           }
-        }
-        if (have) {
+          if (have) {
+            double out[2 * VP];
 #pragma unroll
-          for (int k = 0; k < N; ++k) TS(k, i) = cn[k];
-          TS(N, i) = __builtin_fma(lam, du[N], TS(N, i));
+            for (int k = 0; k < N; ++k) out[k] = cn[k];
+            out[N] = __builtin_fma(lam, du[N], c2[N >> 1][N & 1]);
+            if (NB < 2 * VP) out[2 * VP - 1] = 0.0;
+#pragma unroll
+            for (int p = 0; p < VP; ++p) {
+              d2 v;
+              v[0] = out[2 * p];
+              v[1] = out[2 * p + 1];
+              TS(i, p) = v;
+            }
+          }
         }
       }
     }
