@@ -76,6 +76,10 @@ constexpr int LG = 32;      // operating points per wave (two lanes each)
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+struct LaneParams {
+  double sig[PNP_NEWTON_MAX_SPECIES], peq[PNP_NEWTON_MAX_SPECIES];
+};
+
 }  // namespace
 
 size_t newton_lane_rec_doubles(int nb, int nx) { return (size_t)nx * (size_t)(nb * nb + nb) * LG; }
@@ -157,12 +161,17 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   constexpr int TL = NB >= 9 ? 8 : (NB >= 8 ? 5 : 0);
   constexpr int TR = NB - TL;                // columns of T in registers
   __shared__ double s_T[TL > 0 ? TL * NB : 1][64];
+  // per-species constants: with all five arrays read from the kernel arguments the scalar registers run out and are spilled to
+  // vector-register lanes (600 v_readlane / v_writelane per row).  The two arrays of the inner loops (q_k beta, ion volumes) stay
+  // scalar; those used once per row come from LDS (broadcast reads issued early in the row)
+  __shared__ LaneParams sP;
   const int lane = threadIdx.x, o = lane & 31;
   const bool side = lane >= 32;              // false: from the wall upwards; true: from the bulk downwards
   const double sgn = side ? -1.0 : 1.0;
   const int nx = G.nx;
   const int m = (nx - 1) >> 1;               // middle row
-  const int n_dn = nx - 1 - m;               // rows of the downward half (nx-1 .. m+1); the upward half has m (0 .. m-1)
+  const int n_dn = nx - 2 - m;               // rows of the downward half (nx-2 .. m+1; the bulk row nx-1 is its initial state); the
+                                             // upward half has m (0 .. m-1) and the middle row
   const int64_t g = blockIdx.x;
   const int64_t b_raw = (G.lane_group0 + g) * LG + o;
   const bool valid = b_raw < G.B && !(G.lane_mask && !G.lane_mask[b_raw < G.B ? b_raw : 0]);
@@ -180,9 +189,13 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 #pragma unroll
     for (int k = 0; k < N; ++k) s_cb[k][o] = G.cbulk[(size_t)b * N + k];
   }
+  if (lane < PNP_NEWTON_MAX_SPECIES) {
+    sP.sig[lane] = G.sig[lane];
+    sP.peq[lane] = G.peq[lane];
+  }
   __syncthreads();
   // row visited by the lane in forward step s (clamped to a valid row where the lane rests)
-  auto fwd_row = [&](int s) { return side ? (s < n_dn ? nx - 1 - s : m + 1) : (s < m ? s : m); };
+  auto fwd_row = [&](int s) { return side ? (s < n_dn ? nx - 2 - s : m + 1) : (s < m ? s : m); };
 
   bool have = valid, fresh = true;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
@@ -199,6 +212,10 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     }
     it += 1;
     // =========================== forward: both halves eliminate towards the middle ======================================
+    // (an opaque OFFSET, not an opaque pointer: the address stays a known LDS address -- ds_read, not flat_load)
+    int poff = 0;
+    asm volatile("" : "+v"(poff));
+    const LaneParams* P = (const LaneParams*)((const char*)&sP + poff);
     double hc[N], hphi, hw = 0.0, hinv = 1.0;             // the point "here"
     double bphi = 0.0, binv = 1.0;                        // behind: potential, 1/(1 - phi0)
     double eJ[N], eBd[N], eBn[N], eJu[N];                 // behind edge as the point here sees it: outflow, own / neighbour weight, dJ/du
@@ -228,11 +245,18 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       p_wea = G.gw[side ? i - 1 : i];
       p_web = G.gw[side ? i : (i > 0 ? i - 1 : 0)];
     };
+    double mphi = 0.0;
     {
-      const int i = side ? nx - 1 : 0;
-      d2 h2[VP];
+      // upward half: starts on the wall row with nothing behind it.  Downward half: the bulk row nx-1 (Dirichlet: identity block,
+      // x = -(state - bulk values), nothing carried ahead: T = 0) IS its initial state -- it starts on row nx-2 with the bulk point
+      // and the last edge behind it, so no row of the sweep needs switched-off edges
+      const int i = side ? nx - 2 : 0;
+      d2 h2[VP], b2[VP];
 #pragma unroll
-      for (int p = 0; p < VP; ++p) h2[p] = TS(i, p);
+      for (int p = 0; p < VP; ++p) {
+        h2[p] = TS(i, p);
+        b2[p] = TS(nx - 1, p);
+      }
       request(0);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
@@ -246,15 +270,58 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       if constexpr (MPB) {
         double f = 0.0;
 #pragma unroll
-        for (int k = 0; k < N; ++k) f = __builtin_fma(A.vol[k], hc[k], f);
+        for (int k = 0; k < N; ++k) f = __builtin_fma(G.vol[k], hc[k], f);
         hw = -log1p_sc(-f);
         hinv = 1.0 / (1.0 - f);
       }
+      if (side) {
+        double bc[N], bw = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) bc[k] = b2[k >> 1][k & 1];
+        bphi = b2[N >> 1][N & 1];
+        if constexpr (MPB) {
+          double f = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) f = __builtin_fma(G.vol[k], bc[k], f);
+          bw = -log1p_sc(-f);
+          binv = 1.0 / (1.0 - f);
+        }
+        const double we = G.gw[nx - 2];
+        const double dphi = bphi - hphi, dw = bw - hw;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const LEdge e = lane_edge_flux(__builtin_fma(G.qb[k], dphi, dw), hc[k], bc[k], we);     // left: row nx-2, right: the bulk row
+          eJ[k] = e.J;
+          eBd[k] = e.Bp;
+          eBn[k] = e.Bm;
+          eJu[k] = e.Ju;
+          t[k] = -(bc[k] - s_cb[k][o]);
+        }
+        t[N] = -(bphi - phiB);
+        mphi = fabs(t[N]);
+        if (!(mphi == mphi)) mphi = INFINITY;
+#pragma unroll
+        for (int p = 0; p < VP; ++p) {
+          d2 v;
+          v[0] = t[2 * p];
+          v[1] = 2 * p + 1 < NB ? t[2 * p + 1 < NB ? 2 * p + 1 : 0] : 0.0;
+          XS(nx - 1, p) = v;
+        }
+        if (first) {
+#pragma unroll
+          for (int p = 0; p < CP; ++p) {
+            d2 v;
+            v[0] = bc[2 * p];
+            v[1] = 2 * p + 1 < N ? bc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
+            CO(nx - 1, p) = v;
+          }
+        }
+      }
     }
-    const int S = n_dn + 1;             // n_dn row steps (the upward half rests in the last one when nx is even), then the middle row
+    const int S = (n_dn > m ? n_dn : m) + 1;     // row steps of the longer half (the other one rests in the last of them), then the middle row
     for (int s = 0; s < S; ++s) {
       const bool last = s == S - 1;     // the middle row: upward half only
-      const bool act = last ? !side : (side || s < m);
+      const bool act = last ? !side : (side ? s < n_dn : s < m);
       // this row's inputs have arrived during the previous row; the next row's are requested before this row's stores are issued
       double ac[N], aphi, co[N];
 #pragma unroll
@@ -274,28 +341,27 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         __builtin_amdgcn_wave_barrier();
       }
       if (act) {
+        asm volatile("" : "+v"(poff));    // (the constants are read again in this row instead of living in registers across rows)
+        P = (const LaneParams*)((const char*)&sP + poff);
         const int i = fwd_row(s);
-        const bool firstrow = s == 0;
-        const bool wall = firstrow && !side, bulk = firstrow && side;
+        const bool wall = s == 0 && !side;
         // ---- the point ahead and the edge towards it --------------------------------------------------------------------
         double aw = 0.0, ainv = 1.0;
         if constexpr (MPB) {
           double f = 0.0;
 #pragma unroll
-          for (int k = 0; k < N; ++k) f = __builtin_fma(A.vol[k], ac[k], f);
+          for (int k = 0; k < N; ++k) f = __builtin_fma(G.vol[k], ac[k], f);
           aw = -log1p_sc(-f);
           ainv = 1.0 / (1.0 - f);
         }
-        const double wa = bulk ? 0.0 : 1.0, wb = firstrow ? 0.0 : 1.0;
-        const double ws = bulk ? 0.0 : vi;
-        const double web = firstrow ? 0.0 : web_;
+        const double web = web_;
         double aJ[N], aBd[N], aBn[N], aJu[N];
         {
           const double dphi = aphi - hphi, dw = aw - hw;
 #pragma unroll
           for (int k = 0; k < N; ++k) {
             // the edge is evaluated in its left -> right orientation whichever way the lane walks
-            const double u = sgn * __builtin_fma(A.qb[k], dphi, dw);
+            const double u = sgn * __builtin_fma(G.qb[k], dphi, dw);
             double h_ = hc[k];              // (opaque: a select between elements of two arrays is otherwise turned into one
             asm volatile("" : "+v"(h_));    //  dynamically indexed stack array)
             const double cl = side ? ac[k] : h_, cr = side ? h_ : ac[k];
@@ -321,21 +387,16 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
           const double cok = first ? hc[k] : co[k];
-          const double sg = ws * A.sig[k];
-          rho = __builtin_fma(A.peq[k], hc[k], rho);
-          double F = sg * (hc[k] - cok) + wa * aJ[k] + wb * eJ[k];
+          const double sg = vi * P->sig[k];
+          rho = __builtin_fma(P->peq[k], hc[k], rho);
+          double F = sg * (hc[k] - cok) + aJ[k] + eJ[k];
           if (wall) F -= G.flux[(size_t)b * N + k] * A.fl[k];
-          if (bulk) F = hc[k] - s_cb[k][o];
           rhs[k] = -F;
-          diag[k] = sg + wa * aBd[k] + wb * eBd[k] + (bulk ? 1.0 : 0.0);
-          Js[k] = wa * aJu[k] + wb * eJu[k];
+          diag[k] = sg + aBd[k] + eBd[k];
+          Js[k] = aJu[k] + eJu[k];
         }
         double dNN, ahNN;           // Poisson row: diagonal entry, entry of the ahead block
-        if (bulk) {
-          rhs[N] = -(hphi - phiB);
-          dNN = 1.0;
-          ahNN = 0.0;
-        } else if (wall) {
+        if (wall) {
           if (A.wall_bc == 0) {
             rhs[N] = -(hphi - phiM);
             dNN = 1.0;
@@ -350,10 +411,10 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           dNN = -(wea + web);
           ahNN = wea;
         }
-        const double pq = (wall || bulk) ? 0.0 : vi;          // charge term of the Poisson row (interior rows only)
+        const double pq = wall ? 0.0 : vi;                    // charge term of the Poisson row (not on the wall row)
         // ---- D' = D - Bk T, r' = r - Bk t: column by column, the behind record is consumed on the way -------------------------
-        // Bk[k][j] = -bb_k [j == k] + Jb_k (qb_k [j == N] + vol_j binv) (k < N), bb = wb eBn, Jb = wb eJu;  Bk[N][N] = web
-        // (Bk T)[k][j] = -bb_k T[k][j] + Jb_k (qb_k T[N][j] + binv sum_q vol_q T[q][j])
+        // Bk[k][j] = -eBn_k [j == k] + eJu_k (qb_k [j == N] + vol_j binv) (k < N);  Bk[N][N] = web
+        // (Bk T)[k][j] = -eBn_k T[k][j] + eJu_k (qb_k T[N][j] + binv sum_q vol_q T[q][j])
         double D[NB][NB];           // D[r][c], row-major
 #pragma unroll
         for (int j = 0; j <= NB; ++j) {         // j == NB: the right-hand side, with t for T[j]
@@ -363,7 +424,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           double sj = 0.0;
           if constexpr (MPB) {
 #pragma unroll
-            for (int q = 0; q < N; ++q) sj = __builtin_fma(A.vol[q], col[q], sj);
+            for (int q = 0; q < N; ++q) sj = __builtin_fma(G.vol[q], col[q], sj);
             sj *= binv;
           }
           const double tN = col[N];
@@ -371,15 +432,15 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           for (int k = 0; k < N; ++k) {
             double v;
             if (j == NB) v = rhs[k];
-            else if (j == N) v = -A.qb[k] * Js[k];
-            else v = (MPB ? -Js[k] * (A.vol[j < N ? j : 0] * hinv) : 0.0) + (j == k ? diag[k] : 0.0);
-            v = __builtin_fma(wb * eBn[k], col[k], v);
-            v = __builtin_fma(-(wb * eJu[k]), __builtin_fma(A.qb[k], tN, sj), v);
+            else if (j == N) v = -G.qb[k] * Js[k];
+            else v = (MPB ? -Js[k] * (G.vol[j < N ? j : 0] * hinv) : 0.0) + (j == k ? diag[k] : 0.0);
+            v = __builtin_fma(eBn[k], col[k], v);
+            v = __builtin_fma(-eJu[k], __builtin_fma(G.qb[k], tN, sj), v);
             if (j == NB) rhs[k] = v;
             else D[k][j < NB ? j : 0] = v;
           }
           if (j == NB) rhs[N] = __builtin_fma(-web, tN, rhs[N]);
-          else D[N][j < NB ? j : 0] = __builtin_fma(-web, tN, j == N ? dNN : pq * A.peq[j < N ? j : 0]);
+          else D[N][j < NB ? j : 0] = __builtin_fma(-web, tN, j == N ? dNN : pq * P->peq[j < N ? j : 0]);
         }
         // ---- implicit wall kinetics (fill_row in pnp_newton.hip): rate K g(c_s) E joins the wall flux -------------------------
         if (wall && A.n_wk > 0) {
@@ -402,7 +463,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             }
           }
         }
-        // ahead block Ah[k][j] = wa (-aBn_k [j == k] + aJu_k (qb_k [j == N] + vol_j ainv)) (k < N);  Ah[N][N] = ahNN
+        // ahead block Ah[k][j] = -aBn_k [j == k] + aJu_k (qb_k [j == N] + vol_j ainv) (k < N);  Ah[N][N] = ahNN
         if (last) {
           // ---- middle row: the downward half's record (row m+1) enters the same way -------------------------------------------
 #pragma unroll
@@ -416,14 +477,14 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             double sj = 0.0;
             if constexpr (MPB) {
 #pragma unroll
-              for (int q = 0; q < N; ++q) sj = __builtin_fma(A.vol[q], col[q], sj);
+              for (int q = 0; q < N; ++q) sj = __builtin_fma(G.vol[q], col[q], sj);
               sj *= ainv;
             }
 #pragma unroll
             for (int k = 0; k < N; ++k) {
               double v = j == NB ? rhs[k] : D[k][j < NB ? j : 0];
               v = __builtin_fma(aBn[k], col[k], v);
-              v = __builtin_fma(-aJu[k], __builtin_fma(A.qb[k], col[N], sj), v);
+              v = __builtin_fma(-aJu[k], __builtin_fma(G.qb[k], col[N], sj), v);
               if (j == NB) rhs[k] = v;
               else D[k][j < NB ? j : 0] = v;
             }
@@ -485,9 +546,9 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
               double v;
-              if (j == N) v = aJu[k] * A.qb[k];
-              else v = (MPB ? aJu[k] * (A.vol[j] * ainv) : 0.0) - (j == k ? aBn[k] : 0.0);
-              y[k] = wa * v;
+              if (j == N) v = aJu[k] * G.qb[k];
+              else v = (MPB ? aJu[k] * (G.vol[j] * ainv) : 0.0) - (j == k ? aBn[k] : 0.0);
+              y[k] = v;
             }
             y[N] = j == N ? ahNN : 0.0;
             solve(y, (MPB || j == N) ? 0 : j);
@@ -537,23 +598,26 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       const double other = partner(own);          // (cross-lane: every lane takes part, the select comes afterwards)
       x[r] = side ? other : own;
     }
-    double mphi = side ? 0.0 : fabs(x[N]);
-    if (!(mphi == mphi)) mphi = INFINITY;
+    if (!side) {
+      mphi = fabs(x[N]);
+      if (!(mphi == mphi)) mphi = INFINITY;
+    }
     {
-      auto bwd_row = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 1) : (s < m ? m - 1 - s : 0); };
+      const int nb_ = n_dn > m ? n_dn : m;
+      auto bwd_row = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 2) : (s < m ? m - 1 - s : 0); };
       d2 Rn[RP];
       {
         const int i = bwd_row(0);
 #pragma unroll
         for (int p = 0; p < RP; ++p) Rn[p] = REC(i, p);
       }
-      for (int s = 0; s < n_dn; ++s) {
-        const bool act = side || s < m;
+      for (int s = 0; s < nb_; ++s) {
+        const bool act = side ? s < n_dn : s < m;
         const int i = bwd_row(s);
         d2 R[RP];
 #pragma unroll
         for (int p = 0; p < RP; ++p) R[p] = Rn[p];
-        if (s + 1 < n_dn) {
+        if (s + 1 < nb_) {
           const int in = bwd_row(s + 1);
 #pragma unroll
           for (int p = 0; p < RP; ++p) Rn[p] = REC(in, p);
@@ -587,7 +651,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     // =========================== damping, clips, update (oracle/pnp_physical.py: newton_step) ================================
     double upd = 0.0;
     {
-      auto upd_row = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 1) : s; };
+      const int nu_ = n_dn + 1 > m + 1 ? n_dn + 1 : m + 1;
+      auto upd_row = [&](int s) { return side ? (s <= n_dn ? m + 1 + s : nx - 1) : (s <= m ? s : m); };
       d2 xn[VP], cn2[VP];
       {
         const int i = upd_row(0);
@@ -597,8 +662,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           cn2[p] = TS(i, p);
         }
       }
-      for (int s = 0; s <= m; ++s) {
-        const bool act = side ? s < n_dn : true;
+      for (int s = 0; s < nu_; ++s) {
+        const bool act = side ? s <= n_dn : s <= m;
         const int i = upd_row(s);
         d2 x2[VP], c2[VP];
 #pragma unroll
@@ -606,7 +671,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           x2[p] = xn[p];
           c2[p] = cn2[p];
         }
-        if (s < m) {
+        if (s + 1 < nu_) {
           const int in = upd_row(s + 1);
 #pragma unroll
           for (int p = 0; p < VP; ++p) {
@@ -629,8 +694,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             const double lo = 0.1 * cc_[k];
             cn[k] = t_ < lo ? lo : t_;
             if constexpr (MPB) {
-              f_old = __builtin_fma(A.vol[k], cc_[k], f_old);
-              f_new = __builtin_fma(A.vol[k], cn[k], f_new);
+              f_old = __builtin_fma(G.vol[k], cc_[k], f_old);
+              f_new = __builtin_fma(G.vol[k], cn[k], f_new);
             }
           }
           if constexpr (MPB) {
