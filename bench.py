@@ -414,6 +414,12 @@ def main():
     if args.pmc_child:
         pmc_child(args)
         return
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher -- N ranks (one per GPU, RCCL rendezvous
+        # on 127.0.0.1) are started BEFORE anything here touches the GPU, rank 0 prints the one JSON line, the exit code is theirs.
+        # (Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` RANK is set and every process is a rank.)
+        from catint_amd.parallel import spawn_ranks
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -451,6 +457,8 @@ def main():
     B, N, nx = args.batch, args.nspecies, args.nx
     solver, (prob, c0, pb, vz, fl) = compat_solver(B, N, nx, args.method, 1000 + rank, device)
 
+    per_rank_wall = []
+
     def barrier():
         solver.synchronize()
         torch.cuda.synchronize()
@@ -467,9 +475,11 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([wall, ev_ms], device=comm_dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall, ev_ms = float(t[0]), float(t[1])
+            mine = torch.tensor([wall, ev_ms], device=comm_dev, dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank_wall[:] = [float(e[0]) for e in every]
+            wall, ev_ms = max(per_rank_wall), max(float(e[1]) for e in every)       # the contract: MAX over ranks
         return wall, ev_ms
 
     # ---- settling (untimed, not part of W): code objects loaded, clocks up (a cold GPU's clocks settle over ~0.1 s of load) ---------
@@ -626,6 +636,11 @@ def main():
             out['physical_mode'] = physical_mode(args, device, not args.no_cpu_baseline, pmc if isinstance(pmc, dict) else {}, warm_clocks)
         if gather_ms is not None:
             out['gather_ms'] = gather_ms
+            out['gather'] = {'collective': 'all_gather_into_tensor of [B_local, N+2] fp64 observables', 'backend': backend,
+                             'bytes_per_rank': int(B * (N + 2) * 8)}
+        if world > 1:
+            out['per_rank_timesteps_per_s'] = [B * args.steps / w for w in per_rank_wall]
+            out['n_ranks_launched'] = world
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(prob, c0, pb, vz, fl, args.method, args.cpu_seconds)
             if args.method == 'Crank-Nicolson':

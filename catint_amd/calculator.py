@@ -75,6 +75,12 @@ class Calculator(object):
             raise CalculatorError("calculator '%s' is not part of the MI355X transport path "
                                   "(supported: %s)" % (self.calc, ', '.join(GPU_CALCS + MOL_CALCS + PHYSICAL_CALCS)))
         self.physical = self.calc in PHYSICAL_CALCS
+        # roughness factor: every wall flux the COMSOL model prescribes is j_i = RF*flux_factor*flux_i (comsol_model.py:1000, :1134)
+        self.RF = float(self.tp.system.get('RF', 1.0)) if self.physical else 1.0
+        if self.physical and self.tp.system.get('flow rate') not in (None, 0, 0.0, '0', '0.0'):
+            # the reference adds system['flow rate'] (a number or a COMSOL expression) to the convection velocity tds.u
+            # (comsol_model.py:902-903, :918); the native solver carries no convection term -- refuse instead of ignoring it
+            raise CalculatorError("system['flow rate'] (convection) is not carried by the MI355X transport solver")
         if not self.physical and not getattr(self.tp, 'mesh_uniform', True):
             raise CalculatorError('the finite-difference integrators need a uniform mesh; graded meshes belong to calc="comsol"')
         if self.mode is None:      # COMSOL studies default to ['stat'] (transport.py:811-812); the FD integrators are transient
@@ -276,7 +282,7 @@ class Calculator(object):
         alpha = [float(r.get('alpha', 0.0)) for r in rx]
         sat = [float(r.get('saturation', 0.0)) for r in rx]
         law = any(alpha) or any(sat)
-        solver.set_wall_kinetics(species, nu, k, alpha if law else None, sat if law else None)
+        solver.set_wall_kinetics(species, nu, self.RF * k, alpha if law else None, sat if law else None)
 
     def surface_kinetic_fluxes(self, csurf, phiM, clip=False, reactions=None, vsurf=None):
         """Flux [B][N] into the electrolyte implied by set_surface_kinetics at the surface state csurf [B][N], vsurf [B] = phi(x=0)
@@ -313,11 +319,12 @@ class Calculator(object):
         pb = np.zeros((B, 4)); pb[:, 0] = phiM
         vz = np.zeros(B)
         if warm:
-            solver.set_flux(flux)
+            solver.set_flux(self.RF * np.asarray(flux, float))
             if self.mode != 'stationary':
                 solver.step(self.tp.nt - 1)
                 return solver.get_status()
             return solver.solve_stationary()
+        flux = self.RF * np.asarray(flux, float)        # what reaches the wall: j = RF * flux (comsol_model.py:1134)
         if self.mode != 'stationary':
             solver.set_batch(c0, pb, vz, flux)
             self._apply_surface_kinetics(solver, phiM)
@@ -701,7 +708,7 @@ class Calculator(object):
                     # warm start from the previous SCF iterate (restart=True of comsol.run, calculator.py:523)
                     warm = istep > 1 and self.mode == 'stationary' and not restart
                     if warm:      # fluxes in, surface state out, one device synchronisation (pnp_solve_surface)
-                        cs, vs, es, status = solver.solve_surface(flux)
+                        cs, vs, es, status = solver.solve_surface(self.RF * flux)
                     else:
                         status = self.solve_physical(solver, c0, phiM, flux, nramp=1 if istep > 1 else 8, warm=False)
                         cs, vs, es = solver.get_surface()
@@ -714,7 +721,7 @@ class Calculator(object):
                     restart = bool(stuck.any() or (status == 2).any())
                     status = np.where(stuck, 0, status)
                 else:
-                    solver.set_batch(c0, pb, vz, flux)
+                    solver.set_batch(c0, pb, vz, self.RF * flux)
                     n_first = 1 if self.calc == 'Crank-Nicolson' else 0
                     solver.step(tp.nt - n_first)
                     cs, vs, es = solver.get_surface()
@@ -732,7 +739,9 @@ class Calculator(object):
                 bad = active & (~np.isfinite(cs).all(axis=1) | (status == 2))
                 failed |= bad
                 active = active & ~bad & ((acc > self.tau_scf) | (sc < 0.0).any(axis=1))
-                if device_loop and active.any() and istep < max_iter and istep >= 2 and not restart:
+                if device_loop and active.any() and istep < max_iter and istep >= 2 and not restart and self.RF == 1.0:
+                    # (with a roughness factor the loop stays on the host: the device table would fold RF into the fluxes the
+                    #  bookkeeping of the loop sees, the reference scales only what COMSOL is given)
                     # hand the loop state over; the table with the rate constants at the full potentials is the kinetic model
                     self.surface_kinetics = kinetics
                     self._apply_surface_kinetics(solver, phiM)

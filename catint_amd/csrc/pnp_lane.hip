@@ -200,6 +200,9 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   bool have = valid, fresh = true;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
   double upd_prev = INFINITY;
+#ifdef PNP_LANE_STAMPS
+  double stamp_f = 0.0, stamp_b = 0.0, stamp_u = 0.0, stamp_n = 0.0;
+#endif
 
   for (;;) {
     if (__ballot(have) == 0ull) break;
@@ -211,6 +214,9 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       fresh = false;
     }
     it += 1;
+#ifdef PNP_LANE_STAMPS
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
     // =========================== forward: both halves eliminate towards the middle ======================================
     // (an opaque OFFSET, not an opaque pointer: the address stays a known LDS address -- ds_read, not flat_load)
     int poff = 0;
@@ -589,6 +595,9 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         }
       }
     }
+#ifdef PNP_LANE_STAMPS
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
     // =========================== backward: x_i = t_i - T_i x_ahead-of-the-elimination, outwards from the middle ============
     // (t of the middle row IS x_m; the upward half holds it, the downward half gets it from its partner lane)
     double x[NB];
@@ -648,6 +657,9 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     mphi = fmax(mphi, partner(mphi));
     double lam = 1.0;
     if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+#ifdef PNP_LANE_STAMPS
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
     // =========================== damping, clips, update (oracle/pnp_physical.py: newton_step) ================================
     double upd = 0.0;
     {
@@ -726,6 +738,15 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     }
     upd = fmax(upd, partner(upd));
     upd = fmax(upd, mphi * A.vt_inv);
+#ifdef PNP_LANE_STAMPS
+    {   // diagnosis build (tools/probe/lane_stamps.sh): cycles of the three passes of this iteration, summed per lane
+      const unsigned long long ts3 = __builtin_readcyclecounter();
+      stamp_f += (double)(ts1 - ts0);
+      stamp_b += (double)(ts2 - ts1);
+      stamp_u += (double)(ts3 - ts2);
+      stamp_n += 1.0;
+    }
+#endif
     // =========================== bookkeeping of the lane's operating point (identical in both halves) ========================
     if (have) {
       bool accept = false;
@@ -750,6 +771,14 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       }
     }
   }
+#ifdef PNP_LANE_STAMPS
+  if (lane == 0 && b_raw + 3 < G.B) {      // per wave: mean cycles per iteration of the three passes, in place of four lanes' iteration counts
+    G.iters[b_raw + 0] = (int32_t)(stamp_f / stamp_n);
+    G.iters[b_raw + 1] = (int32_t)(stamp_b / stamp_n);
+    G.iters[b_raw + 2] = (int32_t)(stamp_u / stamp_n);
+    G.iters[b_raw + 3] = (int32_t)stamp_n;
+  }
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------

@@ -2,7 +2,64 @@
 polarization observables.  Operating points are independent (the reference treats them as an MPI task
 farm, catint/calculator.py:209-212; gather of the per-rank result dicts catint/catint_io.py:167-178), so
 each rank owns one contiguous block of lanes and nothing is communicated during the solve."""
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_env(rank, world, port, base=None):
+    """Environment of one rank of a single-node job (what `torch.distributed.run` would set): the reference's task farm assigns
+    descriptor points by `itask % mpi_size != mpi_rank` (catint/calculator.py:209-212); here a rank is a process that owns one GPU."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL between processes needs it on this driver
+    return env
+
+
+def spawn_ranks(nranks, argv, extra_env=None, stdout=None, stderr=None, timeout=None):
+    """Start `nranks` child processes running `argv` (one per GPU, rendezvous on 127.0.0.1) and wait for them; returns the
+    largest exit code.  Must be called BEFORE the calling process touches the GPU (no HIP call, no torch.cuda.is_available()):
+    children of a GPU-initialised process are off limits on the GPU pool, and the parent has nothing to compute anyway.  Rank r's
+    stdout/stderr go to stdout[r] / stderr[r] when lists of files are given, else they are inherited (rank 0 prints the result)."""
+    port = free_port()
+    procs = []
+    for r in range(int(nranks)):
+        env = rank_env(r, nranks, port)
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if stdout is None else stdout[r],
+                                      stderr=None if stderr is None else stderr[r]))
+    import time
+    rc, t0 = 0, time.time()
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):      # a failed rank must not leave the others waiting in a collective
+                break
+            if timeout is not None and time.time() - t0 > timeout:
+                rc = 1
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+                rc = max(rc, 1)
+            else:
+                rc = max(rc, abs(p.returncode))
+    return rc
 
 
 def shard_bounds(B, world, rank):

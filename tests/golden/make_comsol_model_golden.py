@@ -66,8 +66,12 @@ def main():
             f.write(DRIVER)
         env = dict(os.environ, PYTHONPATH=REF, PYTHONHASHSEED='0', PYTHONDONTWRITEBYTECODE='1', OMP_NUM_THREADS='1')
         outs = {}
-        for name in ('co2r_runpy', 'co2r_numeric_flux'):
-            case = dict(next(c for c in T.CASES if c['name'] == name))
+        for name in ('co2r_runpy', 'co2r_numeric_flux', 'co2r_numeric_flux_rf2'):
+            # (the third case: the numeric-flux system with a roughness factor of 2 -- j_i = RF*flux_factor*flux_i, comsol_model.py:1134)
+            case = dict(next(c for c in T.CASES if c['name'] == name.replace('_rf2', '')))
+            if name.endswith('_rf2'):
+                case['name'] = name
+                case['system'] = dict(case['system'], RF=2.0)
             case.setdefault('comsol_args', T.RUNPY_COMSOL)
             case.setdefault('descriptors', [['phiM', [-0.5, -0.6]]])
             cj, oj = os.path.join(tmp, name + '.json'), os.path.join(tmp, name + '.out.json')

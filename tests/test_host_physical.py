@@ -256,3 +256,47 @@ def test_flux_sign_repair_of_run_single_step():
     assert tp.species['K+'].get('flux', 0.0) in (0.0, '0.0', 0)           # species outside the electrode reactions are not touched
     tp.species['CO2']['flux'] = 0.0                       # zero fluxes carry no sign
     assert not calc.flux_sign_error()
+
+
+def test_roughness_factor_scales_every_wall_flux_like_the_reference_model():
+    """j_i = RF*flux_factor*flux_i (reference catint/comsol_model.py:1134): the fluxes and kinetic rate constants that reach the
+    solver carry system['RF']; expected numbers from the j1..j7 / RF strings the reference's model generator emits for the run.py
+    system with one numeric flux and RF = 2 (tests/golden/comsol_model_runpy.json, case co2r_numeric_flux_rf2)."""
+    import json
+    import os
+    import re
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    par = json.load(open(os.path.join(gold, 'comsol_model_runpy.json')))['co2r_numeric_flux_rf2']['pairs']['param']
+    rf = float(par['RF'])
+    assert rf == 2.0
+    expected = [rf * float(re.match(r'RF\*flux_factor\*(.+)\[mol/m\^2/s\]$', par['j%d' % (i + 1)]).group(1)) for i in range(7)]
+    case = next(c for c in json.load(open(os.path.join(gold, 'transport_cases.json'))) if c['input']['name'] == 'co2r_numeric_flux')['input']
+    species = collections.OrderedDict((name, dict(d)) for name, d in case['species'])
+    system = dict(case['system'], RF=2.0)
+    if system.get('active site density') == 'run.py':
+        system['active site density'] = 9.61e-05 / 6.02214076e23 * (1e10) ** 2
+    tp = Transport(species=species, electrode_reactions=case.get('electrode_reactions'), electrolyte_reactions=case.get('electrolyte_reactions'),
+                   system=system, nx=case['nx'], descriptors={'phiM': [system['phiM']]})
+    calc = Calculator(transport=tp, calc='comsol')
+    assert calc.RF == 2.0
+    s = FakeSolver()
+    flux = np.repeat(tp.flux_bound[None, :, 0], 1, axis=0)
+    calc.solve_physical(s, np.zeros((1, tp.nspecies * tp.nx)), np.array([system['phiM']]), flux, nramp=1)
+    got = next(c for c in s.calls if c[0] == 'set_batch')[2][0]
+    assert np.allclose(got, expected, rtol=1e-12, atol=0.0), (got, expected)
+    assert np.abs(got).max() > 0
+    # warm path and kinetic rate constants
+    s = FakeSolver()
+    calc.solve_physical(s, None, np.array([system['phiM']]), flux, warm=True)
+    assert np.allclose(next(c for c in s.calls if c[0] == 'set_flux')[1][0], expected)
+    calc.set_surface_kinetics([{'species': 'CO2', 'rate': 3.0e-3, 'stoichiometry': {'CO2': -1.0, 'CO': 1.0}}])
+    s = FakeSolver()
+    calc._apply_surface_kinetics(s, np.array([system['phiM']]))
+    assert np.allclose(next(c for c in s.calls if c[0] == 'kinetics')[3], 2.0 * 3.0e-3)
+
+
+def test_convection_is_refused_not_ignored():
+    tp = make_tp([0.1], **{'flow rate': 1e-3})
+    with pytest.raises(CalculatorError, match='flow rate'):
+        Calculator(transport=tp, calc='comsol')
+    Calculator(transport=make_tp([0.1], **{'flow rate': 0.0}), calc='comsol')      # a zero velocity is no convection

@@ -69,3 +69,44 @@ def test_two_rank_gather_even_and_ragged():
     assert all('ok' in o for o in outs)
     outs = run_world(37)     # ragged: 19 + 18 lanes
     assert all('ok' in o for o in outs)
+
+
+def test_spawn_ranks_sets_the_rendezvous_environment(tmp_path):
+    """The launcher behind `python bench.py --gpus N`: N processes, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, output per rank."""
+    from catint_amd.parallel import spawn_ranks
+    code = ("import os; print(os.environ['RANK'], os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], "
+            "os.environ['MASTER_PORT'], os.environ['HSA_ENABLE_IPC_MODE_LEGACY'], os.environ.get('EXTRA'))")
+    files = [open(tmp_path / ('r%d.txt' % r), 'w') for r in range(3)]
+    rc = spawn_ranks(3, [sys.executable, '-c', code], extra_env={'EXTRA': 'x'}, stdout=files, timeout=60)
+    for f in files:
+        f.close()
+    assert rc == 0
+    rows = [open(tmp_path / ('r%d.txt' % r)).read().split() for r in range(3)]
+    assert [row[0] for row in rows] == ['0', '1', '2'] and [row[1] for row in rows] == ['0', '1', '2']
+    assert all(row[2] == '3' and row[3] == '127.0.0.1' and row[6] == 'x' for row in rows)
+    assert len({row[4] for row in rows}) == 1 and int(rows[0][4]) > 0          # one port for all ranks
+    # a failing rank is reported
+    assert spawn_ranks(2, [sys.executable, '-c', "import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)"], timeout=60) == 3
+
+
+def test_bench_gpus_flag_reaches_the_launcher(monkeypatch):
+    """bench.py --gpus N with no RANK in the environment must hand over to spawn_ranks with its own command line, before torch / HIP."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_spawn(n, argv, **kw):
+        seen['n'], seen['argv'] = n, argv
+        return 0
+
+    import catint_amd.parallel as par
+    monkeypatch.setattr(par, 'spawn_ranks', fake_spawn)
+    monkeypatch.delenv('RANK', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7', '--warmup', '2'])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert seen['n'] == 4 and seen['argv'][1].endswith('bench.py') and seen['argv'][2:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']
