@@ -33,7 +33,7 @@ SYMBOLS = [
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_integrate_dopri5', 'pnp_integrate_dop853', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
-    'pnp_set_potential', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
+    'pnp_set_potential', 'pnp_set_lanes', 'pnp_set_lane_mask', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
 ]
 
 
@@ -131,6 +131,10 @@ def load_library():
     lib.pnp_solve_stationary.argtypes = [vp, C.c_double, C.c_int32, ip]
     lib.pnp_get_newton_iterations.argtypes = [vp, ip]
     lib.pnp_set_potential.argtypes = [vp, dp]
+    lib.pnp_set_lanes.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64), dp, dp]
+    lib.pnp_set_lanes.restype = C.c_int
+    lib.pnp_set_lane_mask.argtypes = [vp, ip]
+    lib.pnp_set_lane_mask.restype = C.c_int
     lib.pnp_set_wall_kinetics.argtypes = [vp, C.c_int32, ip, dp, dp]
     lib.pnp_set_wall_kinetics.restype = C.c_int
     lib.pnp_integrate_dopri5.argtypes = [vp, C.POINTER(PnpOdeParams), C.c_int32, ip, C.c_int32, dp, ip, C.POINTER(C.c_int64), dp]
@@ -329,6 +333,23 @@ class PnpSolver(object):
 
     def set_potential(self, phi):
         self._check(self._lib.pnp_set_potential(self._h, _dptr(_f64(phi, (self.B, self.nx)))))
+
+    def set_lanes(self, lanes, c, phi=None):
+        """State of a few lanes (c [n][N][nx] or [n][N*nx], phi [n][nx] or None) without touching the rest of the batch, its counters
+        or its flags (pnp_set_lanes)."""
+        idx = np.ascontiguousarray(lanes, dtype=np.int64)
+        n = len(idx)
+        cc = _f64(np.asarray(c, float).reshape(n, self.N, self.nx), (n, self.N, self.nx))
+        pp = None if phi is None else _f64(phi, (n, self.nx))
+        self._check(self._lib.pnp_set_lanes(self._h, n, idx.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(cc), _dptr(pp)))
+
+    def set_lane_mask(self, mask=None):
+        """Only lanes with a non-zero mask take part in the following solves of the physical mode (None: all lanes again)."""
+        if mask is None:
+            self._check(self._lib.pnp_set_lane_mask(self._h, None))
+            return
+        m = np.ascontiguousarray(np.asarray(mask).astype(np.int32).reshape(self.B))
+        self._check(self._lib.pnp_set_lane_mask(self._h, _iptr(m)))
 
     # -- hot path --------------------------------------------------------------------------
     def step(self, nsteps=1, steps_per_launch=0):

@@ -159,7 +159,7 @@ class Calculator(object):
                 # status: 0 ok, 1 = the integrator gave up on the lane (nsteps / step size / stiffness: self.ode_idid)
                 out = [int(n) for n in itout if n < nt]
                 rk = s.integrate_dopri5 if self.calc == 'dopri5' else s.integrate_dop853
-                cout, idid, self.ode_stats, _ = rk(nt, out, nsteps=10000, **getattr(self, 'ode_options', {}))
+                cout, idid, self.ode_stats, _ = rk(nt, out, **dict({'nsteps': 10000}, **getattr(self, 'ode_options', {})))
                 self.ode_idid = idid
                 status = (idid < 0).astype(np.int32)
             else:
@@ -199,7 +199,7 @@ class Calculator(object):
             if self.calc in DEVICE_ODE_CALCS and getattr(self, 'ode_on_device', True):
                 out = [n for n in range(nt) if n in tp.itout]
                 rk = s.integrate_dopri5 if self.calc == 'dopri5' else s.integrate_dop853
-                cout, idid, stats, t_end = rk(nt, out, nsteps=10000, **getattr(self, 'ode_options', {}))
+                cout, idid, stats, t_end = rk(nt, out, **dict({'nsteps': 10000}, **getattr(self, 'ode_options', {})))
                 self.status = 0
                 self.ode_idid, self.ode_stats = int(idid[0]), stats[0].copy()
                 # a failed call ends the reference's loop after appending its result (:959-963): sol stops at that interval
@@ -212,7 +212,7 @@ class Calculator(object):
             if self.calc in ('lsoda', 'odeint'):     # :946-948
                 sol = integrate.odeint(lambda c, t: f_ty(t, c), tp.c0, tp.tmesh, ml=tp.nspecies, mu=tp.nspecies)
             else:                                    # :955-963 (the reference's nsteps=10000 branch)
-                r = integrate.ode(f_ty).set_integrator(self.calc, nsteps=10000, **getattr(self, 'ode_options', {}))
+                r = integrate.ode(f_ty).set_integrator(self.calc, **dict({'nsteps': 10000}, **getattr(self, 'ode_options', {})))
                 r.set_initial_value(tp.c0)
                 sol = []
                 while r.successful() and r.t < nt * dt:
@@ -223,13 +223,16 @@ class Calculator(object):
         return [np.array(sol[n, :]) for n in range(0, nt) if n in tp.itout and n < len(sol)]
 
     # -- physical mode ---------------------------------------------------------------------------
-    def _physical_solver(self, B, nx=None, dx=None, dt=None):
+    def _physical_solver(self, B, nx=None, dx=None, dt=None, xmesh=None):
         """Handle of the implicit coupled solver with the boundary model of the COMSOL generator: Stern Robin wall
         (tp.system['Stern capacitance'] in muF/cm^2, ['phiPZC']; comsol_model.py:613,:982,:1167), bulk potential 0 V
         (:662-663), size-modified drift for species carrying 'MPB_radius' (:1041-1063).
         tp.system['wall potential'] = 'dirichlet' switches the Stern layer off (phi(0) = phiM)."""
         tp = self.tp
         nk = getattr(tp, 'newton', {})
+        if xmesh is not None:
+            xmesh = np.asarray(xmesh, float)
+            nx, dx = len(xmesh), float(xmesh[1] - xmesh[0])
         s = PnpSolver(nspecies=tp.nspecies, nx=tp.nx if nx is None else nx, dx=tp.dx if dx is None else dx,
                       dt=tp.dt if dt is None else dt, beta=tp.beta, eps=tp.eps, D=tp.D, charges=tp.charges, method='Newton',
                       pb_mode=0, batch_capacity=B, device=self.device)
@@ -239,7 +242,9 @@ class Calculator(object):
         s.set_newton(wall_bc='stern' if stern else 'dirichlet', stern_capacitance=cs if stern else 0.0,
                      phi_pzc=float(tp.system.get('phiPZC', 0.0)), tol=nk.get('tol', 1e-8), maxit=nk.get('maxit', 50),
                      dphi_max=nk.get('dphi_max', 0.05), mpb_radius=radii if any(radii) else None)
-        if not getattr(tp, 'mesh_uniform', True):
+        if xmesh is not None:
+            s.set_grid(xmesh)
+        elif not getattr(tp, 'mesh_uniform', True):
             s.set_grid(tp.xmesh)
         if getattr(tp, 'use_reactions', False) and getattr(tp, 'reactions', None):      # tp.reactions[r]['reactants'], ['rates']
             names = list(tp.species.keys())
@@ -270,15 +275,20 @@ class Calculator(object):
         rx = getattr(self, 'surface_kinetics', None)
         if not rx:
             return
-        del lanes      # (rate functions take the lanes' potentials; nothing else is per lane)
         names = list(self.tp.species.keys())
         species = [names.index(r['species']) if r.get('species') is not None else -1 for r in rx]
         nu = np.zeros((len(rx), len(names)))
         for i, r in enumerate(rx):
             for sp, v in r['stoichiometry'].items():
                 nu[i, names.index(sp)] = v
-        k = np.stack([np.broadcast_to(np.asarray(r['rate'](phiM) if callable(r['rate']) else r['rate'], float), phiM.shape)
-                      for r in rx], axis=1)
+        def per_lane(rate):
+            # a rate given per lane of the FULL batch (array, or a callable closing over such arrays) is cut down to the lanes of a
+            # sub-batch -- the retry ladder solves failed lanes as a batch of their own
+            v = np.asarray(rate(phiM) if callable(rate) else rate, float)
+            if lanes is not None and v.ndim == 1 and v.shape[0] != phiM.shape[0] and v.shape[0] > int(np.max(lanes)):
+                v = v[np.asarray(lanes)]
+            return np.broadcast_to(v, phiM.shape)
+        k = np.stack([per_lane(r['rate']) for r in rx], axis=1)
         alpha = [float(r.get('alpha', 0.0)) for r in rx]
         sat = [float(r.get('saturation', 0.0)) for r in rx]
         law = any(alpha) or any(sat)
@@ -305,7 +315,7 @@ class Calculator(object):
                 out[:, names.index(sp)] += v * K * g
         return out
 
-    def solve_physical(self, solver, c0, phiM, flux, nramp=8, warm=False):
+    def solve_physical(self, solver, c0, phiM, flux, nramp=8, warm=False, retry=True):
         """One transport solve of every lane (run_single_step, calculator.py:408-535).
         Stationary mode: Newton from the current state (warm) or from the bulk state.  If lanes do not converge from the
         bulk state -- or the potentials are far from phiPZC, or surface kinetics are coupled in, where that is the rule --
@@ -313,7 +323,8 @@ class Calculator(object):
         in stages of at most tp.newton['dphi_stage'] (0.2 V; 0.1 ... 0.5 V give the same answer on the CO2R example), the prescribed fluxes grow proportionally and the surface
         rate constants are evaluated at the stage potential, each stage warm-started from the previous one (the reference's
         parametric sweeps: flux_factor / PZC / CS ramps, transport.py:877-893, comsol_model.py:1147-1167).
-        Time-dependent mode: tp.nt-1 backward-Euler steps.  Returns status [B]."""
+        Time-dependent mode: tp.nt-1 backward-Euler steps.  retry=False: no rerun ladder for lanes that fail (the first solve of an
+        SCF cycle, where a lane without a solution is an expected answer).  Returns status [B]."""
         phiM = np.asarray(phiM, float)
         B = len(phiM)
         pb = np.zeros((B, 4)); pb[:, 0] = phiM
@@ -349,26 +360,46 @@ class Calculator(object):
         # only the failed lanes walk the path again, as a batch of their own, with 2, 4, 8 x the stages; what converges is patched
         # into the state of the main handle.
         self.retry_log = []
-        rungs = int(nk.get('retry_rungs', 3))
-        for rung in range(1, rungs + 1):
+        rungs = int(nk.get('retry_rungs', 3)) if retry else 0
+        mesh_rungs = int(nk.get('retry_mesh_rungs', 1)) if retry else 0
+        for rung in range(1, rungs + mesh_rungs + 1):
             bad = np.flatnonzero(st != 0)
             if len(bad) == 0:
                 break
-            with self._physical_solver(len(bad)) as sub:
-                st_sub = self._continuation(sub, np.asarray(c0)[bad], pb[bad], vz[bad], np.asarray(flux)[bad], phiM[bad], start, nst * 2 ** rung,
+            mesh = rung > rungs          # the last rungs refine the boundary mesh as well (grid_factor_bound *= 1.5, calculator.py:466-531)
+            stages = nst * 2 ** min(rung, max(rungs, 1))
+            xf = None
+            if mesh:
+                from .host import graded_mesh
+                x = np.asarray(self.tp.xmesh, float)
+                xf = graded_mesh(x[-1], (x[1] - x[0]) / 1.5 ** (rung - rungs), len(x))
+            with self._physical_solver(len(bad), xmesh=xf) as sub:
+                st_sub = self._continuation(sub, np.asarray(c0)[bad], pb[bad], vz[bad], np.asarray(flux)[bad], phiM[bad], start, stages,
                                             lanes=bad)
                 c_sub, phi_sub = sub.get_state()[:2]
             good = st_sub == 0
-            self.retry_log.append({'rung': rung, 'stages': nst * 2 ** rung, 'lanes': bad.tolist(), 'recovered': bad[good].tolist()})
+            entry = {'rung': rung, 'stages': stages, 'lanes': bad.tolist(), 'recovered': [], 'mesh_refined': bool(mesh)}
+            self.retry_log.append(entry)
             if good.any():
-                c_all, phi_all = solver.get_state()[:2]
-                c_all[bad[good]] = c_sub[good]
-                phi_all[bad[good]] = phi_sub[good]
-                solver.set_batch(c_all.reshape(B, -1), pb, vz, flux)
-                solver.set_potential(phi_all)
-                self._apply_surface_kinetics(solver, phiM)
+                c_sub = np.asarray(c_sub, float).reshape(len(bad), self.tp.nspecies, -1)[good]
+                phi_sub = np.asarray(phi_sub, float).reshape(len(bad), -1)[good]
+                if mesh:      # back onto the batch's mesh: the finer solution is the initial guess of the confirming solve there
+                    x = np.asarray(self.tp.xmesh, float)
+                    c_sub = np.stack([[np.interp(x, xf, row) for row in lane] for lane in c_sub])
+                    phi_sub = np.stack([np.interp(x, xf, row) for row in phi_sub])
+                # only the recovered lanes travel (pnp_set_lanes); counters, flags and the other lanes stay as they are ...
+                solver.set_lanes(bad[good], c_sub, phi_sub)
+                # ... and the main handle's own verdict on them is what is reported: one solve restricted to these lanes
+                mask = np.zeros(B, np.int32)
+                mask[bad[good]] = 1
+                solver.set_lane_mask(mask)
+                try:
+                    st2 = solver.solve_stationary()
+                finally:
+                    solver.set_lane_mask(None)
                 st = st.copy()
-                st[bad[good]] = 0
+                st[bad[good]] = st2[bad[good]]
+                entry['recovered'] = [int(b_) for b_ in bad[good] if st[b_] == 0]
         return st
 
     def _continuation(self, solver, c0, pb, vz, flux, phiM, start, nst, lanes=None):
@@ -658,7 +689,12 @@ class Calculator(object):
                 tp.species[sp]['surface_concentration'] = float(v)
         sc = np.repeat(np.array([[tp.species[sp]['surface_concentration'] for sp in names]], float), B, axis=0)
         if getattr(self, 'surface_init', None) is not None:      # per-lane start (initialize_surface_concentrations_from_file)
-            sc = np.array(self.surface_init, float).reshape(B, N)
+            init = np.array(self.surface_init, float)
+            self.surface_init = None          # consumed once, as the reference re-initialises once (calculator.py:242-258)
+            if init.size != B * N:
+                raise CalculatorError('surface concentrations read from a results folder hold %d values, the descriptor lattice of this '
+                                      'calculator needs %d lanes x %d species' % (init.size, B, N))
+            sc = init.reshape(B, N)
         flux = np.repeat(tp.flux_bound[None, :, 0], B, axis=0).astype(float)
         mix = np.full(B, float(self.mix_scf))
         acc = np.full(B, np.inf)
@@ -710,7 +746,7 @@ class Calculator(object):
                     if warm:      # fluxes in, surface state out, one device synchronisation (pnp_solve_surface)
                         cs, vs, es, status = solver.solve_surface(self.RF * flux)
                     else:
-                        status = self.solve_physical(solver, c0, phiM, flux, nramp=1 if istep > 1 else 8, warm=False)
+                        status = self.solve_physical(solver, c0, phiM, flux, nramp=1 if istep > 1 else 8, warm=False, retry=False)
                         cs, vs, es = solver.get_surface()
                     # Wall fluxes that would drive a concentration negative have no solution inside the positive cone the
                     # damped Newton stays in: COMSOL hands the SCF loop a negative surface concentration there

@@ -68,6 +68,7 @@ struct pnp_handle {
   double* scf_snap = nullptr;            // (N + 1) ldx B doubles: per-lane state of the last converged transport solve
   int32_t* scf_i = nullptr;              // 3 B flags + 65 counters
   const int32_t* newton_mask = nullptr;  // lanes to solve (null: all)
+  int32_t* user_mask = nullptr;          // pnp_set_lane_mask's copy
   bool newton_explicit_kinetics = false; // the wall-kinetics table feeds the prescribed fluxes instead of the Jacobian
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
   int64_t dev_bytes = 0;
@@ -109,7 +110,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->ode_buf, (void*)h->ode_int})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -375,6 +376,7 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
   h->B = B;
+  h->newton_mask = nullptr;      // (a lane mask belongs to the batch it was set for)
   h->a.B = B;
   // One contiguous upload into a staging buffer; unpack_state_kernel writes the pitched rows (zero pads: they travel through
   // the kernels untouched), the bulk Dirichlet values = last grid point of the initial state (calculator_old.py:540) and the
@@ -405,7 +407,9 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   // next one or two -- when the dispatch before it ON THIS QUEUE was one of the upload's small element-wise kernels; after a
   // wave-per-operating-point kernel (this one, or a one-step launch) it runs at full rate.  Dispatches on other queues, idle time
   // and extra synchronisation change nothing.
-  if (!getenv("CATINT_PNP_NO_POST_UPLOAD_DISPATCH")) {
+  // Only batches that can fill every SIMD in one round were affected (B = 960, 1024 with the headline kernel; B = 512 was not): smaller
+  // uploads -- the per-iteration uploads of a small compat SCF loop -- skip the extra dispatch, its buffers and its synchronisation.
+  if (h->B >= 768 && !getenv("CATINT_PNP_NO_POST_UPLOAD_DISPATCH")) {
     const int rc = ensure_potential_buffers(h);
     if (rc != PNP_OK) return rc;
     HIP_TRY(h, launch_poisson(h->a, h->lapl[0], h->v, h->gradv, h->stream));
@@ -872,6 +876,42 @@ int pnp_set_potential(pnp_handle* h, const double* phi) {
   const size_t w = (size_t)h->a.nx * sizeof(double), dp = (size_t)h->a.ldx * sizeof(double);
   HIP_TRY(h, hipMemcpy2DAsync(h->v, dp, phi, w, w, (size_t)h->B, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
+int pnp_set_lanes(pnp_handle* h, int64_t n, const int64_t* lanes, const double* c, const double* phi) {
+  if (!h || (n > 0 && (!lanes || !c))) return fail(h, PNP_EINVAL, "pnp_set_lanes: null argument");
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_set_lanes: the handle was not created with PNP_METHOD_NEWTON");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_set_lanes: call pnp_set_batch first");
+  if (n < 0) return fail(h, PNP_EINVAL, "pnp_set_lanes: n < 0");
+  for (int64_t i = 0; i < n; ++i)
+    if (lanes[i] < 0 || lanes[i] >= h->B) return fail(h, PNP_EINVAL, "pnp_set_lanes: lane index out of range");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
+  const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
+  // a handful of lanes: one strided copy per lane (N rows of the concentrations, one of the potential), all on the handle's stream
+  for (int64_t i = 0; i < n; ++i) {
+    HIP_TRY(h, hipMemcpy2DAsync(h->c + (size_t)lanes[i] * N * ldx, dp, c + (size_t)i * N * nx, w, w, (size_t)N, hipMemcpyHostToDevice,
+                                h->stream));
+    if (phi) HIP_TRY(h, hipMemcpyAsync(h->v + (size_t)lanes[i] * ldx, phi + (size_t)i * nx, w, hipMemcpyHostToDevice, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PNP_OK;
+}
+
+int pnp_set_lane_mask(pnp_handle* h, const int32_t* mask) {
+  if (!h) return PNP_EINVAL;
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_set_lane_mask: the handle was not created with PNP_METHOD_NEWTON");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_set_lane_mask: call pnp_set_batch first");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (!mask) {
+    h->newton_mask = nullptr;
+    return PNP_OK;
+  }
+  if (!h->user_mask) HIP_TRY(h, dev_alloc(h, &h->user_mask, (size_t)h->cfg.batch_capacity));
+  HIP_TRY(h, hipMemcpyAsync(h->user_mask, mask, (size_t)h->B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->newton_mask = h->user_mask;
   return PNP_OK;
 }
 

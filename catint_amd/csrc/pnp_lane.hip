@@ -786,7 +786,23 @@ bool newton_lane_supported(int nb, int nx, int mode) { return nb >= 2 && nb <= 9
 
 bool newton_lane_preferred(int nb, int nx, int64_t B, int mode) {
   if (!newton_lane_supported(nb, nx, mode)) return false;
-  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 'l';
+  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) {
+    if (f[0] == 'l') return true;
+    if (f[0] != 0) return false;           // another kernel is forced (tests, probes)
+  }
+  // Measured (tools/probe/lane_sweep.py -> profiles/r03_lane_sweep.jsonl: transient steps, steric ions, Stern wall; timesteps/s of
+  // this kernel over the best of the others).  A lane advances its operating point at a fixed pace whatever the batch (N = 8,
+  // nx = 512: 3.4 ms per Newton iteration), so its rate grows with the batch until every SIMD holds a wave (B = 32 768) and is
+  // HBM-bound from there on; the workgroup-per-point kernels saturate at a few hundred points.  Crossovers:
+  //   N >= 5:  0.4-0.6 x at B = 512, 1.3-1.7 x at 2048, 4-5 x at 8192, 8-10 x at 32 768
+  //   N = 4:   0.6-0.9 x at 2048, 1.8-3.5 x at 8192 (the pair kernel spills there)
+  //   N = 3:   0.6-0.75 x at 8192, 1.1-1.5 x at 32 768 against the pair kernel; grids too long for it (nx > 1024): 2.7 x at 8192
+  //   N = 2:   only on grids too long for the pair kernel (1.95 x at B = 8192, nx = 4096)
+  if (nb >= 6) return B >= 1280;
+  if (nb == 5) return B >= 4096;
+  const bool pair = newton_pair_threads(nb, nx) > 0;
+  if (nb == 4) return pair ? B >= 24576 : B >= 4096;
+  if (nb == 3) return !pair && B >= 4096;
   return false;
 }
 

@@ -108,7 +108,11 @@ int pnp_set_reactions(pnp_handle* h, int32_t nreactions, const int32_t* n_lhs, c
  * pb[B][4]       {potential wall, potential bulk, gradient wall, gradient bulk} = tp.pb_bound
  *                (slots not selected by cfg.pb_mode are ignored)
  * vzeta[B]       tp.system['vzeta'] (calculator_old.py:529)
- * flux[B][N]     tp.flux_bound[k,0], wall flux (calculator_old.py:531, :1001)                  */
+ * flux[B][N]     tp.flux_bound[k,0], wall flux (calculator_old.py:531, :1001)
+ * For batches of 768 operating points or more the finite-difference handle also evaluates the potential and its gradient of the
+ * uploaded state right away (two [capacity][row pitch] buffers, allocated on first use and counted in pnp_device_bytes; one more
+ * kernel and synchronisation per upload): the dispatch keeps the first large launch after an upload at the sustained rate.
+ */
 int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, const double* vzeta,
                   const double* flux);
 
@@ -257,6 +261,14 @@ int pnp_scf_cycle(pnp_handle* h, const pnp_scf_params* p, const double* nel /* [
 int pnp_get_newton_iterations(pnp_handle* h, int32_t* iters /* [B] */);
 /* Overwrite the potential rows (initial guess of the physical mode), phi[B][nx]. */
 int pnp_set_potential(pnp_handle* h, const double* phi);
+/* Overwrite the state (concentrations c[n][N][nx], potential phi[n][nx]) of the n lanes lanes[0..n) and leave every other lane, the
+ * iteration counters, the bulk values and the status flags alone: how a lane recovered elsewhere -- on a finer continuation ramp or
+ * a finer mesh, the reference's rerun ladder (catint/calculator.py:466-531) -- comes back into the batch without the whole state
+ * crossing PCIe.  phi may be NULL (potential rows unchanged). */
+int pnp_set_lanes(pnp_handle* h, int64_t n, const int64_t* lanes, const double* c, const double* phi);
+/* Restrict the following pnp_step / pnp_solve_stationary / pnp_solve_surface calls of the physical mode to the lanes with a non-zero
+ * mask[b] (the others keep state, status and iteration counters); mask == NULL: all lanes again.  The mask is copied. */
+int pnp_set_lane_mask(pnp_handle* h, const int32_t* mask /* [B] or NULL */);
 
 /* ---- read-back ------------------------------------------------------------------------------ */
 /* Any pointer may be NULL. c[B][N][nx]; v, grad_v, lapl_v [B][nx] are the Poisson solve of the

@@ -45,7 +45,7 @@ def test_config5_share_physical_mode_sweep_kernel_8192_lanes():
             full = s.get_state() if len(idx) <= 64 else None
             return cs, vs, s.newton_iterations(), s.get_status(), full
 
-    cs, vs, its, st, _ = solve(np.arange(B), 2)                     # the library's choice at this batch: the sweep kernel
+    cs, vs, its, st, _ = solve(np.arange(B), 2)                     # the library's choice at this batch: the lane kernel (pnp_lane.hip)
     assert np.all(st == 0) and np.all(np.isfinite(cs)) and cs.min() > 0 and its.min() >= 4 and its.max() <= 2 * 50
     # lane permutation: teams pick the lanes up in another order, results must follow the lanes
     perm = np.random.default_rng(3).permutation(B)
@@ -70,10 +70,10 @@ def test_config5_share_physical_mode_sweep_kernel_8192_lanes():
     assert np.abs(full[0][1] - rc).max() <= 2e-9 * np.abs(rc).max() and np.abs(full[1][1] - rphi).max() <= 2e-9 * 0.2
 
 
-def test_half_size_batch_of_large_blocks_takes_the_two_sided_sweep():
-    """4096 lanes x 8 size-modified species x 512 points (585 waves of lane teams one-sided, 1366 waves of team pairs): the library's
-    choice is the two-sided sweep -- lane permutation property, sampled lanes against the oracle incl. iteration counts, and the
-    same lanes through the one-sided sweep."""
+def test_half_size_batch_of_large_blocks_lane_kernel_and_both_sweeps():
+    """4096 lanes x 8 size-modified species x 512 points: the library's choice is the lane kernel (one operating point per lane) --
+    lane permutation property, sampled lanes against the oracle incl. iteration counts, and the same lanes through the one-sided and
+    the two-sided sweep kernels (lane teams; 585 / 1366 waves)."""
     B, N, nx = 4096, 8, 512
     prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=18, phi_max=0.2, dt_factor=0.1)
     pb = np.nan_to_num(pb)
@@ -99,12 +99,13 @@ def test_half_size_batch_of_large_blocks_takes_the_two_sided_sweep():
         rc, rphi, rit = PH.integrate(p, c0[b].reshape(N, nx), np.zeros(nx), prob.dt, 3, tol=1e-9)
         assert sum(rit) == its[b], (b, rit, its[b])
         assert np.abs(cs[b] - rc[:, 0]).max() <= 2e-9 * np.abs(rc).max() and abs(vs[b] - rphi[0]) <= 2e-9 * 0.2
-    os.environ['CATINT_NEWTON_KERNEL'] = 'sweep'
-    try:
-        cs1, vs1, its1, st1 = solve(np.arange(B), 3)
-    finally:
-        del os.environ['CATINT_NEWTON_KERNEL']
-    assert np.array_equal(its1, its) and np.abs(cs1 - cs).max() <= 1e-10 * np.abs(cs).max() and not np.array_equal(cs1, cs)
+    for kern in ('sweep', 'both'):
+        os.environ['CATINT_NEWTON_KERNEL'] = kern
+        try:
+            cs1, vs1, its1, st1 = solve(np.arange(B), 3)
+        finally:
+            del os.environ['CATINT_NEWTON_KERNEL']
+        assert np.array_equal(its1, its) and np.abs(cs1 - cs).max() <= 1e-10 * np.abs(cs).max() and not np.array_equal(cs1, cs)
 
 
 def test_config5_share_compat_mode_8192_lanes():

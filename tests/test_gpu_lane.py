@@ -142,3 +142,45 @@ def test_not_converged_and_nan_are_reported_per_lane():
     others = np.delete(np.arange(B), 7)
     assert set(np.unique(st[others])) <= {0, 1} and (st[others] == 1).any()
     assert (its[st == 1] == 4).all()                     # maxit + 1 marks a failed solve
+
+
+@pytest.mark.parametrize("kernel", ['lane', 'team'])
+def test_lane_mask_and_set_lanes(kernel, monkeypatch):
+    """pnp_set_lane_mask / pnp_set_lanes, the two entry points behind the rerun ladder (reference catint/calculator.py:466-531): a solve
+    restricted to some lanes leaves the others bit for bit alone; lanes recovered elsewhere are patched in without touching the rest
+    of the batch and the confirming solve needs one iteration."""
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    N, nx, B = 6, 64, 70
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 11)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    kw = dict(stern_capacitance=0.25, wall_bc='stern', mpb_radius=[3.5e-10] * N)
+    with _capi.PnpSolver(N, nx, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+        s.set_newton(**kw)
+        s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+        st = s.solve_stationary()
+        cref, pref = s.get_state()[:2]
+        itref = s.newton_iterations()
+        assert (st == 0).all()
+    even = np.arange(B) % 2 == 0
+    with _capi.PnpSolver(N, nx, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+        s.set_newton(**kw)
+        s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+        s.set_lane_mask(even)
+        st = s.solve_stationary()
+        c1, p1 = s.get_state()[:2]
+        it1 = s.newton_iterations()
+        assert np.array_equal(c1[even], cref[even]) and np.array_equal(p1[even], pref[even]) and np.array_equal(it1[even], itref[even])
+        assert np.array_equal(c1[~even].reshape(-1, N, nx), c0[~even]) and (p1[~even] == 0).all() and (it1[~even] == 0).all()
+        # the odd lanes arrive from elsewhere (here: the reference run, perturbed in the last digits); only they are solved again
+        lanes = np.flatnonzero(~even)
+        s.set_lanes(lanes, cref[lanes] * (1 + 1e-9), pref[lanes])
+        s.set_lane_mask(~even)
+        st = s.solve_stationary()
+        s.set_lane_mask(None)
+        c2, p2 = s.get_state()[:2]
+        it2 = s.newton_iterations()
+        assert (st == 0).all()
+        assert np.array_equal(c2[even], cref[even]) and np.array_equal(it2[even], itref[even])          # untouched by patch and solve
+        assert (it2[~even] <= 2).all() and np.abs(c2 - cref).max() <= 1e-8 * np.abs(cref).max()

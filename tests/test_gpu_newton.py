@@ -186,27 +186,34 @@ def test_two_sided_sweep_equals_the_one_sided_sweep(monkeypatch):
     assert np.abs(c1 - c2).max() <= 1e-10 * np.abs(c1).max() and np.abs(p1 - p2).max() <= 1e-11
 
 
-def test_sweep_kernel_is_the_default_for_large_batches_of_large_blocks(monkeypatch):
-    # N >= 5 species and at least 1024 waves of lane teams (10 operating points per wave at N = 5) take the sweep kernel: same
-    # answers and iteration counts as the lane-team kernel
+def test_kernel_choice_for_large_batches_of_large_blocks(monkeypatch):
+    # N >= 5 species and B >= 1280 operating points take the lane kernel (pnp_lane.hip; measured crossover, profiles/r03_lane_sweep.jsonl):
+    # the default equals the forced lane kernel bit for bit; the sweep kernels (one lane team per operating point, one- and two-sided)
+    # stay selectable and give the same answers and iteration counts as the lane-team kernel
     N, nx, B = 5, 24, 10240
+    monkeypatch.delenv('CATINT_NEWTON_KERNEL', raising=False)
     a = run_gpu_only(N, nx, B, 5)
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'lane')
+    forced = run_gpu_only(N, nx, B, 5)
+    assert np.array_equal(a[0], forced[0]) and np.array_equal(a[1], forced[1]) and np.array_equal(a[2], forced[2])
     monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'team')
     b = run_gpu_only(N, nx, B, 5)
     assert np.abs(a[0] - b[0]).max() <= 1e-9 * np.abs(b[0]).max() and np.abs(a[1] - b[1]).max() <= 1e-10
     assert np.array_equal(a[2], b[2]) and (a[2] <= 50).all()
     assert not np.array_equal(a[0], b[0])            # (two different linear solvers: not the same bits)
-    # half that batch (512 waves of teams one-sided, 1024 waves of team pairs): the two-sided sweep is the default
+    for kern in ('sweep', 'both'):
+        monkeypatch.setenv('CATINT_NEWTON_KERNEL', kern)
+        c = run_gpu_only(N, nx, B // 2, 6)
+        monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'team')
+        d = run_gpu_only(N, nx, B // 2, 6)
+        assert np.abs(c[0] - d[0]).max() <= 1e-9 * np.abs(d[0]).max() and np.array_equal(c[2], d[2])
+        assert not np.array_equal(c[0], d[0])
+    # below the crossover the lane-team kernel stays the choice
     monkeypatch.delenv('CATINT_NEWTON_KERNEL')
-    B2 = 5120
-    a2 = run_gpu_only(N, nx, B2, 6)
-    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'both')
-    forced = run_gpu_only(N, nx, B2, 6)
+    e = run_gpu_only(N, nx, 640, 7)
     monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'team')
-    b2 = run_gpu_only(N, nx, B2, 6)
-    assert np.array_equal(a2[0], forced[0]) and np.array_equal(a2[1], forced[1])      # default == forced two-sided, bit for bit
-    assert np.abs(a2[0] - b2[0]).max() <= 1e-9 * np.abs(b2[0]).max() and np.array_equal(a2[2], b2[2])
-    assert not np.array_equal(a2[0], b2[0])
+    f = run_gpu_only(N, nx, 640, 7)
+    assert np.array_equal(e[0], f[0]) and np.array_equal(e[2], f[2])
 
 
 @pytest.mark.parametrize("N,nx", [(3, 513), (2, 1030), (3, 1200)])

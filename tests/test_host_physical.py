@@ -172,14 +172,17 @@ def test_booth_stern_field():
 
 
 class LadderSolver(FakeSolver):
-    """A fake whose lanes `stuck` never converge while the handle walks fewer than `need` stages; get_state / set_potential record
-    the patching of recovered lanes."""
+    """A fake whose lanes `stuck` never converge while the handle walks fewer than `need` stages; set_lanes / set_lane_mask record
+    the patching of recovered lanes and the confirming solve restricted to them."""
 
-    def __init__(self, B, nx, N, stuck=(), need=10 ** 9):
+    def __init__(self, B, nx, N, stuck=(), need=10 ** 9, confirm_fails=()):
         FakeSolver.__init__(self)
         self.B, self.nx, self.N, self.stuck, self.need = B, nx, N, list(stuck), need
         self.stages = 0
         self.c = np.zeros((B, N, nx)); self.phi = np.zeros((B, nx))
+        self.mask = None
+        self.confirm_fails = list(confirm_fails)
+        self.grid = None
 
     def __enter__(self):
         return self
@@ -191,17 +194,26 @@ class LadderSolver(FakeSolver):
         FakeSolver.set_batch(self, c0, pb, vz, flux)
         self.c = np.array(c0, float).reshape(self.B, self.N, self.nx).copy()
 
-    def set_potential(self, phi):
-        self.phi = np.array(phi, float).copy()
-        self.calls.append(('set_potential',))
+    def set_lanes(self, lanes, c, phi=None):
+        self.calls.append(('set_lanes', list(lanes)))
+        self.c[np.asarray(lanes)] = np.asarray(c, float).reshape(len(lanes), self.N, self.nx)
+        if phi is not None:
+            self.phi[np.asarray(lanes)] = phi
+
+    def set_lane_mask(self, mask=None):
+        self.mask = None if mask is None else np.asarray(mask).copy()
+        self.calls.append(('mask', None if mask is None else list(np.flatnonzero(mask))))
 
     def get_state(self):
         return self.c.copy(), self.phi.copy(), None, None
 
     def solve_stationary(self):
-        self.stages += 1
         self.calls.append(('solve',))
         st = np.zeros(self.B, np.int32)
+        if self.mask is not None:            # confirming solve of patched lanes: their state stays, the verdict is the handle's
+            st[self.confirm_fails] = 1
+            return st
+        self.stages += 1
         if self.stages < self.need:
             st[self.stuck] = 1
         self.c[:] = 7.0 + self.stages           # a recognisable state: the stage count
@@ -210,11 +222,12 @@ class LadderSolver(FakeSolver):
 
 
 def test_failed_lanes_walk_finer_ramps_and_are_patched_back(monkeypatch):
-    """The reference's convergence ladder (calculator.py:455-531: rerun with the ramp interval halved, ...) per lane: only the failed
-    lanes go again, as their own batch, with 2, 4, 8 x the stages; what converges replaces those lanes' state in the main handle."""
+    """The reference's convergence ladder (calculator.py:455-531: rerun with the ramp interval halved, the boundary mesh refined, ...)
+    per lane: only the failed lanes go again, as their own batch, with 2, 4, 8 x the stages; what converges replaces those lanes'
+    state in the main handle (pnp_set_lanes: nothing else moves) and is confirmed by a solve of the main handle restricted to them."""
     phis = np.linspace(-0.5, -2.0, 4)
     tp = make_tp(phis)
-    tp.newton = {'retry_rungs': 3}
+    tp.newton = {'retry_rungs': 3, 'retry_mesh_rungs': 0}
     calc = Calculator(transport=tp, calc='comsol')
     main = LadderSolver(4, tp.nx, 3, stuck=[1, 3])
     subs = []
@@ -231,9 +244,58 @@ def test_failed_lanes_walk_finer_ramps_and_are_patched_back(monkeypatch):
     assert [r['stages'] for r in calc.retry_log] == [22, 44, 88] and [r['lanes'] for r in calc.retry_log] == [[1, 3], [1, 3], [3]]
     assert [r['recovered'] for r in calc.retry_log] == [[], [1], [3]]
     assert list(st) == [0, 0, 0, 0]
-    # the recovered lanes carry the sub-batches' states, the others the main handle's
+    # the recovered lanes carry the sub-batches' states, the others the main handle's; only those lanes travelled
     assert (main.c[1] == 7.0 + 44).all() and (main.phi[1] == -44).all() and (main.c[3] == 7.0 + 88).all() and (main.c[0] == 7.0 + 11).all()
-    assert [c[0] for c in main.calls].count('set_potential') == 2
+    assert [c[1] for c in main.calls if c[0] == 'set_lanes'] == [[1], [3]]
+    assert [c[1] for c in main.calls if c[0] == 'mask'] == [[1], None, [3], None]
+    assert not any(c[0] == 'set_potential' for c in main.calls)
+
+
+def test_mesh_rung_and_the_main_handles_verdict(monkeypatch):
+    """After the ramp rungs the boundary mesh is refined by 1.5 per rung (grid_factor_bound *= 1.5 in the reference's ladder): the
+    sub-batch is built on the finer graded mesh, its solution interpolated onto the batch's mesh, and what the main handle says about
+    the patched lane stands -- a lane whose confirming solve fails stays failed."""
+    phis = np.linspace(-0.5, -2.0, 3)
+    tp = make_tp(phis)
+    tp.set_graded_mesh(tp.xmesh[1] / 50.0)
+    tp.newton = {'retry_rungs': 1, 'retry_mesh_rungs': 2}
+    calc = Calculator(transport=tp, calc='comsol')
+    main = LadderSolver(3, tp.nx, 3, stuck=[0, 2], confirm_fails=[2])
+    grids = []
+
+    def fake_sub(B, xmesh=None, **kw):
+        grids.append(None if xmesh is None else np.array(xmesh))
+        return LadderSolver(B, tp.nx, 3, stuck=[] if xmesh is not None else [0, 1])       # converges only on a refined mesh
+    monkeypatch.setattr(calc, '_physical_solver', fake_sub)
+    st = calc.solve_physical(main, np.ones((3, 3 * tp.nx)), phis, np.zeros((3, 3)))
+    assert [r['mesh_refined'] for r in calc.retry_log] == [False, True, True]
+    h0 = tp.xmesh[1] - tp.xmesh[0]
+    assert grids[0] is None and np.isclose(grids[1][1] - grids[1][0], h0 / 1.5) and np.isclose(grids[2][1] - grids[2][0], h0 / 2.25)
+    assert grids[1][-1] == tp.xmesh[-1] and len(grids[1]) == tp.nx
+    assert calc.retry_log[1]['recovered'] == [0] and calc.retry_log[2]['lanes'] == [2] and calc.retry_log[2]['recovered'] == []
+    assert list(st) == [0, 0, 1]
+
+
+def test_per_lane_rate_constants_follow_the_failed_lanes_through_the_ladder(monkeypatch):
+    """A rate given as an array over the full batch (or a callable returning one) is cut down to the sub-batch of failed lanes."""
+    phis = np.linspace(-0.5, -2.0, 4)
+    tp = make_tp(phis)
+    tp.newton = {'retry_rungs': 1, 'retry_mesh_rungs': 0}
+    calc = Calculator(transport=tp, calc='comsol')
+    k_lane = np.array([1.0, 2.0, 3.0, 4.0])
+    calc.set_surface_kinetics([{'species': 'CO2', 'rate': k_lane, 'stoichiometry': {'CO2': -1.0}},
+                               {'species': 'CO2', 'rate': lambda v: 10.0 * k_lane[:len(v)] if len(v) == 4 else 10.0 * k_lane, 'stoichiometry': {'CO2': -1.0}}])
+    main = LadderSolver(4, tp.nx, 3, stuck=[1, 3])
+    subs = []
+
+    def fake_sub(B, **kw):
+        subs.append(LadderSolver(B, tp.nx, 3))
+        return subs[-1]
+    monkeypatch.setattr(calc, '_physical_solver', fake_sub)
+    st = calc.solve_physical(main, np.ones((4, 3 * tp.nx)), phis, np.zeros((4, 3)))
+    assert list(st) == [0, 0, 0, 0]
+    kin = [c for c in subs[0].calls if c[0] == 'kinetics']
+    assert kin and all(np.allclose(c[3][:, 0], [2.0, 4.0]) and np.allclose(c[3][:, 1], [20.0, 40.0]) for c in kin)
 
 
 def test_flux_sign_repair_of_run_single_step():
