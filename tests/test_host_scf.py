@@ -1,86 +1,97 @@
-"""Host logic (CPU): the batched SCF outer loop against a straight per-lane transcription of the reference's
-`run_scf_cycle` (catint/calculator.py:294-406) with a synthetic kinetics/transport pair."""
+"""Host logic (CPU): the batched SCF outer loop against the iterates of the REFERENCE's own `Calculator.run_scf_cycle` /
+`evaluate_accuracy` (catint/calculator.py:260-406).
+
+tests/golden/scf_cycle.json was written by tests/golden/make_scf_golden.py, which runs the reference's loop itself (an empty stand-in
+module named `catmap` only lets `import catint.calculator` succeed; the loop's kinetics and transport calls are replaced by the
+analytic pair below): per lane the mixed surface concentrations the kinetics saw, the fluxes, the transport's answers, the mixing
+factor, the iteration at which the loop left.  The batched loop must walk the same iterates lane by lane -- with lanes converging
+after different iteration counts, a negative surface concentration in the first iterations (clamp to 1e-20, :341-344), the decay of
+the mixing factor after 41 stalled iterations (:319-323) and a lane that never leaves the negative-concentration fallback (:332-334).
+"""
 import collections
+import json
+import os
 
 import numpy as np
+import pytest
 
-from catint_amd.transport import Transport
 from catint_amd.calculator import Calculator
-from catint_amd.units import unit_F
+from catint_amd.transport import Transport
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'scf_cycle.json')))
 
 
-def make():
-    species = collections.OrderedDict([('K+', {'bulk_concentration': 100.0}), ('OH-', {'bulk_concentration': 1e-4}),
-                                       ('CO2', {'bulk_concentration': 33.0, 'diffusion': 1.91e-9, 'symbol': 'CO_2'}),
-                                       ('CO', {'bulk_concentration': 0.0, 'diffusion': 2.23e-9, 'symbol': 'CO'})])
-    tp = Transport(species=species, system={'phiM': -0.5, 'boundary thickness': 8e-5, 'bulk_pH': 6.8}, nx=50,
-                   pb_bound={'potential': {'wall': 'phiM', 'bulk': 0.0}}, descriptors={'phiM': list(np.linspace(-0.5, -1.1, 7))})
-    return tp
+def make(case):
+    species = collections.OrderedDict((name, {k: v for k, v in d.items() if k != 'flux'}) for name, d in case['species'])
+    return Transport(species=species, system=dict(case['system']), nx=case['nx'], pb_bound=case['pb_bound'],
+                     descriptors={'phiM': list(case['phis'])})
 
 
-def kinetics(sc, phiM):
-    """Tafel-like CO2 -> CO + 2 OH-; returns fluxes [N] (educts negative)"""
-    j = 1e-7 * max(sc[2], 0.0) * np.exp(-8.0 * (phiM + 0.5))
-    return np.array([0.0, 2 * j, -j, j])
-
-
-def transport(flux, cb):
-    """diffusion-layer algebra standing in for the PDE solve: c_s = c_b + flux * L / D, may go negative"""
-    D = np.array([1.957e-9, 5.273e-9, 1.91e-9, 2.23e-9])
-    return cb + flux * 8e-5 / D
-
-
-def reference_scf_one_lane(phiM, cb, sc0, tau, mix0, nel, nprod, max_iter=1000):
-    """transcription of calculator.py:294-406 for one descriptor point"""
-    sc = sc0.copy(); mix = mix0
-    istep = 0; step_to_check = 0; acc = np.inf
-    sc_old = None; cd_old = None; flux = np.zeros(4)
-    while (acc > tau or (sc < 0).any()) and istep < max_iter:
-        istep += 1
-        if istep - step_to_check > 40:
-            mix *= 0.9; step_to_check = istep
-        if istep > 2:
-            sc = np.where(sc < 0, sc_old, mix * sc + (1 - mix) * sc_old)
-        else:
-            sc = np.where(sc < 0, 1e-20, sc)
-        sc_old = sc.copy()
-        flux = kinetics(sc, phiM)
-        sc = transport(flux, cb)
-        cd = flux * nel * unit_F / nprod / 10.
-        if istep > 1:
-            errs = [abs(p1 - p2) / p1 for p1, p2 in zip(cd, cd_old) if p1 != 0]
-            acc = max(errs)
-        cd_old = cd.copy()
-    return sc, flux, acc, istep, mix
-
-
-def test_batched_scf_equals_per_lane_reference_loop():
-    tp = make()
-    calc = Calculator(transport=tp, calc='Crank-Nicolson', dt=1e-3, tmax=1e-2, ntout=1, tau_scf=1e-6, mix_scf=0.3)
-    cb = np.array([tp.species[sp]['bulk_concentration'] for sp in tp.species])
-    nel = np.array([1, 1, 1, 2.0]); nprod = np.array([1, 1, 1, 1.0])
-    phis = np.array(tp.descriptors['phiM'])
+@pytest.mark.parametrize('entry', GOLDEN, ids=[e['input']['name'] for e in GOLDEN])
+def test_batched_scf_walks_the_reference_loops_iterates(entry):
+    case, ref = entry['input'], entry['reference']
+    tp = make(case)
+    assert list(tp.species.keys()) == ref['species_order']
+    calc = Calculator(transport=tp, calc='Crank-Nicolson', dt=1e-3, tmax=1e-2, ntout=1, tau_scf=case['tau_scf'], mix_scf=case['mix_scf'])
+    phis = np.array(case['phis'])
+    B = len(phis)
+    cb = np.array(ref['bulk'])
+    D = np.array(case['D'])
+    L = case['system']['boundary thickness']
+    kin = case['kinetics']
+    # electrode reaction CO2 + H2O + 2 e- -> CO + 2 OH-: nel = 2 and nprod = 1 for its key species CO, 1 / 1 for every other species
+    # (calculator.py:389-400)
+    nel = np.array([1.0, 1.0, 1.0, 2.0])
+    nprod = np.ones(4)
+    seen = []
 
     def flux_cb(state):
-        return np.stack([kinetics(state['surface_concentration'][i], state['phiM'][i]) for i in range(len(phis))])
+        sc, ph = state['surface_concentration'], state['phiM']
+        j = kin['k0'] * np.maximum(sc[:, kin['educt']], 0.0) * np.exp(-kin['alpha'] * (ph - kin['phi0']))
+        fl = j[:, None] * np.array(kin['nu'])[None, :]
+        seen.append({'sc_in': sc.copy(), 'flux': fl.copy(), 'surface_pH': state['surface_pH'].copy()})
+        return fl
 
     def transport_fn(flux):
-        cs = np.stack([transport(flux[i], cb) for i in range(len(phis))])
-        return cs, phis.copy(), np.zeros(len(phis))
+        cs = cb[None, :] + flux * L / D[None, :]
+        seen[-1]['sc_out'] = cs.copy()
+        return cs, phis.copy(), np.zeros(B)
 
-    out = calc.run_scf_cycle(flux_cb, nel=nel, nprod=nprod, transport_fn=transport_fn)
-    assert out['converged'].all()
-    its = []
-    for i, phi in enumerate(phis):
-        sc, flux, acc, istep, mix = reference_scf_one_lane(phi, cb, cb.copy(), 1e-6, 0.3, nel, nprod)
-        its.append(istep)
-        assert np.allclose(out['surface_concentration'][i], sc, rtol=1e-12, atol=0)
-        assert np.allclose(out['flux'][i], flux, rtol=1e-12, atol=0)
-        assert abs(out['accuracy'][i] - acc) <= 1e-12 * max(1.0, abs(acc))
-        assert abs(out['mix'][i] - mix) < 1e-15
-        assert tp.alldata[i]['species']['CO']['electrode_current_density'] == out['current_density'][i, 3]
-    # lanes converge after different iteration counts; the batch runs until the slowest one
-    assert out['iterations'] == max(its) and len(set(its)) > 1
-    # surface pH follows OH- (no H+ among the species), calculator.py:353-356; it is evaluated from the mixed
-    # surface state at the START of the last iteration, hence the loose tolerance against the final state
-    assert np.allclose(out['surface_pH'], 14 + np.log10(out['surface_concentration'][:, 1] / 1000.), rtol=0, atol=5e-3)
+    max_iter = max(l['iterations'] for l in ref['lanes'])
+    out = calc.run_scf_cycle(flux_cb, nel=nel, nprod=nprod, transport_fn=transport_fn, max_iter=max_iter)
+    for i, lane in enumerate(ref['lanes']):
+        n = lane['iterations']
+        # the iterates: what the kinetics saw, returned, and what the transport answered, iteration by iteration
+        for it, t in enumerate(lane['trace_head']):
+            assert np.allclose(seen[it]['sc_in'][i], t['sc_in'], rtol=1e-13, atol=0), (i, it)
+            assert np.allclose(seen[it]['flux'][i], t['flux'], rtol=1e-13, atol=0)
+            assert np.allclose(seen[it]['sc_out'][i], t['sc_out'], rtol=1e-13, atol=1e-300)
+            if it > 0 or not np.isnan(t['surface_pH']):
+                assert np.isclose(seen[it]['surface_pH'][i], t['surface_pH'], rtol=1e-13)
+        for k, t in enumerate(lane['trace_tail']):
+            it = n - len(lane['trace_tail']) + k
+            assert np.allclose(seen[it]['sc_in'][i], t['sc_in'], rtol=1e-12, atol=0), (i, it)
+            assert np.allclose(seen[it]['sc_out'][i], t['sc_out'], rtol=1e-12, atol=1e-300)
+        for k, t in enumerate(lane.get('trace_41_42', [])):
+            assert np.allclose(seen[40 + k]['sc_in'][i], t['sc_in'], rtol=1e-12, atol=0)
+        # where the lane left the loop: a converged lane is frozen from the reference's last iteration on
+        if lane['converged']:
+            assert out['converged'][i]
+            assert np.allclose(out['surface_concentration'][i], lane['final_sc'], rtol=1e-12, atol=0)
+            assert np.allclose(out['flux'][i], lane['final_flux'], rtol=1e-12, atol=0)
+            assert np.isclose(out['surface_pH'][i], lane['final_surface_pH'], rtol=1e-12)
+            if n < max_iter:       # (frozen: the kinetics of later iterations see the same surface state)
+                assert np.array_equal(seen[n]['sc_in'][i], seen[-1]['sc_in'][i])
+        else:
+            assert not out['converged'][i] and (out['surface_concentration'][i] < 0).any()
+        assert np.isclose(out['mix'][i], lane['final_mix'], rtol=1e-14), (out['mix'][i], lane['final_mix'])
+    assert out['iterations'] == max_iter
+    its = [l['iterations'] for l in ref['lanes']]
+    if case['name'] == 'tafel_mix03':
+        assert len(set(its)) > 1                      # lanes converge after different iteration counts; the batch runs until the slowest
+        for i in range(B):
+            assert tp.alldata[i]['species']['CO']['electrode_current_density'] == out['current_density'][i, 3]
+    if case['name'] == 'slow_mixing_decay':
+        assert [m[0] for m in ref['lanes'][0]['mix_changes'][:3]] == [1, 41, 82]      # (`istep - step_to_check > 40`)
+    if case['name'] == 'negative_surface_concentration':
+        assert all(l['negative_iterations'] == [1] for l in ref['lanes'])
