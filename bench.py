@@ -118,12 +118,19 @@ def pmc_child(args):
             item(s, inp, lambda s, w: s.step(3))
             s, inp = newton_solver(8192, 8, 512, 4444, steric=True)
             item(s, inp, lambda s, w: s.step(2))
+            s, inp = newton_solver(32768, 8, 512, 4446, steric=True)
+            item(s, inp, lambda s, w: s.step(2))
+            s, inp = newton_solver(BC_SHAPE[0], BC_SHAPE[1], BC_SHAPE[2], 4447, steric=True)
+            item(s, inp, lambda s, w: s.step(2))
 
 
-PMC_ITEMS = ['headline', 'per_step_launch', 'beyond_cache_per_step', 'beyond_cache_fused', 'physical_pair', 'physical_sweep']
+PMC_ITEMS = ['headline', 'per_step_launch', 'beyond_cache_per_step', 'beyond_cache_fused', 'physical_pair', 'physical_sweep',
+             'physical_lane_32k', 'physical_lane_config3']
 PMC_GROUPS = [['FETCH_SIZE'], ['WRITE_SIZE'],
               ['SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_INSTS_LDS', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY',
-               'SQ_ACTIVE_INST_VALU']]
+               'SQ_ACTIVE_INST_VALU'],
+              # fp64 arithmetic counted apart from the other vector instructions (moves, selects, accumulator-register copies, integer)
+              ['SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_TRANS_F64']]
 
 
 def collect_pmc(args):
@@ -141,9 +148,13 @@ def collect_pmc(args):
         for gi, grp in enumerate(PMC_GROUPS):
             d = os.path.join(tmp, 'g%d' % gi)
             r = subprocess.run([exe, '--pmc'] + grp + ['--output-format', 'csv', '-d', d, '--'] + child, cwd='/tmp', env=env,
-                               capture_output=True, text=True, timeout=240)
+                               capture_output=True, text=True, timeout=420)
             files = glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not files:
+                if gi >= 3:          # the optional fp64 split: report what the other passes gave
+                    for rec in out.values():
+                        rec['fp64_split_error'] = 'rocprofv3 pass %s failed (rc %d)' % (grp[0], r.returncode)
+                    continue
                 return {'error': 'rocprofv3 pass %s failed (rc %d): %s' % (grp[0], r.returncode, (r.stderr or r.stdout)[-300:])}
             rows = list(csv.DictReader(open(files[0])))
             disp = {}
@@ -354,36 +365,81 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
                                 'lanes_ok': ok8}
     except Exception as e:      # never let the extra line break the headline
         out['config4_shape'] = {'error': str(e)}
-    # large batch of large blocks: the sweep kernel (block Thomas, one lane team per operating point)
-    try:
-        SB = 8192
-        s8, inp = newton_solver(SB, 8, 512, 4444, device, steric=True)
+    # large batches of large blocks: the lane kernel (pnp_lane.hip: one operating point per lane, block Thomas from both ends in
+    # registers).  Its roofline is HBM: the block-Thomas records (N+1)(N+2) doubles per grid row are written by the forward pass and
+    # read by the back-substitution of EVERY Newton iteration; algorithmic bytes per lane-iteration = 8 nx (2 (N+1)(N+2) + 6 N + 5).
+    def lane_bytes(N_, nx_):
+        return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + 6 * N_ + 5)
+
+    def lane_record(LB, LN, LX, seed, steps, pmc_key, what):
+        s8, inp = newton_solver(LB, LN, LX, seed, device, steric=True)
         s8.set_batch(*inp[1:])
         s8.step(1)
         s8.synchronize()
         warm()
-        ms8 = timed_steps(s8, 4, 0)
+        ms8 = timed_steps(s8, steps, 0)
         it8 = s8.newton_iterations()
         ok8 = int((s8.get_status() == 0).sum())
         s8.set_batch(*inp[1:])
         s8.step(2)
-        ms2 = timed_steps(s8, 2, 0)
+        ms2 = timed_steps(s8, 2, 0)                # the launch shape the counters were collected on: 2 steps
         it2 = float(s8.newton_iterations().sum())
         s8.close()
-        rec = {'workload': 'batch=%d, 8 species size-modified, 512 points, Stern wall (sweep kernel)' % SB,
-               'timesteps_per_s': SB * 4 / (ms8 * 1e-3), 'newton_iterations_per_s': float(it8.sum()) / (ms8 * 1e-3), 'lanes_ok': ok8}
-        r = newton_roofline(pmc.get('physical_sweep') if isinstance(pmc, dict) else None, 0, SB, 0)
-        if r:
-            roof, lane_ops = r
-            roof['achieved_fp64_lane_ops_per_s'] = lane_ops / (ms2 * 1e-3)
-            roof['frac'] = roof['achieved_fp64_lane_ops_per_s'] / FP64_VALU_PEAK
-            roof['valu_wave_insts_per_lane_iteration'] = roof['valu_wave_insts_per_launch'] / max(it2, 1.0)
-            if 'hbm_bytes_per_launch' in roof:
-                roof['hbm_bytes_per_lane_iteration'] = roof['hbm_bytes_per_launch'] / max(it2, 1.0)
-            rec['roofline'] = roof
-        out['large_batch_8_species'] = rec
-        # half that batch: the two-sided sweep (two lane teams per operating point) is the library's choice
-        s8, inp = newton_solver(SB // 2, 8, 512, 4445, device, steric=True)
+        its = float(it8.sum())
+        alg = lane_bytes(LN, LX)
+        rec = {'workload': 'batch=%d, %d species size-modified, %d points, Stern wall, backward Euler: %s' % (LB, LN, LX, what),
+               'timesteps_per_s': LB * steps / (ms8 * 1e-3), 'newton_iterations_per_s': its / (ms8 * 1e-3),
+               'mean_newton_iterations_per_step': its / (LB * steps), 'ms_per_step': ms8 / steps, 'lanes_ok': ok8}
+        roof = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'algorithmic_bytes_per_lane_iteration': alg,
+                'achieved': alg * its / (ms8 * 1e-3) / 1e9, 'traffic': None,
+                'achieved_is': 'algorithmic bytes per Newton iteration and operating point (state + block-Thomas records, written by the '
+                               'forward pass and read by the back-substitution) x iterations / HIP-event time of the launch'}
+        roof['frac'] = roof['achieved'] / HBM_PEAK_GBS
+        pr = pmc.get(pmc_key) if isinstance(pmc, dict) else None
+        if pr and 'hbm_bytes_per_launch' in pr:
+            roof['kernel'] = pr.get('kernel')
+            roof['kernel_resources'] = {k: pr.get(k) for k in ('grid_threads', 'workgroup', 'vgpr', 'scratch_bytes')}
+            roof['traffic'] = pr['hbm_bytes_per_launch'] / max(it2, 1.0)           # per lane-iteration, like the algorithmic figure
+            roof['traffic_over_algorithmic'] = roof['traffic'] / alg
+            roof['hbm_GBs_measured'] = pr['hbm_bytes_per_launch'] / (ms2 * 1e-3) / 1e9
+            roof['hbm_frac_measured'] = roof['hbm_GBs_measured'] / HBM_PEAK_GBS
+            roof['traffic_note'] = ('a wave iterates until the slowest of its 32 operating points has finished its timesteps; lanes that '
+                                    'finished earlier still stream their records, so measured bytes per LANE-iteration exceed the '
+                                    'algorithmic figure by the spread of the iteration counts (2-step launch: ~1.2x, long launches ~1.05x)')
+            lim = limiter_from_sq(pr)
+            if lim:
+                roof['sq'] = lim
+            if 'SQ_INSTS_VALU' in pr:
+                roof['valu_wave_insts_per_lane_iteration'] = pr['SQ_INSTS_VALU'] / max(it2, 1.0)
+            f64 = [pr.get(k) for k in ('SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_TRANS_F64')]
+            if all(v is not None for v in f64) and 'SQ_INSTS_VALU' in pr:
+                n64 = float(sum(f64))
+                roof['fp64_valu'] = {'fp64_wave_insts_per_launch': n64, 'share_of_valu_insts': n64 / max(pr['SQ_INSTS_VALU'], 1.0),
+                                     'fma_share_of_fp64': f64[2] / max(n64, 1.0),
+                                     # lane-operations: 64 per wave instruction, two flops per fused multiply-add
+                                     'fp64_lane_ops_per_s': n64 * 64.0 / (ms2 * 1e-3), 'frac_of_fp64_vector_peak': n64 * 64.0 / (ms2 * 1e-3) / FP64_VALU_PEAK}
+            elif pr.get('fp64_split_error'):
+                roof['fp64_valu'] = {'error': pr['fp64_split_error']}
+        rec['roofline'] = roof
+        return rec
+
+    try:
+        out['large_batch_8_species'] = lane_record(8192, 8, 512, 4444, 10, 'physical_sweep',
+                                                   'one wave per CU (256 waves), paced by the arithmetic and the latency of a single wave')
+        out['large_batch_8_species_32k'] = lane_record(32768, 8, 512, 4446, 6, 'physical_lane_32k', 'one wave per SIMD (1024 waves)')
+    except Exception as e:
+        out['large_batch_8_species'] = {'error': str(e)}
+    try:      # one GPU's share of BASELINE configs[3] in the coupled-Newton mode
+        out['config3_share'] = lane_record(BC_SHAPE[0], BC_SHAPE[1], BC_SHAPE[2], 4447, 4, 'physical_lane_config3',
+                                           "one GPU's share of configs[3] (262144 points over 8 GPUs)")
+    except Exception as e:
+        out['config3_share'] = {'error': str(e)}
+    try:      # one GPU's share of BASELINE configs[4]: 8192 lanes x 8 species x 4096 points (24 GB of records)
+        out['config4_share'] = lane_record(8192, 8, 4096, 4448, 2, None, "one GPU's share of configs[4] (65536 points over 8 GPUs)")
+    except Exception as e:
+        out['config4_share'] = {'error': str(e)}
+    try:      # below the lane kernel's crossover: lane teams, two-sided sweep
+        s8, inp = newton_solver(1024, 8, 512, 4445, device, steric=True)
         s8.set_batch(*inp[1:])
         s8.step(1)
         s8.synchronize()
@@ -392,11 +448,11 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         it4 = s8.newton_iterations()
         ok4 = int((s8.get_status() == 0).sum())
         s8.close()
-        out['mid_batch_8_species'] = {'workload': 'batch=%d, 8 species size-modified, 512 points, Stern wall (two-sided sweep kernel)' % (SB // 2),
-                                      'timesteps_per_s': (SB // 2) * 4 / (ms4 * 1e-3), 'newton_iterations_per_s': float(it4.sum()) / (ms4 * 1e-3),
-                                      'lanes_ok': ok4}
+        out['small_batch_8_species'] = {'workload': 'batch=1024, 8 species size-modified, 512 points, Stern wall (lane-team kernels)',
+                                        'timesteps_per_s': 1024 * 4 / (ms4 * 1e-3), 'newton_iterations_per_s': float(it4.sum()) / (ms4 * 1e-3),
+                                        'lanes_ok': ok4}
     except Exception as e:
-        out['large_batch_8_species'] = {'error': str(e)}
+        out['small_batch_8_species'] = {'error': str(e)}
     if with_cpu:
         from oracle import pnp_physical as PH
         nl, ns = 2, 2

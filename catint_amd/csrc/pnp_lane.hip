@@ -751,7 +751,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     if (have) {
       bool accept = false;
       if (lam == 1.0) {
-        accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol);
+        accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
+              newton_at_rounding_floor(upd, upd_prev, A.tol);
         upd_prev = upd;
       } else {
         upd_prev = INFINITY;

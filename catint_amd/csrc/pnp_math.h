@@ -15,6 +15,19 @@ __device__ __forceinline__ double nrcp(double x) {   // v_rcp_f64 + two Newton s
   return __builtin_fma(r, e, r);
 }
 
+// Third way out of the Newton loop (besides update < tol and the quadratic error estimate): the iteration has reached its rounding
+// floor.  Near the solution a full step contracts quadratically; two consecutive full steps within 100 tol of which the second is not
+// even half the first are rounding noise of an ill-conditioned Jacobian (stiff reaction terms: cond(J) eps ~ 3e-9 in the case of
+// tests/golden/fuzz/newton_case117.json), not Newton -- without this rule such a lane iterates until the noise happens to dip below
+// tol (20 iterations on the device, 31 in the oracle, 37 in another kernel for the same state).  Same rule in oracle/pnp_physical.py.
+__device__ __forceinline__ bool newton_at_rounding_floor(double upd, double upd_prev, double tol) {
+#ifdef PNP_NO_ROUNDING_FLOOR_EXIT      // (diagnosis builds)
+  return false;
+#else
+  return upd_prev < 100.0 * tol && upd < 100.0 * tol && upd > 0.5 * upd_prev;
+#endif
+}
+
 // exp(u) - 1 for |u| >= 0.05 (smaller arguments take the Taylor branch of the caller), all constants in scalar registers.
 // The library expm1 keeps its ~10 polynomial coefficients in vector registers hoisted out of the Newton loop; in the
 // 128-register kernels they were spilled and re-read from scratch -- one dependent memory round trip per Horner step.

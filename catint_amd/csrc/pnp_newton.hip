@@ -686,7 +686,8 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
           // strict: the update itself is below tol.  With A.estimate the state is accepted as soon as the quadratic error
           // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
           // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
-          if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol)) {
+          if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
+              newton_at_rounding_floor(upd, upd_prev, A.tol)) {
             conv = true;
             break;
           }
@@ -1049,7 +1050,8 @@ __global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
           // strict: the update itself is below tol.  With A.estimate the state is accepted as soon as the quadratic error
           // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
           // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
-          if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol)) {
+          if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
+              newton_at_rounding_floor(upd, upd_prev, A.tol)) {
             conv = true;
             break;
           }
@@ -1601,7 +1603,8 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
           // strict: the update itself is below tol.  With A.estimate the state is accepted as soon as the quadratic error
           // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
           // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
-          if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol)) {
+          if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
+              newton_at_rounding_floor(upd, upd_prev, A.tol)) {
             conv = true;
             break;
           }
@@ -1863,7 +1866,8 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
     if (have) {
       bool accept = false;
       if (lam == 1.0) {
-        accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol);
+        accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
+              newton_at_rounding_floor(upd, upd_prev, A.tol);
         upd_prev = upd;
       } else {
         upd_prev = INFINITY;
@@ -2138,7 +2142,8 @@ __global__ __launch_bounds__(64, 2) void newton_sweep2_kernel(const NewtonArgs G
     if (have) {
       bool accept = false;
       if (lam == 1.0) {
-        accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol);
+        accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
+              newton_at_rounding_floor(upd, upd_prev, A.tol);
         upd_prev = upd;
       } else {
         upd_prev = INFINITY;

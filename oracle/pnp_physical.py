@@ -294,7 +294,8 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
     """Solve one backward-Euler step (or, with dt=inf, the stationary problem) by damped Newton.
     Damping (identical on the device): the whole update is scaled so that |d phi| <= dphi_max, a concentration
     never drops below 10 % of its previous iterate, and neither does the free volume fraction 1-phi0 (MPB).
-    Converged when the scaled update max(|dc_k,i|/(c_k,i + c_bulk_k), |dphi| beta max|q|) < tol on a full step.
+    Converged when the scaled update max(|dc_k,i|/(c_k,i + c_bulk_k), |dphi| beta max|q|) < tol on a full step, or when the
+    iteration sits on its rounding floor (see below).
     Returns (c, phi, iterations, history of update norms); iterations = maxit+1 if not converged."""
     c = c.copy(); phi = phi.copy()
     N = p.N
@@ -335,6 +336,11 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
             # estimate=True: also accept when two consecutive undamped iterations contract and the quadratic estimate
             # upd^2/upd_prev of the error of the state just computed is below tol
             if upd < tol or (estimate and np.isfinite(upd_prev) and upd < 0.1 * upd_prev and upd * (upd / upd_prev) < tol):
+                return c, phi, it, hist
+            # rounding floor: two consecutive full steps within 100 tol, the second not even half the first -- near the solution
+            # Newton contracts quadratically, so this is the noise of an ill-conditioned Jacobian, not progress (same rule on the
+            # device: newton_at_rounding_floor in catint_amd/csrc/pnp_math.h)
+            if upd_prev < 100.0 * tol and upd < 100.0 * tol and upd > 0.5 * upd_prev:
                 return c, phi, it, hist
             upd_prev = upd
         else:

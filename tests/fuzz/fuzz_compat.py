@@ -44,6 +44,9 @@ for case in range(ncase):
                   lax_friedrich=lf, use_migration=mig)
     if os.environ.get('FUZZ_ONLY') and case != int(os.environ['FUZZ_ONLY']):
         continue
+    if os.environ.get('FUZZ_DUMP'):          # the case as data (to freeze an outlier into a regression test)
+        np.savez_compressed(os.environ['FUZZ_DUMP'], N=N, nx=nx, B=B, method=method, lf=lf, mig=mig, D=D, q=q, dx=dx, dt=dt, pb=pbv, vz=vz,
+                            fl=fl, nsteps=nsteps, spl=spl, c0=c0, beta=BETA, eps=EPS)
     if os.environ.get('FUZZ_GROWTH'):       # one case, error against the oracle step by step: rounding amplification or a discrepancy?
         for ns in (1, 2, 3, 5, 8, nsteps):
             with solver_from_problem(p, method, batch_capacity=B) as s:

@@ -212,3 +212,49 @@ def test_config3_co2r_sweep_4096_lanes_against_the_oracle():
     j = calc.kinetic_flux[:, names.index('CO')]
     assert j[0] > 0 and (np.diff(j[:2000]) > 0).all()          # Tafel rise along the first half of the sweep
     assert j.max() < tp.D[names.index('CO2')] * cb[names.index('CO2')] / tp.xmesh[-1]      # below the pure-diffusion limit
+
+
+# ---- configs[2]: the SCF outer loop of the 4096-point sweep (kinetics <-> transport, calculator.py:294-406) on the device --------------
+def test_config3_scf_outer_loop_4096_lanes_device_loop_equals_host_loop():
+    """BASELINE configs[2] is a 4096-point polarization sweep WITH the SCF outer loop.  CatMAP is not available; the kinetic model is
+    the Tafel law of tests/test_gpu_calculator.py (first order in the surface CO2 concentration), on which explicit mixing with the
+    reference's mix_scf = 0.02 (run.py:95) converges: 4096 voltages from -0.6 to -1.4 V as one batch through pnp_scf_cycle (mixing,
+    fallback, accuracy, mix decay per lane on the device, transport solves masked to the lanes still iterating), against (a) the
+    batched HOST loop -- itself pinned to the reference's run_scf_cycle, tests/test_host_scf.py -- driving the same GPU transport
+    solves with the law as a Python callback, and (b) the analytic fixed point of a neutral species."""
+    import collections
+    from catint_amd.calculator import Calculator
+    from catint_amd.transport import Transport
+    B = 4096
+    phis = list(np.linspace(-0.6, -1.4, B))
+    rate = lambda phiM: 1e-4 * np.exp(-12.0 * (phiM + 0.6))       # noqa: E731
+    kin = [{'species': 'CO2', 'rate': rate, 'stoichiometry': {'CO2': -1.0, 'CO': 1.0}}]
+
+    def make_tp():
+        species = collections.OrderedDict([('K+', {'bulk_concentration': 100.0}), ('HCO3-', {'bulk_concentration': 100.0}),
+                                           ('CO2', {'bulk_concentration': 34.0}), ('CO', {'bulk_concentration': 0.0})])
+        return Transport(species=species, system={'phiM': phis[0], 'boundary thickness': 4e-8, 'Stern capacitance': 20.0, 'phiPZC': 0.1},
+                         nx=256, descriptors={'phiM': phis})
+
+    tp = make_tp()
+    calc = Calculator(transport=tp, calc='comsol', tau_scf=1e-6, mix_scf=0.02)
+    calc.set_surface_kinetics(kin)
+    dev = calc.run_scf_cycle(nel=[1, 1, 2, 2], max_iter=3000)
+    assert dev['converged'].all() and not dev['failed'].any() and dev['iterations'] > 100
+    L = (tp.nx - 1) * tp.dx
+    kap = rate(np.array(phis)) * L / tp.D[2]
+    assert np.allclose(dev['surface_concentration'][:, 2], 34.0 / (1.0 + kap), rtol=2e-4)
+    assert (np.diff(-dev['flux'][:, 2]) > 0).all()                                  # the Tafel rise into the transport plateau
+    tp2 = make_tp()
+    host_calc = Calculator(transport=tp2, calc='comsol', tau_scf=1e-6, mix_scf=0.02)
+
+    def cb(state):
+        f = np.zeros((B, 4))
+        f[:, 2] = -rate(state['phiM']) * np.maximum(state['surface_concentration'][:, 2], 0.0)
+        f[:, 3] = -f[:, 2]
+        return f
+    host = host_calc.run_scf_cycle(cb, nel=[1, 1, 2, 2], max_iter=3000)
+    assert host['converged'].all() and dev['iterations'] == host['iterations']
+    assert np.array_equal(dev['mix'], host['mix'])
+    assert np.allclose(dev['surface_concentration'], host['surface_concentration'], rtol=1e-9, atol=1e-12)
+    assert np.allclose(dev['flux'], host['flux'], rtol=1e-9, atol=1e-18)

@@ -515,3 +515,24 @@ def test_register_budget_does_not_change_results(N, nx, B, monkeypatch):
     for b in (b1, b2):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert (a[2] <= 50).all()
+
+
+@pytest.mark.parametrize("kernel", ['', 'generic', 'team'])
+def test_fuzz_case_117_stops_at_the_rounding_floor(kernel, monkeypatch):
+    """The outlier of the randomised runs (tests/fuzz/fuzz_newton.py, seed 101, case 117: 3 species, 3 stiff homogeneous reactions, wall
+    fluxes, graded 400-point grid, stationary; frozen as tests/golden/fuzz/newton_case117.json).  Newton converges quadratically by
+    iteration 17; from there the scaled update floats at ~3e-9 -- cond(J) eps of this Jacobian -- ABOVE the tolerance of 1e-10, and every
+    linear solver left the loop when ITS rounding noise happened to dip below it: 20 iterations (pair kernel), 31 (oracle, LAPACK),
+    37 (row-per-thread kernel), all with the same state to 4e-9.  With the rounding-floor exit (pnp_math.h: newton_at_rounding_floor;
+    oracle/pnp_physical.py) they all stop within an iteration of each other, on the same state."""
+    import json
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fuzz', 'newton_case117.json')))
+    got, ref = run_both(d['N'], d['nx'], B=d['B'], seed=d['seed'], newton_kw=d['newton_kw'], reactions=d['reactions'],
+                        flux=np.array(d['flux']), x=np.array(d['x']), stationary=True, phi_lo=-0.3, phi_hi=0.3,
+                        points_per_debye=d['points_per_debye'])
+    c, phi, its, st = got
+    rc, rphi, rit = ref
+    assert (st == 0).all() and rit[0] == 20
+    assert abs(int(its[0]) - int(rit[0])) <= 1, (its, rit)
+    assert np.abs(c - rc).max() <= 1e-8 * np.abs(rc).max() and np.abs(phi - rphi).max() <= 1e-9

@@ -363,3 +363,25 @@ def test_newton_solution_is_the_root_an_independent_solver_finds():
         u = sol.x.reshape(4, nx)
         assert np.abs(u[:3] - c).max() <= 1e-8 * np.abs(c).max() and np.abs(u[3] - phi).max() <= 1e-9
         assert np.abs(fun(np.concatenate([c, phi[None]], 0).reshape(-1))).max() <= 1e-9 * max(1.0, np.abs(fun(u0)).max())
+
+
+def test_rounding_floor_exit_of_the_newton_iteration():
+    """Fuzz case 117 (tests/golden/fuzz/newton_case117.json): after quadratic convergence the scaled update sits at ~3e-9 -- the rounding
+    floor of an ill-conditioned Jacobian -- above tol = 1e-10.  The iteration leaves there (two consecutive full steps within 100 tol,
+    the second not half the first) instead of running until the noise dips below tol; the state it leaves is a root of the residual."""
+    import json
+    import os
+    from tests.test_gpu_newton import BETA, EPS, make_lanes
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fuzz', 'newton_case117.json')))
+    N, nx = d['N'], d['nx']
+    D, q, cb, dx, phiM = make_lanes(N, nx, d['B'], d['seed'], phi_lo=-0.3, phi_hi=0.3, points_per_debye=d['points_per_debye'])
+    p = PH.PhysicalProblem(D=D, charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=cb[0], phiM=phiM[0], flux=np.array(d['flux'])[0],
+                           reactions=d['reactions'], x=np.array(d['x']) * dx)
+    c0 = np.repeat(cb[0][:, None], nx, axis=1)
+    c, phi, it, hist = PH.newton_step(p, c0, np.zeros(nx), c0, np.inf, tol=1e-10, maxit=60)
+    assert it == 20 and hist[16] < 1e-7 and hist[15] > 1e-5                 # quadratic phase ends at iteration 17 ...
+    assert all(1e-11 < h < 1e-8 for h in hist[17:])                         # ... then the floor
+    assert hist[-1] > 0.5 * hist[-2] and hist[-1] > 1e-10                   # left on the stagnation rule, not on update < tol
+    F = PH.residual_and_jacobian(p, c, phi, c0, np.inf)[0]
+    F0 = PH.residual_and_jacobian(p, c0, np.zeros(nx), c0, np.inf)[0]
+    assert np.abs(F).max() < 1e-9 * np.abs(F0).max()
