@@ -122,10 +122,27 @@ def pmc_child(args):
             item(s, inp, lambda s, w: s.step(2))
             s, inp = newton_solver(BC_SHAPE[0], BC_SHAPE[1], BC_SHAPE[2], 4447, steric=True)
             item(s, inp, lambda s, w: s.step(2))
+        if args.large_batch > 0:
+            s, inp = compat_solver(args.large_batch, N, nx, args.method, 77)
+            item(s, inp, lambda s, w: s.step(8, 1))
 
 
 PMC_ITEMS = ['headline', 'per_step_launch', 'beyond_cache_per_step', 'beyond_cache_fused', 'physical_pair', 'physical_sweep',
-             'physical_lane_32k', 'physical_lane_config3']
+             'physical_lane_32k', 'physical_lane_config3', 'large_batch']
+
+
+def pmc_items(args):
+    """The records of this run that have a segment in the profiled child, in the child's order (pmc_child)."""
+    names = ['headline', 'per_step_launch']
+    if not args.no_extras:
+        names += ['beyond_cache_per_step', 'beyond_cache_fused']
+        if args.physical_steps > 0:
+            names += ['physical_pair', 'physical_sweep', 'physical_lane_32k', 'physical_lane_config3']
+        if args.large_batch > 0:
+            names += ['large_batch']
+    return names
+
+
 PMC_GROUPS = [['FETCH_SIZE'], ['WRITE_SIZE'],
               ['SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_INSTS_LDS', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY',
                'SQ_ACTIVE_INST_VALU'],
@@ -141,7 +158,7 @@ def collect_pmc(args):
     tmp = tempfile.mkdtemp(prefix='catint_pmc_', dir='/tmp')
     child = [sys.executable, os.path.abspath(__file__), '--pmc-child', '--batch', str(args.batch), '--nspecies', str(args.nspecies),
              '--nx', str(args.nx), '--method', args.method, '--steps', str(args.steps), '--steps-per-launch', str(args.steps_per_launch),
-             '--physical-steps', str(args.physical_steps)] + (['--no-extras'] if args.no_extras else [])
+             '--physical-steps', str(args.physical_steps), '--large-batch', str(args.large_batch)] + (['--no-extras'] if args.no_extras else [])
     env = dict(os.environ, TMPDIR='/tmp')
     out = {}
     try:
@@ -166,7 +183,7 @@ def collect_pmc(args):
             seq = [disp[k] for k in sorted(disp)]
             # segments: marker (surface_kernel) ... timed launches ... marker
             marks = [i for i, dd in enumerate(seq) if 'surface_kernel' in dd['kernel']]
-            for it, name in enumerate(PMC_ITEMS):
+            for it, name in enumerate(pmc_items(args)):
                 if 2 * it + 1 >= len(marks):
                     break
                 seg = seq[marks[2 * it] + 1:marks[2 * it + 1]]
@@ -187,8 +204,13 @@ def collect_pmc(args):
         shutil.rmtree(tmp, ignore_errors=True)
     for rec in out.values():
         if 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
-            # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2
+            # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2.
+            # The guide establishes the factor for 16-byte-per-lane streaming reads: that is what the compat kernels (buffer_load b128
+            # windows) and the lane kernel (16-byte pairs) issue.  The pair / lane-team Newton kernels read 8 bytes per lane
+            # (uncalibrated): for them the x1 figure is kept beside the x2 one as a lower bound.
             rec['hbm_bytes_per_launch'] = (2.0 * rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024.0
+            rec['hbm_bytes_per_launch_fetch_x1'] = (rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024.0
+            rec['fetch_correction'] = 'x2 (16-byte lanes)' if ('step_kernel' in rec['kernel'] or 'lane_kernel' in rec['kernel']) else 'x1 ... x2 (8-byte lanes: uncalibrated)' 
     return out
 
 
@@ -331,6 +353,10 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         roof['valu_wave_insts_per_lane_iteration'] = roof['valu_wave_insts_per_launch'] / max(it3, 1.0)
         if 'hbm_bytes_per_launch' in roof:
             roof['hbm_bytes_per_lane_iteration'] = roof['hbm_bytes_per_launch'] / max(it3, 1.0)
+            pp = pmc.get('physical_pair', {})
+            if 'hbm_bytes_per_launch_fetch_x1' in pp:      # 8-byte lanes: the gfx950 FETCH_SIZE factor is uncalibrated there
+                roof['hbm_bytes_per_lane_iteration_range'] = [pp['hbm_bytes_per_launch_fetch_x1'] / max(it3, 1.0), roof['hbm_bytes_per_lane_iteration']]
+                roof['fetch_correction'] = pp.get('fetch_correction')
             roof['algorithmic_state_bytes_per_lane_timestep'] = 16.0 * (N + 1) * nx
         out['roofline'] = roof
     try:
@@ -605,7 +631,7 @@ def main():
         s2.step(16, 1)
         lms = timed_steps(s2, ls, 1)
         lok = int((s2.get_status() == 0).sum())
-        large = hbm_record(LB, N, nx, ls, ls, lms, None)
+        large = hbm_record(LB, N, nx, ls, ls, lms, pmc.get('large_batch') if isinstance(pmc, dict) else None)
         large.update({'batch': LB, 'steps': ls, 'lanes_ok': lok, 'steps_per_launch': 1, 'state_MB': 8.0 * (N + 2) * nx * LB / 1e6})
         s2.set_batch(*inp[1:])
         for _ in range(4):

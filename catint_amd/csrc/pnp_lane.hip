@@ -206,6 +206,10 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 
   for (;;) {
     if (__ballot(have) == 0ull) break;
+    // (Lanes whose operating point has finished its timesteps run along until the slowest point of the wave is done and keep streaming
+    // their records: measured HBM bytes are 1.13 x the algorithmic figure on 2-step launches, ~1.05 x on long ones.  Two ways of silencing
+    // them were measured on one device in one call, tools/probe/lane_ab.sh, and both LOST: the whole iteration under their exec mask
+    // -9 %, every access through a range-checked buffer resource with out-of-range offsets for finished lanes -6 ... -13 %.)
     const NewtonArgs& A = G;
     const bool first = fresh;          // first iteration of a timestep: the previous time level is the state itself
     if (fresh) {

@@ -16,8 +16,11 @@ def pytest_configure(config):
 
 def pytest_sessionstart(session):
     """The checker library (C oracle) is built by `make` when it is missing or stale.  Do that now, before any test initialises the
-    GPU: on the GPU box a process that has touched the GPU must not start child processes.  (The product library is never built from
-    here: __graft_entry__.build() does that; catint_amd._capi fails loudly if it is missing.)"""
+    GPU: a process that has touched the GPU must never REPLACE itself with another program (exec*), and the build belongs outside
+    the tests anyway.  Starting fresh CHILD processes from a GPU-initialised process is allowed on the GPU pool -- the multi-rank
+    tests (tests/test_gpu_parallel.py) Popen their rank workers from this pytest process -- within the pool's limit of six
+    processes on the card.  (The product library is never built from here: __graft_entry__.build() does that;
+    catint_amd._capi fails loudly if it is missing.)"""
     try:
         from oracle import c_oracle
         c_oracle.load()

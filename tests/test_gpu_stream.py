@@ -26,11 +26,9 @@ def run(p, method, c0, pb, vz, fl, nsteps, spl):
 
 
 @pytest.mark.parametrize('mode', ['5', '6', '7'])
-@pytest.mark.parametrize('N,nx,B', [(3, 512, 700), (2, 200, 513), (6, 1024, 300), (3, 130, 257), (1, 66, 300), (4, 1026, 260), (6, 515, 259)])
+@pytest.mark.parametrize('N,nx,B', [(3, 512, 700), (2, 200, 513), (6, 1024, 300), (3, 130, 257), (2, 66, 300), (4, 1026, 260), (6, 515, 259)])
 @pytest.mark.parametrize('method', ['Crank-Nicolson', 'FTCS'])
 def test_streaming_kernel_matches_oracle_and_previous_kernels(mode, N, nx, B, method, monkeypatch):
-    if N == 1:
-        pytest.skip('synthetic batches need two species')
     p, c0, pb, vz, fl = make_batch(B, N, nx, seed=nx + N, phi_max=0.02, dt_factor=1e-4 if method == 'Crank-Nicolson' else 2e-5)
     rng = np.random.default_rng(nx)
     c0 = c0 * (1 + 0.05 * rng.uniform(-1, 1, c0.shape))

@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B of lane-kernel builds on ONE device in ONE call (devices differ by up to ~10 %: never compare across gpurun calls).
+# usage: bash tools/probe/lane_ab.sh libA.so libB.so ...   (paths relative to the repo root), two interleaved rounds per shape
+LIBS=("$@")
+for spec in "8 512 8192" "8 512 32768" "6 1024 32768"; do
+  read N NX B <<< "$spec"
+  for round in 1 2; do
+    for lib in "${LIBS[@]}"; do
+      r=$(CATINT_PNP_LIB=$PWD/$lib CATINT_NEWTON_KERNEL=lane python tools/newton_bench.py --nspecies $N --nx $NX --batch $B --steps 10 --warmup 2 --stern --mpb 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4g' % d['timesteps_per_s'])")
+      echo "N=$N nx=$NX B=$B round $round $lib: $r"
+    done
+  done
+done
