@@ -64,6 +64,8 @@ struct pnp_handle {
   int sweep_blocks = 0;
   double* lane_buf = nullptr;            // lane kernel: batch-innermost state copies + records of lane_groups groups of 32 operating points
   int64_t lane_groups = 0;
+  double* lane2_buf = nullptr;           // lane-pair kernel: the same for groups of 16
+  int64_t lane2_groups = 0;
   double* scf_d = nullptr;               // (4N + 5) B doubles
   double* scf_snap = nullptr;            // (N + 1) ldx B doubles: per-lane state of the last converged transport solve
   int32_t* scf_i = nullptr;              // 3 B flags + 65 counters
@@ -110,7 +112,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->lane2_buf, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -533,8 +535,29 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.rt = (h->rt_dev && h->rt.n > 0) ? h->rt_dev : nullptr;
   a.n_wk = h->newton_explicit_kinetics ? 0 : h->n_wk;
   a.lane_mask = h->newton_mask;
-  const bool use_lane = newton_lane_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0));
-  if (use_lane) {
+  const bool use_lane2 = newton_lane2_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0));
+  const bool use_lane = !use_lane2 && newton_lane_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0));
+  if (use_lane2) {
+    const size_t per_group = (newton_lane2_rec_doubles(N + 1, nx) + newton_lane2_state_doubles(N + 1, nx)) * sizeof(double);
+    if (!h->lane2_buf) {
+      int64_t groups = (h->cfg.batch_capacity + 15) / 16;
+      const int64_t fit = (int64_t)(((size_t)48 << 30) / per_group);
+      if (groups > fit) groups = fit;
+      if (const char* e = getenv("CATINT_NEWTON_LANE_GROUPS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v < groups) groups = v;
+      }
+      if (groups < 1) groups = 1;
+      HIP_TRY(h, dev_alloc(h, &h->lane2_buf, (size_t)groups * per_group / sizeof(double)));
+      h->lane2_groups = groups;
+    }
+    const size_t vp2 = (size_t)((N + 2) / 2 * 2), cp2 = (size_t)((N + 1) / 2 * 2);
+    a.lane_groups = h->lane2_groups;
+    a.lane_ts = h->lane2_buf;
+    a.lane_xs = a.lane_ts + (size_t)h->lane2_groups * vp2 * nx * 16;
+    a.lane_tco = a.lane_xs + (size_t)h->lane2_groups * vp2 * nx * 16;
+    a.lane_rec = a.lane_tco + (size_t)h->lane2_groups * cp2 * nx * 16;
+  } else if (use_lane) {
     // one operating point per lane: transposed state + records of as many groups of 32 operating points as the batch capacity has,
     // capped at 48 GiB (the launcher walks a larger batch in chunks)
     const size_t per_group = (newton_lane_rec_doubles(N + 1, nx) + newton_lane_state_doubles(N + 1, nx)) * sizeof(double);
@@ -601,7 +624,8 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
     if (v >= 1 && v < blocks) blocks = v;
   }
   if ((int64_t)blocks > h->B) blocks = (int)h->B;
-  if (use_lane) HIP_TRY(h, launch_newton_lane(a, h->stream));
+  if (use_lane2) HIP_TRY(h, launch_newton_lane2(a, h->stream));
+  else if (use_lane) HIP_TRY(h, launch_newton_lane(a, h->stream));
   else HIP_TRY(h, launch_newton(a, blocks, h->stream));
   h->steps_done += nsteps;
   return PNP_OK;

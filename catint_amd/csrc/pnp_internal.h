@@ -154,6 +154,8 @@ struct NewtonArgs {
   double* lane_rec;                      // [groups][nx][((N+1)^2 + (N+1))/2][32][2]
   int64_t lane_groups;                   // groups (of 32 operating points) the three buffers hold
   int64_t lane_group0;                   // first group of this launch (the batch is walked in chunks of lane_groups)
+  int32_t lane_lg, pad3_;                // operating points per group: 32 (lane kernel) or 16 (lane-pair kernel, pnp_lane2.hip)
+  double lane_pivot_limit;               // pivot monitor of the lane kernels (pnp_lane_common.h): multipliers beyond this mark the lane
 };
 int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);
@@ -172,6 +174,13 @@ bool newton_lane_preferred(int nb, int nx, int64_t B, int mode);
 size_t newton_lane_rec_doubles(int nb, int nx);       // records of one group of 32 operating points
 size_t newton_lane_state_doubles(int nb, int nx);     // transposed state + previous time level of one group
 hipError_t launch_newton_lane(const NewtonArgs& a, hipStream_t stream);
+hipError_t launch_lane_transpose(const NewtonArgs& a, int64_t ngroups, bool in, hipStream_t stream);     // a.lane_lg points per group
+// lane-pair kernel (pnp_lane2.hip): four lanes per operating point (two directions x two halves of the block row), N >= 5
+bool newton_lane2_supported(int nb, int nx, int mode);
+bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode);
+size_t newton_lane2_rec_doubles(int nb, int nx);      // per group of 16 operating points
+size_t newton_lane2_state_doubles(int nb, int nx);
+hipError_t launch_newton_lane2(const NewtonArgs& a, hipStream_t stream);
 
 // ---- kinetics <-> transport SCF loop on the device (pnp_scf.hip; Calculator.run_scf_cycle, calculator.py:294-406) ----
 struct ScfArgs {

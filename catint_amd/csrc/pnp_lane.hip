@@ -37,48 +37,18 @@
 
 #include <cstdlib>
 
-#include "pnp_internal.h"
-#include "pnp_math.h"
+#include "pnp_lane_common.h"
 
 namespace pnp {
 
+using namespace lane;
+
 namespace {
-
-struct LEdge {
-  double Bp, Bm, J, Ju;
-};
-
-// Scharfetter-Gummel edge flux, the formulas of edge_flux in pnp_newton.hip (oracle/pnp_physical.py: bernoulli)
-__device__ __forceinline__ LEdge lane_edge_flux(double u, double cl, double cr, double w) {
-  double B, dB;
-  if (fabs(u) < 0.05) {
-    double k12 = 1.0 / 12.0, k720 = -1.0 / 720.0, k30240 = 1.0 / 30240.0, k6 = 1.0 / 6.0, k180 = -1.0 / 180.0, k5040 = 1.0 / 5040.0;
-    asm volatile("" : "+s"(k12), "+s"(k720), "+s"(k30240), "+s"(k6), "+s"(k180), "+s"(k5040));
-    const double u2 = u * u;
-    B = 1.0 - 0.5 * u + u2 * (k12 + u2 * (k720 + u2 * k30240));
-    dB = -0.5 + u * (k6 + u2 * (k180 + u2 * k5040));
-  } else {
-    const double rE = nrcp(expm1_sc(u));
-    B = u * rE;
-    dB = (1.0 - B - u) * rE;
-  }
-  LEdge e;
-  e.Bp = w * B;
-  e.Bm = w * (B + u);
-  e.J = -(e.Bm * cr - e.Bp * cl);
-  e.Ju = -w * ((dB + 1.0) * cr - dB * cl);
-  return e;
-}
 
 __device__ __forceinline__ double partner(double v) { return __shfl_xor(v, 32, 64); }   // the same operating point, other direction
 
 constexpr int LG = 32;      // operating points per wave (two lanes each)
 
-typedef double d2 __attribute__((ext_vector_type(2)));
-
-struct LaneParams {
-  double sig[PNP_NEWTON_MAX_SPECIES], peq[PNP_NEWTON_MAX_SPECIES];
-};
 
 }  // namespace
 
@@ -92,12 +62,13 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
   __shared__ double tile[LG][65];
   const int N = G.N, nx = G.nx, ldx = G.ldx;
   const int VP = (N + 2) / 2, CP = (N + 1) / 2;
+  const int LGr = G.lane_lg;                  // operating points per group (32: lane kernel, 16: lane-pair kernel)
   const int64_t g = blockIdx.x;
   const int i0 = blockIdx.y * 64;
   const int t = threadIdx.x;
-  double* ts = G.lane_ts + (size_t)g * (size_t)nx * VP * LG * 2;
-  double* tco = G.lane_tco + (size_t)g * (size_t)nx * CP * LG * 2;
-  const int64_t b0 = (G.lane_group0 + g) * LG;
+  double* ts = G.lane_ts + (size_t)g * (size_t)nx * VP * LGr * 2;
+  double* tco = G.lane_tco + (size_t)g * (size_t)nx * CP * LGr * 2;
+  const int64_t b0 = (G.lane_group0 + g) * LGr;
   bool bad = false;
   for (int v = 0; v <= N; ++v) {
     if constexpr (IN) {
@@ -106,17 +77,17 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
         const int op = rr * 4 + (t >> 6), ii = t & 63;
         const int64_t b = b0 + op;
         double val = 0.0;
-        if (b < G.B && i0 + ii < nx) val = v < N ? G.c[((size_t)b * N + v) * ldx + i0 + ii] : G.phi[(size_t)b * ldx + i0 + ii];
+        if (op < LGr && b < G.B && i0 + ii < nx) val = v < N ? G.c[((size_t)b * N + v) * ldx + i0 + ii] : G.phi[(size_t)b * ldx + i0 + ii];
         tile[op][ii] = val;
       }
       __syncthreads();
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int ii = rr * 8 + (t >> 5), op = t & 31;
-        if (i0 + ii < nx) {
+        if (i0 + ii < nx && op < LGr) {
           const double val = tile[op][ii];
-          ts[(((size_t)(i0 + ii) * VP + (v >> 1)) * LG + op) * 2 + (v & 1)] = val;
-          if (v < N) tco[(((size_t)(i0 + ii) * CP + (v >> 1)) * LG + op) * 2 + (v & 1)] = val;
+          ts[(((size_t)(i0 + ii) * VP + (v >> 1)) * LGr + op) * 2 + (v & 1)] = val;
+          if (v < N) tco[(((size_t)(i0 + ii) * CP + (v >> 1)) * LGr + op) * 2 + (v & 1)] = val;
         }
       }
       __syncthreads();
@@ -125,7 +96,7 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
       for (int rr = 0; rr < 8; ++rr) {
         const int ii = rr * 8 + (t >> 5), op = t & 31;
         double val = 0.0;
-        if (i0 + ii < nx) val = ts[(((size_t)(i0 + ii) * VP + (v >> 1)) * LG + op) * 2 + (v & 1)];
+        if (i0 + ii < nx && op < LGr) val = ts[(((size_t)(i0 + ii) * VP + (v >> 1)) * LGr + op) * 2 + (v & 1)];
         if (!(fabs(val) < INFINITY)) bad = true;
         tile[op][ii] = val;
       }
@@ -134,7 +105,7 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
       for (int rr = 0; rr < 8; ++rr) {
         const int op = rr * 4 + (t >> 6), ii = t & 63;
         const int64_t b = b0 + op;
-        if (b < G.B && i0 + ii < nx && !(G.lane_mask && !G.lane_mask[b])) {
+        if (op < LGr && b < G.B && i0 + ii < nx && !(G.lane_mask && !G.lane_mask[b])) {
           if (v < N) G.c[((size_t)b * N + v) * ldx + i0 + ii] = tile[op][ii];
           else G.phi[(size_t)b * ldx + i0 + ii] = tile[op][ii];
         }
@@ -144,7 +115,7 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
   }
   if constexpr (!IN) {
     const int64_t b = b0 + (t & 31);
-    if (bad && b < G.B && !(G.lane_mask && !G.lane_mask[b])) atomicMax(&G.status[b], (int32_t)PNP_STATUS_NAN);
+    if (bad && (t & 31) < LGr && b < G.B && !(G.lane_mask && !G.lane_mask[b])) atomicMax(&G.status[b], (int32_t)PNP_STATUS_NAN);
   }
 }
 
@@ -200,6 +171,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   bool have = valid, fresh = true;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
   double upd_prev = INFINITY;
+  double alarm = 0.0;            // pivot monitor (sticky): see PIVOT_GROWTH_LIMIT
 #ifdef PNP_LANE_STAMPS
   double stamp_f = 0.0, stamp_b = 0.0, stamp_u = 0.0, stamp_n = 0.0;
 #endif
@@ -503,6 +475,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           }
         }
         // ---- LU in place, no row exchanges; reciprocal pivots on the diagonal ----------------------------------------------
+        double gmax = 0.0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
           const double inv = nrcp(D[k][k]);
@@ -510,11 +483,13 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 #pragma unroll
           for (int r = k + 1; r < NB; ++r) {
             const double l = D[r][k] * inv;
+            gmax = fmax(gmax, fabs(l));          // pivot monitor: the multipliers are what row exchanges would have kept below one
             D[r][k] = l;
 #pragma unroll
             for (int cc = k + 1; cc < NB; ++cc) D[r][cc] = __builtin_fma(-l, D[k][cc], D[r][cc]);
           }
         }
+        alarm = (gmax > G.lane_pivot_limit || gmax != gmax) ? 1.0 : alarm;
         auto solve = [&](double (&y)[NB], const int start) {     // rows < start of y are zero
 #pragma unroll
           for (int k = 0; k < NB; ++k) {
@@ -752,6 +727,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     }
 #endif
     // =========================== bookkeeping of the lane's operating point (identical in both halves) ========================
+    alarm = fmax(alarm, partner(alarm));
     if (have) {
       bool accept = false;
       if (lam == 1.0) {
@@ -769,7 +745,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         if (step >= A.nsteps) {
           have = false;
           if (!side) {
-            G.status[b] = st;
+            G.status[b] = alarm > 0.0 ? (int)PNP_STATUS_MAXIT : st;        // (a lane that tripped the pivot monitor is never reported converged)
             G.iters[b] = total_it;
           }
         }
@@ -792,7 +768,7 @@ bool newton_lane_supported(int nb, int nx, int mode) { return nb >= 2 && nb <= 9
 bool newton_lane_preferred(int nb, int nx, int64_t B, int mode) {
   if (!newton_lane_supported(nb, nx, mode)) return false;
   if (const char* f = getenv("CATINT_NEWTON_KERNEL")) {
-    if (f[0] == 'l') return true;
+    if (f[0] == 'l') return !(f[1] && f[2] && f[3] && f[4] == '2');      // "lane" (not "lane2": the lane-pair kernel)
     if (f[0] != 0) return false;           // another kernel is forced (tests, probes)
   }
   // Measured (tools/probe/lane_sweep.py -> profiles/r03_lane_sweep.jsonl: transient steps, steric ions, Stern wall; timesteps/s of
@@ -811,6 +787,23 @@ bool newton_lane_preferred(int nb, int nx, int64_t B, int mode) {
   return false;
 }
 
+hipError_t launch_lane_transpose(const NewtonArgs& a, int64_t ngroups, bool in, hipStream_t stream) {
+  const dim3 tg((unsigned)ngroups, (unsigned)((a.nx + 63) / 64));
+  if (in) hipLaunchKernelGGL((lane_transpose_kernel<true>), tg, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((lane_transpose_kernel<false>), tg, dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode) {
+  if (!newton_lane2_supported(nb, nx, mode)) return false;
+  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 'l' && f[1] && f[2] && f[3] && f[4] == '2';
+  // Measured on one device in one call (tools/probe/lane2_probe.sh; N = 8, nx = 512, timesteps/s, lane pair / lane / lane teams):
+  // B = 1024 1.16e5 / 1.00e5 / 1.40e5, 2048 2.40e5 / 1.96e5 / 1.43e5, 4096 4.51e5 / 3.85e5 / 1.44e5, 8192 7.31e5 / 7.07e5 / 1.51e5,
+  // 16 384 0.99e6 / 1.03e6.  Twice the waves for the same batch, but the distribution overhead (selects, DPP moves, duplicated
+  // assembly) leaves a wave's pace only 1.28 x the lane kernel's and two waves on a CU cost each other ~20 %.
+  return B >= 1280 && B < 10240;
+}
+
 template <int NB>
 static hipError_t launch_lane_nb(const NewtonArgs& a0, hipStream_t stream) {
   const int64_t groups = (a0.B + LG - 1) / LG;
@@ -818,6 +811,8 @@ static hipError_t launch_lane_nb(const NewtonArgs& a0, hipStream_t stream) {
   for (int64_t g0 = 0; g0 < groups; g0 += cap) {
     NewtonArgs a = a0;
     a.lane_group0 = g0;
+    a.lane_lg = LG;
+    a.lane_pivot_limit = lane_pivot_limit_from_env();
     const int64_t ng = groups - g0 < cap ? groups - g0 : cap;
     const dim3 tg((unsigned)ng, (unsigned)((a.nx + 63) / 64));
     hipLaunchKernelGGL((lane_transpose_kernel<true>), tg, dim3(256), 0, stream, a);

@@ -184,3 +184,23 @@ def test_lane_mask_and_set_lanes(kernel, monkeypatch):
         assert (st == 0).all()
         assert np.array_equal(c2[even], cref[even]) and np.array_equal(it2[even], itref[even])          # untouched by patch and solve
         assert (it2[~even] <= 2).all() and np.abs(c2 - cref).max() <= 1e-8 * np.abs(cref).max()
+
+
+@pytest.mark.parametrize("kernel,N", [('lane', 3), ('lane', 8), ('lane2', 6), ('lane2', 8)])
+def test_pivot_monitor_reports_a_lane_as_not_converged(kernel, N, monkeypatch):
+    """The lane kernels eliminate without row exchanges; a multiplier beyond 1e8 marks the lane and a marked lane is never reported
+    converged (status 1: the rerun ladder then solves it with the pivoting kernels).  On well-posed systems the monitor stays silent
+    (every other test of this file); with the limit forced below one every lane trips it -- the states are the same, the flags are not."""
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    a = run_gpu_only(N, 48, 40, 7)
+    monkeypatch.setenv('CATINT_LANE_PIVOT_LIMIT', '1e-6')
+    D, q, cb, dx, phiM = make_lanes(N, 48, 40, 7)
+    c0 = np.repeat(cb[:, :, None], 48, axis=2)
+    pb = np.zeros((40, 4))
+    pb[:, 0] = phiM
+    with _capi.PnpSolver(N, 48, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=40) as s:
+        s.set_newton()
+        s.set_batch(c0, pb, np.zeros(40), np.zeros((40, N)))
+        st = s.solve_stationary()
+        c = s.get_state()[0]
+    assert (st == 1).all() and np.array_equal(c, a[0])
