@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9      # fp64 lane-operations/s: 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz (78.6 TFLOP/s FMA)
 BC_SHAPE = (32768, 6, 1024)    # one GPU's share of BASELINE configs[3]
+C4_SHAPE = (8192, 8, 4096)     # one GPU's share of BASELINE configs[4]
 RADII8 = [4.1e-10, 3.6e-10, 3.3e-10, 3e-10, 3e-10, 3e-10, 4.5e-10, 3.5e-10]
 
 
@@ -159,7 +160,9 @@ def collect_pmc(args):
     child = [sys.executable, os.path.abspath(__file__), '--pmc-child', '--batch', str(args.batch), '--nspecies', str(args.nspecies),
              '--nx', str(args.nx), '--method', args.method, '--steps', str(args.steps), '--steps-per-launch', str(args.steps_per_launch),
              '--physical-steps', str(args.physical_steps), '--large-batch', str(args.large_batch)] + (['--no-extras'] if args.no_extras else [])
-    env = dict(os.environ, TMPDIR='/tmp')
+    # (counters are per dispatch: the child keeps every step's rows in ONE dispatch -- no row chunks on separate streams -- so that a
+    # dispatch's bytes are a timestep's bytes; the profiler serialises dispatches anyway)
+    env = dict(os.environ, TMPDIR='/tmp', CATINT_PNP_STEP_STREAMS='1')
     out = {}
     try:
         for gi, grp in enumerate(PMC_GROUPS):
@@ -632,7 +635,8 @@ def main():
         lms = timed_steps(s2, ls, 1)
         lok = int((s2.get_status() == 0).sum())
         large = hbm_record(LB, N, nx, ls, ls, lms, pmc.get('large_batch') if isinstance(pmc, dict) else None)
-        large.update({'batch': LB, 'steps': ls, 'lanes_ok': lok, 'steps_per_launch': 1, 'state_MB': 8.0 * (N + 2) * nx * LB / 1e6})
+        large.update({'batch': LB, 'steps': ls, 'lanes_ok': lok, 'steps_per_launch': 1, 'state_MB': 8.0 * (N + 2) * nx * LB / 1e6,
+                      'row_chunks': s2.step_row_chunks(ls)})
         s2.set_batch(*inp[1:])
         for _ in range(4):
             s2.step(8, 8)
@@ -657,6 +661,7 @@ def main():
             ms1 = timed_steps(s3, 8, 1, reps=3)
             ok1 = int((s3.get_status() == 0).sum())
             rec1 = hbm_record(BB, BN, BX, 8, 8, ms1, pmc.get('beyond_cache_per_step'))
+            rec1['row_chunks'] = s3.step_row_chunks(8)      # (launch_us: per timestep = one launch per chunk, on streams of their own)
             s3.set_batch(*inp[1:])
             s3.step(32, 32)
             s3.synchronize()
@@ -667,6 +672,24 @@ def main():
             beyond = {'workload': "one GPU's share of BASELINE configs[3]: batch=%d, %d species, %d grid points, Crank-Nicolson compat "
                                   'integrator' % (BB, BN, BX), 'state_MB': 8.0 * (BN + 2) * BX * BB / 1e6, 'lanes_ok': ok1,
                       'per_step_launch': rec1, 'fused_32_steps_per_launch': rec32}
+            # one GPU's share of configs[4]: 4096 grid points = four waves per tridiagonal system (step_kernel_mw)
+            CB, CN_, CX = C4_SHAPE
+            del inp
+            s4, inp4 = compat_solver(CB, CN_, CX, args.method, 56, device)
+            s4.set_batch(*inp4[1:])
+            del inp4
+            s4.step(4, 1)
+            s4.synchronize()
+            warm_clocks()
+            s4.step(4, 1)
+            ms4 = timed_steps(s4, 4, 1, reps=3)
+            ok4 = int((s4.get_status() == 0).sum())
+            rec4 = hbm_record(CB, CN_, CX, 4, 4, ms4, None)
+            rec4.update({'row_chunks': s4.step_row_chunks(4), 'lanes_ok': ok4, 'state_MB': 8.0 * (CN_ + 2) * CX * CB / 1e6,
+                         'workload': "one GPU's share of BASELINE configs[4]: batch=%d, %d species, %d grid points, one launch per "
+                                     'timestep (step_kernel_mw: four waves per tridiagonal system)' % (CB, CN_, CX)})
+            s4.close()
+            beyond['beyond_cache_config4'] = rec4
         except Exception as e:
             beyond = {'error': '%s: %s' % (type(e).__name__, e)}
 

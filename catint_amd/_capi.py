@@ -32,7 +32,7 @@ SYMBOLS = [
     'pnp_create', 'pnp_destroy', 'pnp_last_error', 'pnp_version', 'pnp_set_species', 'pnp_set_reactions',
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_integrate_dopri5', 'pnp_integrate_dop853', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
-    'pnp_device_bytes', 'pnp_row_pitch', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
+    'pnp_device_bytes', 'pnp_row_pitch', 'pnp_step_row_chunks', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
     'pnp_set_potential', 'pnp_set_lanes', 'pnp_set_lane_mask', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
 ]
 
@@ -159,6 +159,8 @@ def load_library():
     lib.pnp_device_bytes.restype = C.c_int64
     lib.pnp_row_pitch.argtypes = [vp]
     lib.pnp_row_pitch.restype = C.c_int32
+    lib.pnp_step_row_chunks.argtypes = [vp, C.c_int32]
+    lib.pnp_step_row_chunks.restype = C.c_int32
     _lib = lib
     return lib
 
@@ -434,3 +436,7 @@ class PnpSolver(object):
     @property
     def row_pitch(self):
         return int(self._lib.pnp_row_pitch(self._h))
+
+    def step_row_chunks(self, launches):
+        """Row chunks (HIP streams) a step() call of `launches` launches is cut into."""
+        return int(self._lib.pnp_step_row_chunks(self._h, int(launches)))

@@ -73,6 +73,13 @@ struct pnp_handle {
   int32_t* user_mask = nullptr;          // pnp_set_lane_mask's copy
   bool newton_explicit_kinetics = false; // the wall-kinetics table feeds the prescribed fluxes instead of the Jacobian
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
+  // pnp_step with several launches in one call: the batch is cut into row chunks whose launch sequences run on streams of their own
+  // (rows are independent), so one chunk's launch boundary is covered by the other chunk's rows; created on first use
+  static constexpr int MAX_STEP_STREAMS = 4;
+  hipStream_t aux_stream[MAX_STEP_STREAMS - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[MAX_STEP_STREAMS - 1] = {nullptr, nullptr, nullptr};
+  int step_streams_override = 0;   // CATINT_PNP_STEP_STREAMS (tuning / tests)
+  int alternate_rows = -1;         // CATINT_PNP_ALTERNATE_ROWS = 0 | 1 (tuning / tests); -1: by the size of the state
   int64_t dev_bytes = 0;
   std::string err;
 };
@@ -116,6 +123,14 @@ void pnp_destroy(pnp_handle* h) {
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (int i = 0; i < pnp_handle::MAX_STEP_STREAMS - 1; ++i) {
+    if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    if (h->aux_stream[i]) {
+      (void)hipStreamSynchronize(h->aux_stream[i]);
+      (void)hipStreamDestroy(h->aux_stream[i]);
+    }
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -232,6 +247,8 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   if (const char* e = getenv("CATINT_PNP_WAVES_PER_GRID")) h->waves_override = atoi(e);
   if (const char* e = getenv("CATINT_PNP_SPECIES_PER_WAVE")) h->species_override = atoi(e);
   if (const char* e = getenv("CATINT_PNP_KERNEL")) h->kernel_override = atoi(e);
+  if (const char* e = getenv("CATINT_PNP_STEP_STREAMS")) h->step_streams_override = atoi(e);
+  if (const char* e = getenv("CATINT_PNP_ALTERNATE_ROWS")) h->alternate_rows = atoi(e) != 0 ? 1 : 0;
   DevArgs& a = h->a;
   a.N = N;
   a.nx = cfg->nx;
@@ -441,21 +458,44 @@ static const StepTableEntry* lookup_step(int N, int P, int64_t B, bool fused) {
   return best;
 }
 
-// one or more fused timesteps in a single launch
-static int run_steps(pnp_handle* h, int nsteps) {
+// the rows [b0, b0 + nb) of the batch as a batch of their own
+static DevArgs row_chunk(const DevArgs& a, int64_t b0, int64_t nb) {
+  DevArgs r = a;
+  r.B = nb;
+  r.c = a.c + (size_t)b0 * a.N * a.ldx;
+  r.lapl_a = a.lapl_a + (size_t)b0 * a.ldx;
+  r.lapl_b = a.lapl_b + (size_t)b0 * a.ldx;
+  if (a.rates) r.rates = a.rates + (size_t)b0 * a.N * a.ldx;
+  r.pb = a.pb + (size_t)b0 * 4;
+  r.vzeta = a.vzeta + b0;
+  r.flux = a.flux + (size_t)b0 * a.N;
+  r.cbulk = a.cbulk + (size_t)b0 * a.N;
+  r.status = a.status + b0;
+  return r;
+}
+
+// one or more fused timesteps in a single launch over the rows [b0, b0 + nb) on `stream`; Bsel: the batch size the kernel
+// choice is made for (the whole call's, so that every chunk of a call runs the same kernel)
+static int run_steps_on(pnp_handle* h, int nsteps, int64_t b0, int64_t nb, hipStream_t stream) {
   DevArgs a = h->a;
+  const int64_t Bsel = a.B;
   a.nsteps = nsteps;
   a.lapl_a = h->lapl[h->cur];
   a.lapl_b = h->lapl[1 - h->cur];
+  // One timestep per launch over a state the caches cannot hold: every other launch walks the operating points from the last to
+  // the first, starting on the rows the launch before wrote last (still in L2 / MALL).  Measured (tools/probe/step_streams.py,
+  // profiles/r03_step_streams.jsonl): +6 % at 335 MB of state, nothing lost or gained at 2.1 GB, -2 % at 42 MB.
+  const bool alternate = h->alternate_rows >= 0 ? h->alternate_rows == 1 : (double)a.B * (a.N + 2) * a.ldx * 8.0 >= 128e6;
+  a.reverse = (nsteps == 1 && alternate) ? (int)(h->steps_done & 1) : 0;
+  if (a.has_rates) a.rates = h->rates;
+  if (b0 != 0 || nb != a.B) a = row_chunk(a, b0, nb);
   if (a.has_rates) {
     if (nsteps != 1) return fail(h, PNP_EINVAL, "internal: rate terms need one step per launch");
-    HIP_TRY(h, launch_rates(a, h->rt, h->rates, h->stream));
+    HIP_TRY(h, launch_rates(a, h->rt, const_cast<double*>(a.rates), stream));
   }
   // grids beyond 1026 points: several waves per tridiagonal system
   if (waves_per_system(a.nx) > 1) {
-    HIP_TRY(h, launch_step_mw(a, h->stream));
-    if (nsteps & 1) h->cur = 1 - h->cur;
-    h->steps_done += nsteps;
+    HIP_TRY(h, launch_step_mw(a, stream));
     return PNP_OK;
   }
   // Which kernel: the measured table (pnp_step_table.h, generated by tools/make_step_table.py from a sweep of every variant
@@ -464,7 +504,7 @@ static int run_steps(pnp_handle* h, int nsteps) {
   // branch with an even number of points per lane and no FTCS rate term; everything else runs the LDS-staged kernel with the
   // table's (W, G) when the entry is of that family, else with choose_step_config's.
   const bool fused = nsteps >= 8;
-  const StepTableEntry* te = lookup_step(a.N, h->P, a.B, fused);
+  const StepTableEntry* te = lookup_step(a.N, h->P, Bsel, fused);
   int kind = te ? te->kind : 0, W = te ? te->W : 1, G = te ? te->G : 1;
   const bool direct_ok = step_rr_applicable(a);
   if (kind != 0 && !direct_ok) kind = 0, W = 0;
@@ -474,14 +514,14 @@ static int run_steps(pnp_handle* h, int nsteps) {
   if (kind == 2) {
     // 16 points per lane: the gradient row of the step in LDS (two waves per SIMD instead of one: 0.53 -> 0.60 of the roofline per
     // step and 0.68 -> 0.72 fused on one GPU's share of configs[3]); shorter grids: registers only
-    const int st_mode = h->kernel_override == 6 ? 1 : (h->kernel_override == 7 ? 2 : (h->kernel_override == 5 ? 0 : ((h->P == 16 && a.B >= 2048) ? 2 : 0)));
-    HIP_TRY(h, launch_step_st(a, st_mode, h->stream));
+    const int st_mode = h->kernel_override == 6 ? 1 : (h->kernel_override == 7 ? 2 : (h->kernel_override == 5 ? 0 : ((h->P == 16 && Bsel >= 2048) ? 2 : 0)));
+    HIP_TRY(h, launch_step_st(a, st_mode, stream));
   } else if (kind == 1) {
     int w = W;
     if (h->waves_override >= 1 && h->waves_override <= 4) w = h->waves_override;
-    HIP_TRY(h, launch_step_rr(a, w, h->stream));
+    HIP_TRY(h, launch_step_rr(a, w, stream));
   } else {
-    if (W == 0 || !step_config_supported(W, G)) choose_step_config(a.N, a.B, h->P, fused, &W, &G);
+    if (W == 0 || !step_config_supported(W, G)) choose_step_config(a.N, Bsel, h->P, fused, &W, &G);
     if (h->waves_override >= 1 || h->species_override >= 1) {
       const int w2 = h->waves_override >= 1 ? h->waves_override : W;
       const int g2 = h->species_override >= 1 ? h->species_override : 1;
@@ -490,11 +530,30 @@ static int run_steps(pnp_handle* h, int nsteps) {
         G = g2;
       }
     }
-    HIP_TRY(h, launch_step(a, W, G, h->stream));
+    HIP_TRY(h, launch_step(a, W, G, stream));
   }
+  return PNP_OK;
+}
+
+static int run_steps(pnp_handle* h, int nsteps) {
+  const int rc = run_steps_on(h, nsteps, 0, h->a.B, h->stream);
+  if (rc != PNP_OK) return rc;
   if (nsteps & 1) h->cur = 1 - h->cur;
   h->steps_done += nsteps;
   return PNP_OK;
+}
+
+// Row chunks for a pnp_step call of `launches` launches: 1 = the whole batch on the handle's stream.
+// Measured (tools/probe/step_streams.py, profiles/r03_step_streams.jsonl): two chunks +3 ... 4 % from 4096 operating points up
+// (one chunk's launch boundary is covered by the other's rows), three and four no better than two, and a loss below that (a
+// chunk no longer fills the chip: -4 % at 2048, -11 % at 1024).
+static int step_streams(const pnp_handle* h, int launches) {
+  if (launches < 2) return 1;
+  int S = h->step_streams_override;
+  if (S < 1) return h->a.B >= 4096 ? 2 : 1;
+  if (S > pnp_handle::MAX_STEP_STREAMS) S = pnp_handle::MAX_STEP_STREAMS;
+  while (S > 1 && h->a.B / S < 256) --S;
+  return S;
 }
 
 // physical mode: nsteps backward-Euler steps (stationary: one solve with 1/dt = 0) in one launch
@@ -950,14 +1009,49 @@ int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch) {
   }
   int spl = steps_per_launch <= 0 ? 256 : steps_per_launch;   // kernel boundaries cost ~6 us each
   if (h->a.has_rates) spl = 1;
+  const int S = step_streams(h, (nsteps + spl - 1) / spl);
+  if (S > 1) {
+    // fork: the chunk streams start behind everything queued on the handle's stream; join: the handle's stream continues behind
+    // the last launch of every chunk.  In between each chunk's launches depend only on that chunk's previous launch.
+    if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < S - 1; ++i) {
+      if (!h->aux_stream[i]) HIP_TRY(h, hipStreamCreateWithFlags(&h->aux_stream[i], hipStreamNonBlocking));
+      if (!h->ev_join[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+    for (int i = 0; i < S - 1; ++i) HIP_TRY(h, hipStreamWaitEvent(h->aux_stream[i], h->ev_fork, 0));
+  }
+  const int64_t B = h->a.B;
   int left = nsteps;
-  while (left > 0) {
+  int rc = PNP_OK;
+  while (left > 0 && rc == PNP_OK) {
     const int n = left < spl ? left : spl;
-    const int rc = run_steps(h, n);
-    if (rc != PNP_OK) return rc;
+    if (S == 1) {
+      rc = run_steps(h, n);
+    } else {
+      for (int i = 0; i < S && rc == PNP_OK; ++i) {
+        const int64_t b0 = B * i / S, b1 = B * (i + 1) / S;
+        rc = run_steps_on(h, n, b0, b1 - b0, i == 0 ? h->stream : h->aux_stream[i - 1]);
+      }
+      if (rc == PNP_OK) {
+        if (n & 1) h->cur = 1 - h->cur;
+        h->steps_done += n;
+      }
+    }
     left -= n;
   }
-  return PNP_OK;
+  if (S > 1) {     // (also after a failed launch: whatever was queued is joined)
+    for (int i = 0; i < S - 1; ++i) {
+      HIP_TRY(h, hipEventRecord(h->ev_join[i], h->aux_stream[i]));
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+    }
+  }
+  return rc;
+}
+
+int32_t pnp_step_row_chunks(const pnp_handle* h, int32_t launches) {
+  if (!h || h->newton || !h->have_batch) return 1;
+  return step_streams(h, launches);
 }
 
 int pnp_integrate(pnp_handle* h, int32_t nt, const int32_t* itout, int32_t n_out, double* cout, int32_t* status) {

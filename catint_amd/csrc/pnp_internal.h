@@ -42,6 +42,8 @@ struct DevArgs {
   int32_t use_mig;
   int32_t nsteps;    // timesteps fused into this launch
   int32_t has_rates; // FTCS: add rates[b][k][i]*dt (computed by rates_kernel before the step)
+  int32_t reverse;   // streaming kernel: walk the operating points from the last to the first (see pnp_step: alternate launches of one
+                     // timestep start on the rows the previous launch wrote last, which the caches still hold)
   int64_t B;
   double dx, dt, beta, eps;
   double dx2, inv2dx, nxm1;   // dx*dx, 1/(2 dx), (double)(nx-1): wave-uniform fp64 values would otherwise live in (spilled) vector registers

@@ -90,8 +90,9 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
   const double dx = A.dx;
   constexpr bool cn = CN;
   const int64_t stride = gridDim.x;
-  int64_t b = blockIdx.x;
-  if (b >= A.B) return;
+  int64_t bi = blockIdx.x;
+  if (bi >= A.B) return;
+  int64_t b = A.reverse ? A.B - 1 - bi : bi;
 
   int pf0 = 0, pf1 = 0;    // L2 touches in flight (see the species loop)
   double lw[P + 2];        // lagged charge row window: lapl_v[r0 + t]
@@ -100,8 +101,10 @@ __global__ __launch_bounds__(64, (step_st_min_waves<P, GL>())) void step_kernel_
   if (A.use_mig) load_window<P, ST_AUX_LOAD>(row_rsrc(A.lapl_a + b * (int64_t)ldx, ldx), lw, lane);
   load_window<P, ST_AUX_LOAD>(row_rsrc(A.c + b * (int64_t)N * ldx, ldx), cw, lane);
 
-  for (; b < A.B; b += stride) {
-    const int64_t bn = (b + stride < A.B) ? b + stride : b;      // next operating point of this wave (the last one re-reads itself)
+  for (; bi < A.B; bi += stride) {
+    b = A.reverse ? A.B - 1 - bi : bi;
+    const int64_t bin = (bi + stride < A.B) ? bi + stride : bi;  // next operating point of this wave (the last one re-reads itself)
+    const int64_t bn = A.reverse ? A.B - 1 - bin : bin;
     double* lin = A.lapl_a + b * (int64_t)ldx;
     double* lout = A.lapl_b + b * (int64_t)ldx;
     double* crow0 = A.c + b * (int64_t)N * ldx;

@@ -123,8 +123,12 @@ int pnp_set_pb(pnp_handle* h, const double* pb /* [B][4] */, const double* vzeta
 /* ---- the hot path -------------------------------------------------------------------------- */
 /* Advance every lane by `nsteps` passes of the integrator's time-loop body. The state stays on
  * the device. `steps_per_launch` <= 0 lets the library choose (fused multi-step launches);
- * 1 forces one kernel launch per timestep with the full state read from and written to HBM. */
+ * 1 forces one kernel launch per timestep with the full state read from and written to HBM.
+ * A call of several launches over a large batch cuts the batch into row chunks whose launch sequences run on HIP streams of the
+ * handle's own (operating points are independent); the call forks from and joins into the handle's stream, so callers see the
+ * ordering of a single stream.  pnp_step_row_chunks tells how many chunks a call of `launches` launches uses. */
 int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch);
+int32_t pnp_step_row_chunks(const pnp_handle* h, int32_t launches);
 
 /* integrate_pnp (calculator_old.py:210): runs the reference's loop (n = 1..nt-1 for CN,
  * 0..nt-1 for FTCS) and copies the flattened state of every lane out at the steps listed in

@@ -69,3 +69,40 @@ def test_streaming_kernel_status_flags(monkeypatch):
         c = s.get_state(potential=False)
     assert st[301] == 2 and st[599] == 3 and (np.delete(st, [301, 599]) == 0).all()
     assert np.isfinite(np.delete(c, 301, axis=0)).all()
+
+
+@pytest.mark.parametrize('N,nx,B,kernel', [(3, 512, 1100, None), (2, 200, 1030, '2'), (4, 258, 2049, '4'), (3, 1024, 2300, '7'), (2, 2050, 530, None)])
+@pytest.mark.parametrize('method', ['Crank-Nicolson', 'FTCS'])
+def test_row_chunks_on_streams_of_their_own_change_nothing(N, nx, B, kernel, method, monkeypatch):
+    """pnp_step with several launches in one call cuts the batch into row chunks whose launch sequences run on separate HIP
+    streams (pnp_capi.hip: step_streams), and every other launch of one timestep may walk its rows from the last to the first:
+    the same kernels on the same rows, so the state is the same to the bit as with one stream and one direction -- also with an odd batch, three and four chunks, the charge row's ping-pong over an odd number of steps, and work
+    queued on the handle's stream before (upload) and after (read-back)."""
+    p, c0, pb, vz, fl = make_batch(B, N, nx, seed=B, phi_max=0.02, dt_factor=1e-4 if method == 'Crank-Nicolson' else 2e-5)
+    rng = np.random.default_rng(B)
+    c0 = c0 * (1 + 0.05 * rng.uniform(-1, 1, c0.shape))
+    fl = rng.uniform(-1e-4, 1e-4, fl.shape)
+    if kernel:
+        monkeypatch.setenv('CATINT_PNP_KERNEL', kernel)
+    monkeypatch.setenv('CATINT_PNP_STEP_STREAMS', '1')
+    monkeypatch.setenv('CATINT_PNP_ALTERNATE_ROWS', '0')
+    ref = run(p, method, c0, pb, vz, fl, 5, 1)
+    ref2 = run(p, method, c0, pb, vz, fl, 6, 2)
+    for S in ('1', '2', '3', '4'):
+        monkeypatch.setenv('CATINT_PNP_STEP_STREAMS', S)
+        monkeypatch.setenv('CATINT_PNP_ALTERNATE_ROWS', '1')      # (every other one-step launch walks the rows backwards)
+        got = run(p, method, c0, pb, vz, fl, 5, 1)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), S
+        with solver_from_problem(p, method, batch_capacity=B) as s:       # two calls back to back, then more steps in one launch
+            s.set_batch(c0, pb, vz, fl)
+            s.step(2, 2)
+            s.step(4, 2)
+            got2 = s.get_state() + (s.get_status(),)
+        for a, b in zip(got2, ref2):
+            assert np.array_equal(a, b), S
+    monkeypatch.delenv('CATINT_PNP_STEP_STREAMS')
+    monkeypatch.delenv('CATINT_PNP_ALTERNATE_ROWS')
+    got = run(p, method, c0, pb, vz, fl, 5, 1)                             # the default
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
