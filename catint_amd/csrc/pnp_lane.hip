@@ -776,12 +776,14 @@ bool newton_lane_preferred(int nb, int nx, int64_t B, int mode) {
   // nx = 512: 3.4 ms per Newton iteration), so its rate grows with the batch until every SIMD holds a wave (B = 32 768) and is
   // HBM-bound from there on; the workgroup-per-point kernels saturate at a few hundred points.  Crossovers:
   //   N >= 5:  0.4-0.6 x at B = 512, 1.3-1.7 x at 2048, 4-5 x at 8192, 8-10 x at 32 768
-  //   N = 4:   0.6-0.9 x at 2048, 1.8-3.5 x at 8192 (the pair kernel spills there)
+  //   N = 4:   against the pair kernel in its 512-register build (tools/probe/pair_crossover.py, profiles/r03_pair_crossover.jsonl):
+  //            0.36-0.38 x at 2048, 0.64-0.69 x at 4096, 1.07-1.15 x at 8192, 1.5-1.6 x at 16 384, 2.1 x at 32 768; grids too long
+  //            for the pair kernel (nx > 512): 0.9-1.0 x at 2048, 1.65 x at 4096, 2.9 x at 8192 against the lane teams
   //   N = 3:   0.6-0.75 x at 8192, 1.1-1.5 x at 32 768 against the pair kernel; grids too long for it (nx > 1024): 2.7 x at 8192
   //   N = 2:   only on grids too long for the pair kernel (1.95 x at B = 8192, nx = 4096)
   if (nb >= 6) return B >= 1280;
-  if (nb == 5) return B >= 4096;
   const bool pair = newton_pair_threads(nb, nx) > 0;
+  if (nb == 5) return pair ? B >= 8192 : B >= 3072;
   if (nb == 4) return pair ? B >= 24576 : B >= 4096;
   if (nb == 3) return !pair && B >= 4096;
   return false;

@@ -766,8 +766,14 @@ __device__ __forceinline__ void mm_sub(double (&acc)[NB][NC], int c0, const doub
       for (int j = 0; j < NB; ++j) acc[r][c0 + cc] = __builtin_fma(-A[r][j], Q[j][cc], acc[r][c0 + cc]);
 }
 
+// Register budget: 5 x 5 blocks (N = 4) need ~330 registers for the thread's two block rows, and their exchange buffer ((2 NB^2 + NB) TS
+// doubles: 112 KB at TS = 256) leaves room for one workgroup of at most four waves per CU anyway -- one wave per SIMD, so the whole
+// 512-entry file (256 VGPR + 256 AGPR) is the wave's: bound to 256 threads, the spills go to accumulator registers instead of
+// scratch (740 B per lane before): 3.45e6 -> 5.24e6 Newton iterations/s at N = 4, nx = 512, B = 1024 (steric ions 2.5e6 -> 4.7e6, reactions
+// 2.3e6 -> 4.2e6; profiles/r03_pair_kernel_register_budget_ab.txt).  Smaller blocks fit 256 registers and keep two waves per SIMD: the
+// steric N = 3 instances (172-192 B of scratch) lose 14-24 % when given 512 registers and one wave per SIMD instead.
 template <int NB, int TS, int MODE>
-__global__ __launch_bounds__(512) void newton_pair_kernel(const NewtonArgs G) {
+__global__ __launch_bounds__(NB >= 5 ? 256 : 512) void newton_pair_kernel(const NewtonArgs G) {
   // The scalar parameters (six constants per species, boundary model, tolerances) do not fit the SGPR file next to the
   // pointers: left in the kernel-argument segment they end up as spilled scalars reloaded ~120 times per Newton iteration.
   // A copy in LDS costs broadcast ds_reads instead (+6 % at batch 1024, +15 % at 8192); pointers stay kernel arguments (G)
@@ -2314,9 +2320,10 @@ bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode) {
   // at least one wave of teams per SIMD (1024 SIMDs): below that the chip is not full and, with uniform control flow, a wave
   // waits for its slowest lane -- the CO2R example (7 species, 4096 lanes, iteration counts 3...30) took 0.84 s instead of 0.51 s
   const int64_t waves = (B + 64 / nb - 1) / (64 / nb);
-  if (nb >= 6) return waves >= 1024;
-  // N = 4 with steric ions or reactions: the pair kernel spills there (2.5e6 iterations/s against 3.0-3.6e6; equal for point ions)
-  return nb == 5 && mode >= 1 && waves >= 1280;
+  // (N = 4: the pair kernel in its 512-register build is ahead of the sweep at every batch, 1.4e6 against 0.35-0.99e6 timesteps/s
+  // with steric ions at nx = 512 -- profiles/r03_pair_crossover.jsonl; round 2 sent steric / reacting N = 4 batches here from
+  // 15 k lanes on because the 256-register pair kernel spilled)
+  return nb >= 6 && waves >= 1024;
 }
 
 template <int NB, int TMAX>
