@@ -120,9 +120,9 @@ def pmc_child(args):
             s, inp = newton_solver(8192, 8, 512, 4444, steric=True)
             item(s, inp, lambda s, w: s.step(2))
             s, inp = newton_solver(32768, 8, 512, 4446, steric=True)
-            item(s, inp, lambda s, w: s.step(2))
+            item(s, inp, lambda s, w: s.step(6))
             s, inp = newton_solver(BC_SHAPE[0], BC_SHAPE[1], BC_SHAPE[2], 4447, steric=True)
-            item(s, inp, lambda s, w: s.step(2))
+            item(s, inp, lambda s, w: s.step(4))
         if args.large_batch > 0:
             s, inp = compat_solver(args.large_batch, N, nx, args.method, 77)
             item(s, inp, lambda s, w: s.step(8, 1))
@@ -400,7 +400,7 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
     def lane_bytes(N_, nx_):
         return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + 6 * N_ + 5)
 
-    def lane_record(LB, LN, LX, seed, steps, pmc_key, what):
+    def lane_record(LB, LN, LX, seed, steps, pmc_key, what, pmc_steps=2):
         s8, inp = newton_solver(LB, LN, LX, seed, device, steric=True)
         s8.set_batch(*inp[1:])
         s8.step(1)
@@ -410,8 +410,8 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         it8 = s8.newton_iterations()
         ok8 = int((s8.get_status() == 0).sum())
         s8.set_batch(*inp[1:])
-        s8.step(2)
-        ms2 = timed_steps(s8, 2, 0)                # the launch shape the counters were collected on: 2 steps
+        s8.step(pmc_steps)
+        ms2 = timed_steps(s8, pmc_steps, 0)        # the launch shape the counters were collected on (pmc_child)
         it2 = float(s8.newton_iterations().sum())
         s8.close()
         its = float(it8.sum())
@@ -434,7 +434,7 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
             roof['hbm_frac_measured'] = roof['hbm_GBs_measured'] / HBM_PEAK_GBS
             roof['traffic_note'] = ('a wave iterates until the slowest of its 32 operating points has finished its timesteps; lanes that '
                                     'finished earlier still stream their records, so measured bytes per LANE-iteration exceed the '
-                                    'algorithmic figure by the spread of the iteration counts (2-step launch: ~1.2x, long launches ~1.05x)')
+                                    'algorithmic figure by the spread of the iteration counts (2-step launch: ~1.15x, long launches less)')
             lim = limiter_from_sq(pr)
             if lim:
                 roof['sq'] = lim
@@ -453,18 +453,20 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         return rec
 
     try:
-        out['large_batch_8_species'] = lane_record(8192, 8, 512, 4444, 10, 'physical_sweep',
-                                                   'one wave per CU (256 waves), paced by the arithmetic and the latency of a single wave')
-        out['large_batch_8_species_32k'] = lane_record(32768, 8, 512, 4446, 6, 'physical_lane_32k', 'one wave per SIMD (1024 waves)')
+        out['large_batch_8_species'] = lane_record(8192, 8, 512, 4444, 20, 'physical_sweep',
+                                                   'lane-pair kernel, four lanes per operating point: 512 waves on 1024 SIMDs, paced by the '
+                                                   'arithmetic and the latency of a single wave')
+        out['large_batch_8_species_32k'] = lane_record(32768, 8, 512, 4446, 20, 'physical_lane_32k',
+                                                       'lane kernel, one wave per SIMD (1024 waves); 20 timesteps in one launch', pmc_steps=6)
     except Exception as e:
         out['large_batch_8_species'] = {'error': str(e)}
     try:      # one GPU's share of BASELINE configs[3] in the coupled-Newton mode
-        out['config3_share'] = lane_record(BC_SHAPE[0], BC_SHAPE[1], BC_SHAPE[2], 4447, 4, 'physical_lane_config3',
-                                           "one GPU's share of configs[3] (262144 points over 8 GPUs)")
+        out['config3_share'] = lane_record(BC_SHAPE[0], BC_SHAPE[1], BC_SHAPE[2], 4447, 10, 'physical_lane_config3',
+                                           "one GPU's share of configs[3] (262144 points over 8 GPUs); 10 timesteps in one launch", pmc_steps=4)
     except Exception as e:
         out['config3_share'] = {'error': str(e)}
     try:      # one GPU's share of BASELINE configs[4]: 8192 lanes x 8 species x 4096 points (24 GB of records)
-        out['config4_share'] = lane_record(8192, 8, 4096, 4448, 2, None, "one GPU's share of configs[4] (65536 points over 8 GPUs)")
+        out['config4_share'] = lane_record(8192, 8, 4096, 4448, 4, None, "one GPU's share of configs[4] (65536 points over 8 GPUs)")
     except Exception as e:
         out['config4_share'] = {'error': str(e)}
     try:      # below the lane kernel's crossover: lane teams, two-sided sweep
