@@ -30,7 +30,7 @@ STATUS_OK, STATUS_MAXIT, STATUS_NAN, STATUS_NEGATIVE = 0, 1, 2, 3
 # every symbol include/catint_pnp.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     'pnp_create', 'pnp_destroy', 'pnp_last_error', 'pnp_version', 'pnp_set_species', 'pnp_set_reactions',
-    'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_integrate_dopri5', 'pnp_integrate_dop853', 'pnp_get_state',
+    'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_integrate_dopri5', 'pnp_integrate_dop853', 'pnp_integrate_rkc', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_step_row_chunks', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
     'pnp_set_potential', 'pnp_set_lanes', 'pnp_set_lane_mask', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
@@ -141,6 +141,8 @@ def load_library():
     lib.pnp_integrate_dopri5.restype = C.c_int
     lib.pnp_integrate_dop853.argtypes = lib.pnp_integrate_dopri5.argtypes
     lib.pnp_integrate_dop853.restype = C.c_int
+    lib.pnp_integrate_rkc.argtypes = lib.pnp_integrate_dopri5.argtypes
+    lib.pnp_integrate_rkc.restype = C.c_int
     lib.pnp_set_wall_rate_law.argtypes = [vp, C.c_int32, dp, dp]
     lib.pnp_set_wall_rate_law.restype = C.c_int
     lib.pnp_set_grid.argtypes = [vp, dp]
@@ -385,6 +387,22 @@ class PnpSolver(object):
         """scipy.integrate.ode('dop853') of every lane on the device (keyword names and defaults are scipy's for this integrator)."""
         return self._integrate_rk(self._lib.pnp_integrate_dop853, nt, itout, rtol, atol, nsteps, first_step, max_step, safety, ifactor,
                                   dfactor, beta, nstiff, check_every)
+
+    def integrate_rkc(self, nt, itout, rtol=1e-6, atol=1e-12, nsteps=100000, max_step=0.0, check_every=0):
+        """Stiff method-of-lines integration of every lane on the device (pnp_integrate_rkc: Runge-Kutta-Chebyshev with error control,
+        the batched counterpart of odeint / ode('vode' | 'lsoda'), calculator_old.py:946-963).  Returns (cout[n_out, B, N*nx] = state
+        after interval itout[j], idid[B], stats[B, 7] = attempted / accepted / rejected steps, RHS evaluations of the steps, interval
+        of the last call, RHS evaluations of the spectral-radius estimates, largest stage count; t_end[B])."""
+        itout = np.ascontiguousarray(itout, dtype=np.int32)
+        cout = np.zeros((len(itout), self.B, self.N * self.nx))
+        idid = np.zeros(self.B, np.int32)
+        stats = np.zeros((self.B, 7), np.int64)
+        t_end = np.zeros(self.B)
+        p = PnpOdeParams(C.sizeof(PnpOdeParams), int(nsteps), float(rtol), float(atol), 0.0, float(max_step), 0.0, 0.0, 0.0, 0.0, 0,
+                         int(check_every))
+        self._check(self._lib.pnp_integrate_rkc(self._h, C.byref(p), int(nt), _iptr(itout), len(itout), _dptr(cout), _iptr(idid),
+                                                stats.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(t_end)))
+        return cout, idid, stats, t_end
 
     def _integrate_rk(self, fn, nt, itout, rtol, atol, nsteps, first_step, max_step, safety, ifactor, dfactor, beta, nstiff, check_every):
         itout = np.ascontiguousarray(itout, dtype=np.int32)

@@ -21,11 +21,15 @@ from .units import unit_F
 CALC_LIST = ['FTCS', 'Crank-Nicolson', 'odeint', 'vode', 'lsoda', 'dopri5', 'dop853', 'odeint', 'odespy', 'comsol']
 CALC_LIST = CALC_LIST + ['Newton']
 GPU_CALCS = ('FTCS', 'Crank-Nicolson')
-MOL_CALCS = ('odeint', 'lsoda', 'dopri5', 'dop853')   # method of lines: RHS on the GPU; 'dopri5' integrates on the device too, the others through scipy
+MOL_CALCS = ('odeint', 'lsoda', 'vode', 'dopri5', 'dop853')   # method of lines: RHS on the GPU; 'dopri5' integrates on the device too, the others through scipy
 # physical mode: what run_single_step asks COMSOL for (calculator.py:408-535, comsol_wrapper.py:145,158) solved on the
 # GPU by the fully implicit coupled Newton kernel; 'comsol' is accepted as its name so reference scripts keep working
 PHYSICAL_CALCS = ('comsol', 'Newton')
 DEVICE_ODE_CALCS = ('dopri5', 'dop853')     # explicit Runge-Kutta integrators that run on the device (pnp_ode.hip)
+# The reference's stiff drivers (odeint = LSODA, ode('vode' | 'lsoda'): calculator_old.py:946-963) take one operating point per call
+# on the host.  Over a BATCH of operating points their role is played by the stiff integrator on the device (pnp_integrate_rkc:
+# Runge-Kutta-Chebyshev with error control, pnp_rkc.hip) -- same tolerances, same output indexing, results within the tolerance.
+DEVICE_STIFF_CALCS = ('odeint', 'lsoda', 'vode')
 
 
 class CalculatorError(ValueError):
@@ -149,12 +153,22 @@ class Calculator(object):
         modes = {pb_mode_from_bound(p) for p in pb}
         if len(modes) != 1:
             raise CalculatorError('all lanes of a batch must use the same pb_bound combination')
-        if self.calc in MOL_CALCS and self.calc not in DEVICE_ODE_CALCS:
-            raise CalculatorError("descriptor sweeps along the method of lines run with calc='dopri5' / 'dop853' (integrator on the device); "
-                                  "'%s' is driven by scipy, one operating point at a time (integrate_pnp)" % self.calc)
         with self._solver(B, modes.pop(), dx, nx, dt) as s:
             s.set_batch(c0, pb, vzeta, flux)
-            if self.calc in DEVICE_ODE_CALCS:
+            if self.calc in DEVICE_STIFF_CALCS:
+                # every lane its own adaptive RKC (pnp_integrate_rkc).  odeint returns the state at tmesh[n] (calculator_old.py:946-948:
+                # row 0 is the initial state), the ode family the state at (n + 1) dt (:959-969).
+                shift = 1 if self.calc in ('odeint', 'lsoda') else 0
+                wanted = [int(n) for n in itout if n < nt]
+                out = [n - shift for n in wanted if n - shift >= 0]
+                opts = {k: v for k, v in getattr(self, 'ode_options', {}).items() if k in ('rtol', 'atol', 'nsteps', 'max_step', 'check_every')}
+                cdev, idid, self.ode_stats, _ = s.integrate_rkc(nt, out, **opts)
+                cout = np.zeros((len(wanted), B, c0.shape[1]))
+                for j, n in enumerate(wanted):
+                    cout[j] = c0 if n - shift < 0 else cdev[out.index(n - shift)]
+                self.ode_idid = idid
+                status = (idid < 0).astype(np.int32)
+            elif self.calc in DEVICE_ODE_CALCS:
                 # every lane its own adaptive DOPRI5 / DOP853 (pnp_integrate_dopri5 / _dop853); output n = state at (n+1) dt (calculator_old.py:959-969);
                 # status: 0 ok, 1 = the integrator gave up on the lane (nsteps / step size / stiffness: self.ode_idid)
                 out = [int(n) for n in itout if n < nt]

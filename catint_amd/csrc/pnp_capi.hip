@@ -32,6 +32,8 @@ struct pnp_handle {
   double* ode_buf = nullptr;                 // pnp_integrate_dopri5 / _dop853: k buffers, y1, ysti ([cap][N][ldx] each) + per-lane reals
   int ode_nbuf = 0;                          // state-sized buffers in ode_buf (8 DOPRI5, 12 DOP853)
   int32_t* ode_int = nullptr;                // ... per-lane integers + 64 counters
+  double* rkc_d = nullptr;                   // pnp_integrate_rkc: per-lane reals [cap][RKC_ND] (the state-sized buffers are ode_buf's)
+  int32_t* rkc_i = nullptr;                  // ... per-lane integers [cap][RKC_NI] + 64 counters
   double* stage = nullptr;                   // upload staging [B][N][nx] (pnp_set_batch)
   SpecConst* spec = nullptr;
   int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
@@ -119,7 +121,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->lane2_buf, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->lane2_buf, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int, (void*)h->rkc_d, (void*)h->rkc_i})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1301,6 +1303,116 @@ int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, con
 int pnp_integrate_dop853(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
                          int32_t* idid, int64_t* stats, double* t_end) {
   return integrate_explicit_rk(h, p, nt, itout, n_out, cout, idid, stats, t_end, 8);
+}
+
+int pnp_integrate_rkc(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
+                      int32_t* idid, int64_t* stats, double* t_end) {
+  if (!h || !p) return fail(h, PNP_EINVAL, "pnp_integrate_rkc: null argument");
+  if (h->newton) return fail(h, PNP_EINVAL, "pnp_integrate_rkc: not part of the physical mode");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_integrate_rkc: call pnp_set_batch first");
+  if (p->struct_size != (int32_t)sizeof(pnp_ode_params)) return fail(h, PNP_EINVAL, "pnp_integrate_rkc: struct_size mismatch (ABI)");
+  if (nt < 0 || n_out < 0 || (n_out > 0 && (!itout || !cout))) return fail(h, PNP_EINVAL, "pnp_integrate_rkc: bad output request");
+  for (int j = 0; j < n_out; ++j)
+    if (itout[j] < 0 || itout[j] >= nt || (j > 0 && itout[j] <= itout[j - 1]))
+      return fail(h, PNP_EINVAL, "pnp_integrate_rkc: itout must be ascending and inside [0, nt)");
+  if (p->rtol < 0.0 || p->atol < 0.0 || p->max_step < 0.0 || p->nsteps < 0) return fail(h, PNP_EINVAL, "pnp_integrate_rkc: negative parameter");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
+  const int64_t B = h->B, cap = h->cfg.batch_capacity;
+  const size_t cnt = (size_t)cap * N * ldx;
+  hipStream_t st = h->stream;
+  const int nbuf = 8;      // (DOPRI5's workspace: five of its buffers are used here)
+  if (!h->ode_buf) {
+    HIP_TRY(h, dev_alloc(h, &h->ode_buf, (size_t)nbuf * cnt + (size_t)cap * ODE_ND));
+    h->ode_nbuf = nbuf;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->ode_buf, 0, (size_t)5 * cnt * sizeof(double), st));   // pads of the rows stay zero
+  if (!h->rkc_d) HIP_TRY(h, dev_alloc(h, &h->rkc_d, (size_t)cap * RKC_ND));
+  if (!h->rkc_i) HIP_TRY(h, dev_alloc(h, &h->rkc_i, (size_t)cap * RKC_NI + 64));
+  RkcArgs a;
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.nx = nx; a.ldx = ldx; a.B = B;
+  a.nmax = p->nsteps > 0 ? p->nsteps : 100000;
+  a.rtol = p->rtol > 0.0 ? p->rtol : 1e-6;
+  a.atol = p->atol > 0.0 ? p->atol : 1e-12;
+  {
+    const double mm = std::sqrt(a.rtol / (10.0 * 2.22e-16));      // beyond this many stages the recurrence amplifies round-off (rkc.f)
+    a.mmax = (int32_t)std::llround(mm < 2.0 ? 2.0 : (mm > 1.0e6 ? 1.0e6 : mm));
+  }
+  a.max_step = p->max_step;
+  a.dt = h->a.dt;
+  a.y = h->c;
+  a.fn = h->ode_buf;
+  a.F = h->ode_buf + cnt;
+  a.arg = h->ode_buf + 2 * cnt;
+  a.yjm2 = h->ode_buf + 3 * cnt;
+  a.ev = h->ode_buf + 4 * cnt;
+  a.d = h->rkc_d;
+  a.i = h->rkc_i;
+  a.counters = h->rkc_i + (size_t)cap * RKC_NI;
+  HIP_TRY(h, hipMemsetAsync(a.d, 0, (size_t)cap * RKC_ND * sizeof(double), st));
+  HIP_TRY(h, hipMemsetAsync(a.i, 0, ((size_t)cap * RKC_NI + 64) * sizeof(int32_t), st));
+  {   // IDID = 1
+    std::vector<int32_t> i0((size_t)B * RKC_NI, 0);
+    for (int64_t b = 0; b < B; ++b) {
+      i0[b * RKC_NI + RKI_IDID] = 1;
+      i0[b * RKC_NI + RKI_INTERVAL] = -1;
+    }
+    HIP_TRY(h, hipMemcpyAsync(a.i, i0.data(), i0.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+  }
+  const int every = p->check_every > 0 ? (p->check_every < 32 ? p->check_every : 32) : 16;
+  const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
+  int next_out = 0;
+  int64_t tick = 0;
+  for (int n = 0; n < nt; ++n) {
+    a.interval = n;
+    HIP_TRY(h, launch_rkc_begin(a, st));
+    a.slot = (int32_t)(tick++ & 63);
+    HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
+    HIP_TRY(h, launch_rkc_advance(a, st));      // first call: argument = the state; later calls: the next step's first stage
+    int32_t left = 1;
+    // a lane needs at most nmax attempted steps of at most mmax + 1 ticks, plus the power iterations (<= 50 per estimate)
+    const int64_t limit = ((int64_t)a.nmax + 1) * ((int64_t)a.mmax + 53) + 64;
+    for (int64_t tries = 0; left != 0 && tries <= limit; tries += every) {
+      for (int e = 0; e < every; ++e) {
+        const int rc = eval_mol_rhs(h, a.arg, a.F);
+        if (rc != PNP_OK) return rc;
+        a.slot = (int32_t)(tick++ & 63);
+        HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
+        HIP_TRY(h, launch_rkc_advance(a, st));
+      }
+      HIP_TRY(h, hipMemcpyAsync(&left, a.counters + a.slot, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    if (next_out < n_out && itout[next_out] == n) {
+      HIP_TRY(h, hipMemcpy2DAsync(cout + (size_t)next_out * B * N * nx, w, a.y, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, st));
+      ++next_out;
+    }
+  }
+  h->cur = 0;
+  HIP_TRY(h, launch_charge_row(h->a, h->lapl[0], st));
+  h->steps_done = 0;
+  std::vector<double> dh((size_t)B * RKC_ND);
+  std::vector<int32_t> ih((size_t)B * RKC_NI);
+  HIP_TRY(h, hipMemcpyAsync(dh.data(), a.d, dh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(ih.data(), a.i, ih.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t* s = ih.data() + b * RKC_NI;
+    if (idid) idid[b] = s[RKI_IDID];
+    if (t_end) t_end[b] = dh[b * RKC_ND + RKC_T];
+    if (stats) {
+      stats[b * 7 + 0] = s[RKI_TOT_NSTEP];
+      stats[b * 7 + 1] = s[RKI_TOT_NACCPT];
+      stats[b * 7 + 2] = s[RKI_TOT_NREJCT];
+      stats[b * 7 + 3] = s[RKI_TOT_NFE];
+      stats[b * 7 + 4] = s[RKI_INTERVAL];
+      stats[b * 7 + 5] = s[RKI_TOT_NFESIG];
+      stats[b * 7 + 6] = s[RKI_MAXM];
+    }
+  }
+  return PNP_OK;
 }
 
 int pnp_get_state(pnp_handle* h, double* c, double* v, double* grad_v, double* lapl_v) {

@@ -239,4 +239,29 @@ hipError_t launch_ode853_stage(const OdeArgs& a, int stage, hipStream_t stream);
 int ode853_stage_dst(int stage);     // k buffer that receives f(stage argument)
 hipError_t launch_ode853_control(const OdeArgs& a, int half, hipStream_t stream);
 
+// ---- stabilised explicit integrator for stiff right-hand sides (pnp_rkc.hip; RKC of Sommeijer, Shampine, Verwer): the batched
+// counterpart of the reference's odeint / ode('vode' | 'lsoda') drivers (calculator_old.py:946-963) ----
+enum { RKC_T = 0, RKC_TEND, RKC_ABSH, RKC_H, RKC_HOLD, RKC_ERROLD, RKC_SPRAD, RKC_HMAX, RKC_SIGMA, RKC_DYNRM, RKC_W0, RKC_W1,
+       RKC_BJM1, RKC_BJM2, RKC_ZJM1, RKC_ZJM2, RKC_DZJM1, RKC_DZJM2, RKC_D2ZJM1, RKC_D2ZJM2, RKC_ERR, RKC_ND = 24 };
+enum { RKI_ACTIVE = 0, RKI_PHASE, RKI_J, RKI_M, RKI_LAST, RKI_NSTSIG, RKI_NEWSPC, RKI_JACATT, RKI_IDID, RKI_NSTEP_CALL, RKI_FIRST,
+       RKI_HAVE_EV, RKI_STARTED, RKI_RHO_IT, RKI_INTERVAL, RKI_TOT_NSTEP, RKI_TOT_NACCPT, RKI_TOT_NREJCT, RKI_TOT_NFE, RKI_TOT_NFESIG,
+       RKI_MAXM, RKC_NI = 24 };
+struct RkcArgs {
+  int32_t N, nx, ldx, nmax;
+  int32_t mmax, slot, interval, pad_;
+  int64_t B;
+  double rtol, atol, max_step, dt;
+  double* y;          // [B][N][ldx] y_n: the state (the handle's c)
+  double* fn;         // f(y_n)
+  double* F;          // f(arg) of the tick
+  double* arg;        // where the right-hand side is wanted next: Y_{j-1} of the stage recurrence / power iterate / Euler probe
+  double* yjm2;       // Y_{j-2}
+  double* ev;         // eigenvector estimate of the power iteration (kept from one estimate to the next)
+  double* d;          // [B][RKC_ND]
+  int32_t* i;         // [B][RKC_NI]
+  int32_t* counters;  // [64] lanes still inside the interval after a tick (slot = tick & 63)
+};
+hipError_t launch_rkc_begin(const RkcArgs& a, hipStream_t stream);
+hipError_t launch_rkc_advance(const RkcArgs& a, hipStream_t stream);
+
 }  // namespace pnp

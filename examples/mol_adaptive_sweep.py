@@ -7,6 +7,7 @@ The reference runs its `calc='dopri5'` / `'dop853'` path one operating point at 
 history, no host round trip per right-hand-side evaluation.
 
     python examples/mol_adaptive_sweep.py --lanes 64 --calc dop853
+    python examples/mol_adaptive_sweep.py --lanes 4096 --calc odeint --tmax 1e-6      # stiff: steps far beyond dx^2 / (2 D)
 """
 import argparse
 import collections
@@ -25,7 +26,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--lanes', type=int, default=32)
     ap.add_argument('--nx', type=int, default=96)
-    ap.add_argument('--calc', default='dopri5', choices=['dopri5', 'dop853'])
+    ap.add_argument('--calc', default='dopri5', choices=['dopri5', 'dop853', 'odeint', 'lsoda', 'vode'],
+                    help="'odeint' / 'lsoda' / 'vode': the stiff integrator on the device (Runge-Kutta-Chebyshev, pnp_integrate_rkc)")
     ap.add_argument('--dt', type=float, default=5e-10)
     ap.add_argument('--tmax', type=float, default=5e-9)
     a = ap.parse_args(argv)

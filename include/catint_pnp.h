@@ -172,6 +172,20 @@ int pnp_integrate_dopri5(pnp_handle* h, const pnp_ode_params* p, int32_t nt, con
 int pnp_integrate_dop853(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
                          int32_t* idid, int64_t* stats, double* t_end);
 
+/* The batched counterpart of the reference's STIFF drivers of the method of lines -- scipy.integrate.odeint (LSODA,
+ * calculator_old.py:946-948) and ode('vode' | 'lsoda') (:955-963), which integrate one operating point per call on the host with
+ * implicit multistep formulas.  On the device every lane runs RKC (Sommeijer, Shampine, Verwer 1998: second-order Runge-Kutta-
+ * Chebyshev, m stages per step cover 0.65 m^2 / rho of the negative real axis; m follows from a spectral radius the integrator
+ * estimates itself, the local error is controlled per lane with rtol / atol as in the other integrators): nothing but right-hand
+ * sides, steps far beyond the explicit limit.  Results agree with odeint within the tolerance, not bit for bit (another formula).
+ * Uses rtol, atol, nsteps (attempted steps per interval, default 100000), max_step, check_every (ticks between two reads of the
+ * "lanes left" counter, default 16) of pnp_ode_params; the other fields are ignored.  Output as pnp_integrate_dopri5 (cout = state after
+ * interval itout[j], i.e. at (n+1) dt).  idid[B]: 1 ok, -2 nsteps exceeded, -3 step size too small, -6 the power iteration for the
+ * spectral radius did not converge; stats[B][7] (nullable): attempted, accepted, rejected steps, right-hand sides of the steps,
+ * interval of the last call, right-hand sides of the spectral-radius estimates, largest stage count. */
+int pnp_integrate_rkc(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const int32_t* itout, int32_t n_out, double* cout,
+                      int32_t* idid, int64_t* stats, double* t_end);
+
 /* ---- physical mode (PNP_METHOD_NEWTON) -------------------------------------------------------------- */
 typedef struct pnp_newton_params {
   int32_t struct_size;       /* = sizeof(pnp_newton_params) */

@@ -270,7 +270,7 @@ def test_dop853_against_scipy_lanes_and_failures():
         assert relerr(a, b) < 1e-9
 
 
-@pytest.mark.parametrize('calc', ['dopri5', 'dop853'])
+@pytest.mark.parametrize('calc', ['dopri5', 'dop853', 'odeint'])
 def test_adaptive_sweep_example_runs(calc):
     import importlib.util
     spec = importlib.util.spec_from_file_location('mol_adaptive_sweep', os.path.join(os.path.dirname(GOLDEN), '..', 'examples', 'mol_adaptive_sweep.py'))
@@ -280,3 +280,121 @@ def test_adaptive_sweep_example_runs(calc):
     assert (out['idid'] == 1).all() and out['stats'][:, 0].min() >= 4
     k = out['surface_K']
     assert np.all(np.diff(k) < 0) and k[0] > 30.0 > k[-1]       # cations pile up at negative wall potentials, deplete at positive ones
+
+
+# ---- the stiff integrator on the device: RKC (pnp_integrate_rkc), batched counterpart of odeint / ode('vode' | 'lsoda') ---------------
+def rkc_oracle_run(s, lane_state, lane, nt, **kw):
+    """oracle/rkc.py on lane `lane`, driving the device right-hand side from the host."""
+    from oracle.rkc import Rkc
+    state = np.array(lane_state, float)
+
+    def f(t, y):
+        state[lane] = y
+        return s.mol_rhs(state)[lane]
+    o = Rkc(f, **kw).set_initial_value(lane_state[lane].copy())
+    out = []
+    for n in range(nt):
+        if not o.successful():
+            break
+        out.append(o.integrate((n + 1) * s.dt_ode).copy())
+    return o, out
+
+
+@pytest.mark.parametrize('interval,kw', [(100, {}), (10000, {}), (10000, {'rtol': 1e-4, 'atol': 1e-9}), (2000, {'rtol': 1e-8}),
+                                         (10000, {'max_step': 2e-8})])
+def test_rkc_same_steps_and_stage_counts_as_the_oracle(interval, kw):
+    """Intervals of 100 ... 10 000 times the reference fixture's (1e-9 ... 1e-7 s: up to 400 times the explicit stability limit): the
+    device takes the oracle's steps -- same attempted / accepted / rejected counts, same right-hand-side evaluations incl. those of the
+    power iteration, same largest stage count -- and lands on the same state to rounding."""
+    d, p, c0, nt, itout = golden_problem(interval=interval)
+    nt = 5
+    with solver_from_problem(p, 'FTCS', batch_capacity=1) as s:
+        s.set_batch(c0[None, :], p.pb[None, :], [p.vzeta], p.flux_bound[None, :])
+        o, ref = rkc_oracle_run(s, c0[None, :].copy(), 0, nt, **kw)
+        s.set_batch(c0[None, :], p.pb[None, :], [p.vzeta], p.flux_bound[None, :])
+        cout, idid, stats, t_end = s.integrate_rkc(nt, list(range(nt)), **kw)
+        c_end = s.get_state()[0]
+    assert idid[0] == 1 and o.idid == 1
+    assert list(stats[0]) == [o.nsteps, o.naccpt, o.nrejct, o.nfe, nt - 1, o.nfesig, o.maxm]
+    assert interval < 10000 or o.maxm >= 8                   # steps well beyond the explicit limit
+    assert t_end[0] == nt * p.dt
+    for n in range(nt):
+        assert relerr(cout[n, 0], ref[n]) < 1e-10
+    assert np.array_equal(c_end[0].reshape(-1), cout[-1, 0])
+
+
+def test_rkc_agrees_with_odeint_within_the_tolerance():
+    """scipy's odeint (LSODA: what the reference calls, calculator_old.py:946-948) on the same device right-hand side."""
+    import scipy.integrate as si
+    d, p, c0, nt, itout = golden_problem(interval=10000)
+    nt = 4
+    with solver_from_problem(p, 'FTCS', batch_capacity=1) as s:
+        s.set_batch(c0[None, :], p.pb[None, :], [p.vzeta], p.flux_bound[None, :])
+        ts = np.arange(nt + 1) * p.dt
+        ref = si.odeint(lambda y, t: s.mol_rhs(y[None, :])[0], c0, ts, rtol=1e-10, atol=1e-14, mxstep=200000)
+        for rtol, bound in ((1e-4, 2e-3), (1e-6, 5e-5), (1e-8, 2e-6)):
+            s.set_batch(c0[None, :], p.pb[None, :], [p.vzeta], p.flux_bound[None, :])
+            cout, idid, stats, _ = s.integrate_rkc(nt, list(range(nt)), rtol=rtol, atol=1e-12)
+            assert idid[0] == 1
+            err = max(relerr(cout[n, 0], ref[n + 1]) for n in range(nt))
+            assert err < bound, (rtol, err)
+
+
+def test_rkc_lanes_are_independent_and_fail_alone():
+    d, p, c0, nt, itout = golden_problem(interval=5000)
+    B, nt = 6, 3
+    rng = np.random.default_rng(5)
+    cs = np.stack([c0 * rng.uniform(0.3, 3.0) for _ in range(B)])
+    pb = np.stack([p.pb] * B); pb[:, 0] = np.linspace(-0.03, 0.06, B)
+    flux = np.stack([p.flux_bound] * B)
+    with solver_from_problem(p, 'FTCS', batch_capacity=B) as s:
+        s.set_batch(cs, pb, [p.vzeta] * B, flux)
+        cout, idid, stats, t_end = s.integrate_rkc(nt, list(range(nt)))
+        assert (idid == 1).all() and len(set(stats[:, 0])) > 1 and (t_end == nt * p.dt).all()      # different step counts in one batch
+        for b in (1, 4):
+            s.set_batch(cs, pb, [p.vzeta] * B, flux)
+            o, ref = rkc_oracle_run(s, cs.copy(), b, nt)
+            assert list(stats[b][:4]) == [o.nsteps, o.naccpt, o.nrejct, o.nfe] and relerr(cout[-1, b], ref[-1]) < 1e-10
+        # a step budget that only some lanes can meet: the others freeze at their last accepted step
+        s.set_batch(cs, pb, [p.vzeta] * B, flux)
+        need = s.integrate_rkc(1, [0])[2][:, 0].astype(int)          # attempted steps of the first interval (the one that needs most)
+        assert len(set(need)) > 1
+        budget = int(np.sort(need)[B // 2 - 1])
+        s.set_batch(cs, pb, [p.vzeta] * B, flux)
+        c2, idid2, st2, t2 = s.integrate_rkc(nt, list(range(nt)), nsteps=budget)
+    assert (idid2 == -2).any() and (idid2 == 1).any()
+    for b in range(B):
+        if idid2[b] == 1:
+            assert np.array_equal(c2[:, b], cout[:, b])          # untouched by the neighbours' failures
+        else:
+            assert t2[b] < nt * p.dt and np.array_equal(c2[int(st2[b][4]), b], c2[-1, b])
+    with solver_from_problem(p, 'FTCS', batch_capacity=1) as s1:              # lane 4 alone: bitwise the same
+        s1.set_batch(cs[4:5], pb[4:5], [p.vzeta], flux[4:5])
+        c1, _, st1, _ = s1.integrate_rkc(nt, list(range(nt)))
+    assert np.array_equal(c1[:, 0], cout[:, 4]) and np.array_equal(st1[0], stats[4])
+
+
+def test_rkc_descriptor_sweep_through_the_calculator():
+    """calc='odeint' / 'lsoda' / 'vode' over a batch of operating points: the stiff integrator on the device; output indexing as the
+    reference's drivers (odeint: state at tmesh[n]; the ode family: state at (n + 1) dt)."""
+    d, p, c0, nt, itout = golden_problem(interval=2000)
+    tp = transport_from_fixture(d)
+    tp.c0 = d['c0'].copy(); tp.flux_bound = d['flux_bound'].copy(); tp.system['vzeta'] = float(d['vzeta'])
+    B = 4
+    cs = np.stack([tp.c0 * f for f in (1.0, 0.7, 1.3, 2.0)])
+    pb = np.stack([tp.pb_array()] * B); pb[:, 0] = np.linspace(-0.02, 0.04, B)
+    flux = np.stack([tp.flux_bound[:, 0]] * B)
+    outs = {}
+    for calc_name in ('odeint', 'vode'):
+        calc = Calculator(transport=tp, calc=calc_name, dt=2000 * float(d['dt']), tmax=6 * 2000 * float(d['dt']), ntout=3)
+        cout, status, _ = calc.integrate_pnp_batch(cs, pb, [tp.system['vzeta']] * B, flux)
+        assert (status == 0).all() and (calc.ode_idid == 1).all()
+        outs[calc_name] = (cout, list(tp.itout))
+    (co, io), (cv, iv) = outs['odeint'], outs['vode']
+    assert io == iv and co.shape == cv.shape == (len(io), B, tp.nspecies * tp.nx)
+    if io[0] == 0:
+        assert np.array_equal(co[0], cs)                      # odeint's first row is the initial state
+    # odeint's entry n is the state at n dt = the ode family's entry n - 1
+    for j, n in enumerate(io):
+        if n >= 1 and (n - 1) in iv:
+            assert np.array_equal(co[j], cv[iv.index(n - 1)])

@@ -122,3 +122,51 @@ def test_dop853_failure_exits_match_scipy(nsteps, idid, msg):
     o = Dop853(stiff, nsteps=nsteps).set_initial_value([1.0, 1.0])
     b = o.integrate(5.0)
     assert o.idid == idid and o.t == r.t and np.array_equal(a, b)
+
+
+# ---- oracle/rkc.py: Runge-Kutta-Chebyshev with error control (what pnp_integrate_rkc runs per lane) ------------------------------------
+def stiff_diffusion(t, y):        # heat equation + reaction on 64 points: spectral radius 1.6e4
+    d = np.zeros_like(y)
+    d[1:-1] = 4000.0 * (y[2:] - 2 * y[1:-1] + y[:-2]) - 3.0 * y[1:-1] ** 2
+    return d
+
+
+@pytest.mark.parametrize('rtol,bound', [(1e-4, 2e-4), (1e-6, 1e-5), (1e-8, 1e-6)])
+def test_rkc_restatement_against_odeint(rtol, bound):
+    from oracle.rkc import Rkc
+    y0 = np.sin(np.linspace(0, np.pi, 64)) ** 2
+    ts = np.arange(0, 11) * 0.01
+    ref = si.odeint(stiff_diffusion, y0, ts, tfirst=True, rtol=1e-12, atol=1e-14)
+    r = Rkc(stiff_diffusion, rtol=rtol, atol=1e-10).set_initial_value(y0)
+    err = 0.0
+    for k in range(1, 11):
+        err = max(err, np.abs(r.integrate(ts[k]) - ref[k]).max())
+    assert r.idid == 1 and err < bound
+    # the point of the method: far fewer steps than the explicit limit 2 / rho would allow (0.1 / 1.25e-4 = 800 Euler steps)
+    assert r.sprad == pytest.approx(1.6e4 * 1.2, rel=0.1) and (rtol < 1e-5 or r.nsteps < 100) and r.nrejct <= 2
+    assert r.nfe == sum(e[2] for e in r.log) + 2          # m evaluations per attempted step + f(y0) + the first-step probe
+
+
+def test_rkc_method_of_lines_right_hand_side_and_failure_exits():
+    """The reference's ode_func (oracle/pnp_ref.mol_rhs, pinned against the reference's fixtures) under RKC against odeint."""
+    import os
+    from oracle import pnp_ref as R
+    from oracle.rkc import Rkc
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'dopri5_dd_n2_nx50.npz'))
+    p, c0, nt, itout, method = R.problem_from_golden(d)
+
+    def f(t, y):
+        return R.mol_rhs(y, p)
+    dt = 1e4 * p.dt                      # 1e-7 s per interval: 400 x the explicit stability limit dx^2 / (2 D)
+    ts = np.arange(0, 4) * dt
+    ref = si.odeint(f, c0, ts, tfirst=True, rtol=1e-10, atol=1e-14)
+    r = Rkc(f, rtol=1e-6, atol=1e-12).set_initial_value(c0)
+    for k in range(1, 4):
+        y = r.integrate(ts[k])
+        assert np.abs(y - ref[k]).max() / np.abs(ref[k]).max() < 5e-5
+    assert r.idid == 1 and r.maxm >= 8 and r.t == ts[3]
+    r2 = Rkc(f, nsteps=3).set_initial_value(c0)
+    r2.integrate(dt)
+    assert r2.idid == -2 and not r2.successful() and r2.t < dt
+    y_frozen = r2.y.copy()
+    assert np.array_equal(r2.integrate(2 * dt), y_frozen)
