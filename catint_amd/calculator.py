@@ -21,15 +21,15 @@ from .units import unit_F
 CALC_LIST = ['FTCS', 'Crank-Nicolson', 'odeint', 'vode', 'lsoda', 'dopri5', 'dop853', 'odeint', 'odespy', 'comsol']
 CALC_LIST = CALC_LIST + ['Newton']
 GPU_CALCS = ('FTCS', 'Crank-Nicolson')
-MOL_CALCS = ('odeint', 'lsoda', 'vode', 'dopri5', 'dop853')   # method of lines: RHS on the GPU; 'dopri5' integrates on the device too, the others through scipy
+MOL_CALCS = ('odeint', 'lsoda', 'dopri5', 'dop853')   # method of lines: RHS on the GPU; 'dopri5' integrates on the device too, the others through scipy
 # physical mode: what run_single_step asks COMSOL for (calculator.py:408-535, comsol_wrapper.py:145,158) solved on the
 # GPU by the fully implicit coupled Newton kernel; 'comsol' is accepted as its name so reference scripts keep working
 PHYSICAL_CALCS = ('comsol', 'Newton')
 DEVICE_ODE_CALCS = ('dopri5', 'dop853')     # explicit Runge-Kutta integrators that run on the device (pnp_ode.hip)
-# The reference's stiff drivers (odeint = LSODA, ode('vode' | 'lsoda'): calculator_old.py:946-963) take one operating point per call
+# The reference's stiff driver (scipy's odeint = LSODA for calc='odeint' / 'lsoda': calculator_old.py:946-948) takes one operating point per call
 # on the host.  Over a BATCH of operating points their role is played by the stiff integrator on the device (pnp_integrate_rkc:
 # Runge-Kutta-Chebyshev with error control, pnp_rkc.hip) -- same tolerances, same output indexing, results within the tolerance.
-DEVICE_STIFF_CALCS = ('odeint', 'lsoda', 'vode')
+DEVICE_STIFF_CALCS = ('odeint', 'lsoda')        # ('vode' raises a TypeError in the reference, SURVEY App. H: refused here as well)
 
 
 class CalculatorError(ValueError):
@@ -157,8 +157,8 @@ class Calculator(object):
             s.set_batch(c0, pb, vzeta, flux)
             if self.calc in DEVICE_STIFF_CALCS:
                 # every lane its own adaptive RKC (pnp_integrate_rkc).  odeint returns the state at tmesh[n] (calculator_old.py:946-948:
-                # row 0 is the initial state), the ode family the state at (n + 1) dt (:959-969).
-                shift = 1 if self.calc in ('odeint', 'lsoda') else 0
+                # row 0 is the initial state; the ode family's entry n is the state at (n + 1) dt, :959-969).
+                shift = 1
                 wanted = [int(n) for n in itout if n < nt]
                 out = [n - shift for n in wanted if n - shift >= 0]
                 opts = {k: v for k, v in getattr(self, 'ode_options', {}).items() if k in ('rtol', 'atol', 'nsteps', 'max_step', 'check_every')}

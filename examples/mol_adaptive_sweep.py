@@ -26,8 +26,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--lanes', type=int, default=32)
     ap.add_argument('--nx', type=int, default=96)
-    ap.add_argument('--calc', default='dopri5', choices=['dopri5', 'dop853', 'odeint', 'lsoda', 'vode'],
-                    help="'odeint' / 'lsoda' / 'vode': the stiff integrator on the device (Runge-Kutta-Chebyshev, pnp_integrate_rkc)")
+    ap.add_argument('--calc', default='dopri5', choices=['dopri5', 'dop853', 'odeint', 'lsoda'],
+                    help="'odeint' / 'lsoda': the stiff integrator on the device (Runge-Kutta-Chebyshev, pnp_integrate_rkc)")
     ap.add_argument('--dt', type=float, default=5e-10)
     ap.add_argument('--tmax', type=float, default=5e-9)
     a = ap.parse_args(argv)

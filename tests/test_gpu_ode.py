@@ -375,9 +375,9 @@ def test_rkc_lanes_are_independent_and_fail_alone():
 
 
 def test_rkc_descriptor_sweep_through_the_calculator():
-    """calc='odeint' / 'lsoda' / 'vode' over a batch of operating points: the stiff integrator on the device; output indexing as the
-    reference's drivers (odeint: state at tmesh[n]; the ode family: state at (n + 1) dt)."""
-    d, p, c0, nt, itout = golden_problem(interval=2000)
+    """calc='odeint' / 'lsoda' over a batch of operating points: the stiff integrator on the device; output indexing as the reference's
+    odeint driver (state at tmesh[n], row 0 the initial state), i.e. the ode family's entry n - 1 (dopri5 on the device, loose bound)."""
+    d, p, c0, nt, itout = golden_problem(interval=200)
     tp = transport_from_fixture(d)
     tp.c0 = d['c0'].copy(); tp.flux_bound = d['flux_bound'].copy(); tp.system['vzeta'] = float(d['vzeta'])
     B = 4
@@ -385,16 +385,19 @@ def test_rkc_descriptor_sweep_through_the_calculator():
     pb = np.stack([tp.pb_array()] * B); pb[:, 0] = np.linspace(-0.02, 0.04, B)
     flux = np.stack([tp.flux_bound[:, 0]] * B)
     outs = {}
-    for calc_name in ('odeint', 'vode'):
-        calc = Calculator(transport=tp, calc=calc_name, dt=2000 * float(d['dt']), tmax=6 * 2000 * float(d['dt']), ntout=3)
+    for calc_name in ('odeint', 'lsoda', 'dopri5'):
+        calc = Calculator(transport=tp, calc=calc_name, dt=200 * float(d['dt']), tmax=6 * 200 * float(d['dt']), ntout=3)
+        calc.ode_options = {'rtol': 1e-8, 'atol': 1e-13, 'nsteps': 100000}
         cout, status, _ = calc.integrate_pnp_batch(cs, pb, [tp.system['vzeta']] * B, flux)
         assert (status == 0).all() and (calc.ode_idid == 1).all()
-        outs[calc_name] = (cout, list(tp.itout))
-    (co, io), (cv, iv) = outs['odeint'], outs['vode']
-    assert io == iv and co.shape == cv.shape == (len(io), B, tp.nspecies * tp.nx)
+        outs[calc_name] = (cout, [int(n) for n in tp.itout if n < tp.nt])
+    (co, io), (cl, il), (cd, idp) = outs['odeint'], outs['lsoda'], outs['dopri5']
+    assert io == il == idp and co.shape == cd.shape == (len(io), B, tp.nspecies * tp.nx) and np.array_equal(co, cl)
     if io[0] == 0:
         assert np.array_equal(co[0], cs)                      # odeint's first row is the initial state
-    # odeint's entry n is the state at n dt = the ode family's entry n - 1
-    for j, n in enumerate(io):
-        if n >= 1 and (n - 1) in iv:
-            assert np.array_equal(co[j], cv[iv.index(n - 1)])
+    hit = 0
+    for j, n in enumerate(io):                                # odeint's entry n = the ode family's entry n - 1
+        if n >= 1 and (n - 1) in idp:
+            assert relerr(co[j], cd[idp.index(n - 1)]) < 1e-6
+            hit += 1
+    assert hit >= 1 or len(io) == 1
