@@ -2,6 +2,7 @@
 // integrate_pnp loop (reference catint/calculator_old.py:210, :512, :990) around the HIP kernels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,12 @@ struct pnp_handle {
   int64_t lane_groups = 0;
   double* lane2_buf = nullptr;           // lane-pair kernel: the same for groups of 16
   int64_t lane2_groups = 0;
+  // lane kernels: which operating point a slot (group, lane) holds -- points ordered by expected Newton iterations, see lane_order
+  int32_t* lane_perm = nullptr;          // device [capacity]
+  std::vector<float> lane_key;           // |phiM - phi_bulk| per operating point (pnp_set_batch / pnp_set_pb): the order of a first call
+  std::vector<int32_t> lane_iters_host, lane_perm_host;
+  bool iters_valid = false;              // h->iters holds the iteration counts of a Newton call on this batch
+  int lane_order_mode = 1;               // CATINT_LANE_ORDER = 0: slot s holds point s (tests, A/B)
   double* scf_d = nullptr;               // (4N + 5) B doubles
   double* scf_snap = nullptr;            // (N + 1) ldx B doubles: per-lane state of the last converged transport solve
   int32_t* scf_i = nullptr;              // 3 B flags + 65 counters
@@ -121,7 +128,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->lane2_buf, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int, (void*)h->rkc_d, (void*)h->rkc_i})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->lane2_buf, (void*)h->lane_perm, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int, (void*)h->rkc_d, (void*)h->rkc_i})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -250,6 +257,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   if (const char* e = getenv("CATINT_PNP_SPECIES_PER_WAVE")) h->species_override = atoi(e);
   if (const char* e = getenv("CATINT_PNP_KERNEL")) h->kernel_override = atoi(e);
   if (const char* e = getenv("CATINT_PNP_STEP_STREAMS")) h->step_streams_override = atoi(e);
+  if (const char* e = getenv("CATINT_LANE_ORDER")) h->lane_order_mode = atoi(e);
   if (const char* e = getenv("CATINT_PNP_ALTERNATE_ROWS")) h->alternate_rows = atoi(e) != 0 ? 1 : 0;
   DevArgs& a = h->a;
   a.N = N;
@@ -385,6 +393,10 @@ int pnp_set_pb(pnp_handle* h, const double* pb, const double* vzeta) {
   HIP_TRY(h, hipMemcpyAsync(h->pb, pb, (size_t)h->B * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->vzeta, vzeta, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->newton) {
+    h->lane_key.resize((size_t)h->B);
+    for (int64_t b = 0; b < h->B; ++b) h->lane_key[b] = (float)std::fabs(pb[b * 4 + 0] - pb[b * 4 + 1]);
+  }
   return PNP_OK;
 }
 
@@ -438,6 +450,11 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   }
   h->have_batch = true;
   h->steps_done = 0;
+  h->iters_valid = false;
+  if (h->newton) {
+    h->lane_key.resize((size_t)B);
+    for (int64_t b = 0; b < B; ++b) h->lane_key[b] = (float)std::fabs(pb[b * 4 + 0] - pb[b * 4 + 1]);
+  }
   return PNP_OK;
 }
 
@@ -556,6 +573,48 @@ static int step_streams(const pnp_handle* h, int launches) {
   if (S > pnp_handle::MAX_STEP_STREAMS) S = pnp_handle::MAX_STEP_STREAMS;
   while (S > 1 && h->a.B / S < 256) --S;
   return S;
+}
+
+// Lane kernels: a wave iterates until the slowest of its operating points is done, and the points that are done keep streaming their
+// records (pnp_lane.hip) -- 1.15-1.28 x the algorithmic HBM bytes measured on random batches.  So the operating points are dealt to
+// the slots (group, lane) in the order of the Newton iterations they are expected to need, most first (the long waves start first,
+// the short ones fill the tail): by the iteration counts of the previous Newton call on this batch (read back here: one small copy
+// and a counting sort per call), before that by the wall-to-bulk potential difference.  The arithmetic of a point does not depend on
+// its slot: results are the same to the bit with and without the order (tests/test_gpu_lane.py).
+static int lane_order(pnp_handle* h, NewtonArgs& a) {
+  a.lane_perm = nullptr;
+  const int64_t B = h->B;
+  if (h->lane_order_mode == 0 || B < 64) return PNP_OK;
+  if (!h->lane_perm) HIP_TRY(h, dev_alloc(h, &h->lane_perm, (size_t)h->cfg.batch_capacity));
+  std::vector<int32_t>& perm = h->lane_perm_host;
+  perm.resize((size_t)B);
+  if (h->iters_valid) {
+    std::vector<int32_t>& it = h->lane_iters_host;
+    it.resize((size_t)B);
+    HIP_TRY(h, hipMemcpyAsync(it.data(), h->iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    constexpr int KMAX = 4096;
+    std::vector<int64_t> start(KMAX + 1, 0);
+    for (int64_t b = 0; b < B; ++b) {
+      const int k = it[b] < 0 ? 0 : (it[b] >= KMAX ? KMAX - 1 : it[b]);
+      start[KMAX - 1 - k + 1] += 1;                      // descending
+    }
+    for (int k = 0; k < KMAX; ++k) start[k + 1] += start[k];
+    for (int64_t b = 0; b < B; ++b) {
+      const int k = it[b] < 0 ? 0 : (it[b] >= KMAX ? KMAX - 1 : it[b]);
+      perm[(size_t)start[KMAX - 1 - k]++] = (int32_t)b;
+    }
+  } else if ((int64_t)h->lane_key.size() == B) {
+    for (int64_t b = 0; b < B; ++b) perm[(size_t)b] = (int32_t)b;
+    const std::vector<float>& key = h->lane_key;
+    std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return key[(size_t)x] > key[(size_t)y]; });
+  } else {
+    return PNP_OK;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->lane_perm, perm.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));        // (the host vector may be rewritten by the next call)
+  a.lane_perm = h->lane_perm;
+  return PNP_OK;
 }
 
 // physical mode: nsteps backward-Euler steps (stationary: one solve with 1/dt = 0) in one launch
@@ -685,10 +744,15 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
     if (v >= 1 && v < blocks) blocks = v;
   }
   if ((int64_t)blocks > h->B) blocks = (int)h->B;
+  if (use_lane2 || use_lane) {
+    const int rc = lane_order(h, a);
+    if (rc != PNP_OK) return rc;
+  }
   if (use_lane2) HIP_TRY(h, launch_newton_lane2(a, h->stream));
   else if (use_lane) HIP_TRY(h, launch_newton_lane(a, h->stream));
   else HIP_TRY(h, launch_newton(a, blocks, h->stream));
   h->steps_done += nsteps;
+  h->iters_valid = true;
   return PNP_OK;
 }
 

@@ -156,6 +156,9 @@ struct NewtonArgs {
   double* lane_rec;                      // [groups][nx][((N+1)^2 + (N+1))/2][32][2]
   int64_t lane_groups;                   // groups (of 32 operating points) the three buffers hold
   int64_t lane_group0;                   // first group of this launch (the batch is walked in chunks of lane_groups)
+  const int32_t* lane_perm;              // [B] operating point of slot s (slot = group * points per group + lane), or null: slot s holds
+                                         // point s.  The host orders the points by expected Newton iterations (pnp_capi.hip:
+                                         // lane_order) so that the lanes of a wave finish together.
   int32_t lane_lg, pad3_;                // operating points per group: 32 (lane kernel) or 16 (lane-pair kernel, pnp_lane2.hip)
   double lane_pivot_limit;               // pivot monitor of the lane kernels (pnp_lane_common.h): multipliers beyond this mark the lane
 };

@@ -75,9 +75,12 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int op = rr * 4 + (t >> 6), ii = t & 63;
-        const int64_t b = b0 + op;
+        const int64_t slot = b0 + op;
         double val = 0.0;
-        if (op < LGr && b < G.B && i0 + ii < nx) val = v < N ? G.c[((size_t)b * N + v) * ldx + i0 + ii] : G.phi[(size_t)b * ldx + i0 + ii];
+        if (op < LGr && slot < G.B && i0 + ii < nx) {
+          const int64_t b = G.lane_perm ? G.lane_perm[slot] : slot;
+          val = v < N ? G.c[((size_t)b * N + v) * ldx + i0 + ii] : G.phi[(size_t)b * ldx + i0 + ii];
+        }
         tile[op][ii] = val;
       }
       __syncthreads();
@@ -104,18 +107,24 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int op = rr * 4 + (t >> 6), ii = t & 63;
-        const int64_t b = b0 + op;
-        if (op < LGr && b < G.B && i0 + ii < nx && !(G.lane_mask && !G.lane_mask[b])) {
-          if (v < N) G.c[((size_t)b * N + v) * ldx + i0 + ii] = tile[op][ii];
-          else G.phi[(size_t)b * ldx + i0 + ii] = tile[op][ii];
+        const int64_t slot = b0 + op;
+        if (op < LGr && slot < G.B && i0 + ii < nx) {
+          const int64_t b = G.lane_perm ? G.lane_perm[slot] : slot;
+          if (!(G.lane_mask && !G.lane_mask[b])) {
+            if (v < N) G.c[((size_t)b * N + v) * ldx + i0 + ii] = tile[op][ii];
+            else G.phi[(size_t)b * ldx + i0 + ii] = tile[op][ii];
+          }
         }
       }
       __syncthreads();
     }
   }
   if constexpr (!IN) {
-    const int64_t b = b0 + (t & 31);
-    if (bad && (t & 31) < LGr && b < G.B && !(G.lane_mask && !G.lane_mask[b])) atomicMax(&G.status[b], (int32_t)PNP_STATUS_NAN);
+    const int64_t slot = b0 + (t & 31);
+    if (bad && (t & 31) < LGr && slot < G.B) {
+      const int64_t b = G.lane_perm ? G.lane_perm[slot] : slot;
+      if (!(G.lane_mask && !G.lane_mask[b])) atomicMax(&G.status[b], (int32_t)PNP_STATUS_NAN);
+    }
   }
 }
 
@@ -144,9 +153,10 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   const int n_dn = nx - 2 - m;               // rows of the downward half (nx-2 .. m+1; the bulk row nx-1 is its initial state); the
                                              // upward half has m (0 .. m-1) and the middle row
   const int64_t g = blockIdx.x;
-  const int64_t b_raw = (G.lane_group0 + g) * LG + o;
-  const bool valid = b_raw < G.B && !(G.lane_mask && !G.lane_mask[b_raw < G.B ? b_raw : 0]);
-  const int64_t b = b_raw < G.B ? b_raw : G.B - 1;      // (parameter loads of the padding lanes stay in range)
+  const int64_t slot = (G.lane_group0 + g) * LG + o;
+  const int64_t slot_c = slot < G.B ? slot : G.B - 1;   // (parameter loads of the padding lanes stay in range)
+  const int64_t b = G.lane_perm ? (int64_t)G.lane_perm[slot_c] : slot_c;      // the operating point this lane holds
+  const bool valid = slot < G.B && !(G.lane_mask && !G.lane_mask[b]);
   d2* ts = (d2*)G.lane_ts + (size_t)g * (size_t)nx * VP * LG + o;
   d2* xs = (d2*)G.lane_xs + (size_t)g * (size_t)nx * VP * LG + o;
   d2* tco = (d2*)G.lane_tco + (size_t)g * (size_t)nx * CP * LG + o;
@@ -753,11 +763,11 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     }
   }
 #ifdef PNP_LANE_STAMPS
-  if (lane == 0 && b_raw + 3 < G.B) {      // per wave: mean cycles per iteration of the three passes, in place of four lanes' iteration counts
-    G.iters[b_raw + 0] = (int32_t)(stamp_f / stamp_n);
-    G.iters[b_raw + 1] = (int32_t)(stamp_b / stamp_n);
-    G.iters[b_raw + 2] = (int32_t)(stamp_u / stamp_n);
-    G.iters[b_raw + 3] = (int32_t)stamp_n;
+  if (lane == 0 && slot + 3 < G.B) {      // per wave: mean cycles per iteration of the three passes, in place of four lanes' iteration counts
+    G.iters[slot + 0] = (int32_t)(stamp_f / stamp_n);
+    G.iters[slot + 1] = (int32_t)(stamp_b / stamp_n);
+    G.iters[slot + 2] = (int32_t)(stamp_u / stamp_n);
+    G.iters[slot + 3] = (int32_t)stamp_n;
   }
 #endif
 }

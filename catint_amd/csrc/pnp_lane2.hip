@@ -73,9 +73,10 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
   const int m = (nx - 1) >> 1;
   const int n_dn = nx - 2 - m;
   const int64_t g = blockIdx.x;
-  const int64_t b_raw = (G.lane_group0 + g) * OG + o;
-  const bool valid = b_raw < G.B && !(G.lane_mask && !G.lane_mask[b_raw < G.B ? b_raw : 0]);
-  const int64_t b = b_raw < G.B ? b_raw : G.B - 1;
+  const int64_t slot = (G.lane_group0 + g) * OG + o;
+  const int64_t slot_c = slot < G.B ? slot : G.B - 1;
+  const int64_t b = G.lane_perm ? (int64_t)G.lane_perm[slot_c] : slot_c;      // the operating point these four lanes hold
+  const bool valid = slot < G.B && !(G.lane_mask && !G.lane_mask[b]);
   d2* ts = (d2*)G.lane_ts + (size_t)g * (size_t)nx * VP * OG + o;
   d2* xs = (d2*)G.lane_xs + (size_t)g * (size_t)nx * VP * OG + o;
   d2* tco = (d2*)G.lane_tco + (size_t)g * (size_t)nx * CP * OG + o;

@@ -204,3 +204,40 @@ def test_pivot_monitor_reports_a_lane_as_not_converged(kernel, N, monkeypatch):
         st = s.solve_stationary()
         c = s.get_state()[0]
     assert (st == 1).all() and np.array_equal(c, a[0])
+
+
+@pytest.mark.parametrize("kernel,N,nx,B,groups", [('lane', 3, 96, 203, None), ('lane', 8, 64, 150, '2'), ('lane2', 6, 80, 133, None),
+                                                  ('lane2', 8, 48, 97, '3')])
+def test_points_ordered_by_expected_iterations_give_the_same_bits(kernel, N, nx, B, groups, monkeypatch):
+    """The host deals the operating points to the slots (group, lane) in the order of the Newton iterations they are expected to need
+    (pnp_capi.hip: lane_order -- first call: wall-to-bulk potential difference; later calls: the previous call's iteration counts), so
+    that the lanes of a wave finish together.  A point's arithmetic does not depend on its slot: state, iteration counts and flags
+    equal those of the identity order to the bit, over a first solve, transient steps after it (ordered by counts), a lane mask and
+    several workspace chunks."""
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    if groups:
+        monkeypatch.setenv('CATINT_NEWTON_LANE_GROUPS', groups)
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 11)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    mask = (np.arange(B) % 3 != 1).astype(np.int32)
+    outs = []
+    for order in ('0', '1'):
+        monkeypatch.setenv('CATINT_LANE_ORDER', order)
+        with _capi.PnpSolver(N, nx, dx, dt, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+            s.set_newton(stern_capacitance=0.25, wall_bc='stern', mpb_radius=[3.5e-10] * N if N >= 6 else None)
+            s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+            s.step(2)
+            it_a = s.newton_iterations()
+            s.step(3)
+            it_b = s.newton_iterations()
+            s.set_lane_mask(mask)
+            s.step(1)
+            s.set_lane_mask(None)
+            c, phi, _, _ = s.get_state()
+            outs.append((c, phi, it_a, it_b, s.newton_iterations(), s.get_status()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert len(set(outs[0][2])) > 1 and (outs[0][5] == 0).all()       # different counts within the batch: the order is not trivial
