@@ -401,3 +401,36 @@ def test_rkc_descriptor_sweep_through_the_calculator():
             assert relerr(co[j], cd[idp.index(n - 1)]) < 1e-6
             hit += 1
     assert hit >= 1 or len(io) == 1
+
+
+def test_rkc_grids_beyond_one_wave_empty_requests_and_argument_checks():
+    """Two waves per system (1500 points: the point-wise right-hand side behind the multi-wave Poisson), no intervals / no outputs,
+    argument checks, and a Newton handle refusing the call."""
+    from catint_amd import _capi
+    from catint_amd.synthetic import make_batch
+    N, nx, B = 2, 1500, 3
+    prob, c0, pb, vz, flux = make_batch(B, N, nx, seed=4, dt_factor=1e-2)
+    with solver_from_problem(prob, 'FTCS', batch_capacity=B) as s:
+        s.set_batch(c0, pb, vz, flux)
+        c_start = s.get_state()[0].reshape(B, -1)
+        o, ref = rkc_oracle_run(s, c_start.copy(), 2, 2)
+        s.set_batch(c0, pb, vz, flux)
+        cout, idid, stats, t_end = s.integrate_rkc(2, [1])
+        assert idid[2] == 1 and list(stats[2][:4]) == [o.nsteps, o.naccpt, o.nrejct, o.nfe] and relerr(cout[0, 2], ref[-1]) < 1e-10
+        assert o.maxm >= 3                                     # beyond the explicit limit
+        s.set_batch(c0, pb, vz, flux)
+        c_none, idid0, st0, t0 = s.integrate_rkc(0, [])        # nothing to do
+        assert c_none.shape == (0, B, N * nx) and (idid0 == 1).all() and (t0 == 0).all() and (st0 == 0)[:, :4].all()
+        assert np.array_equal(s.get_state()[0].reshape(B, -1), c_start)
+        c_no_out, idid1, _, t1 = s.integrate_rkc(1, [])        # integrate, report nothing
+        assert c_no_out.shape[0] == 0 and (idid1 == 1).all() and (t1 == prob.dt).all()
+        with pytest.raises(_capi.PnpError, match='itout'):
+            s.integrate_rkc(2, [1, 0])
+        with pytest.raises(_capi.PnpError, match='itout'):
+            s.integrate_rkc(2, [2])
+        with pytest.raises(_capi.PnpError, match='negative'):
+            s.integrate_rkc(2, [1], rtol=-1.0)
+    with _capi.PnpSolver(N, 64, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=1) as sn:
+        sn.set_newton()
+        with pytest.raises(_capi.PnpError, match='physical mode'):
+            sn.integrate_rkc(1, [0])
