@@ -81,10 +81,15 @@ class Calculator(object):
         self.physical = self.calc in PHYSICAL_CALCS
         # roughness factor: every wall flux the COMSOL model prescribes is j_i = RF*flux_factor*flux_i (comsol_model.py:1000, :1134)
         self.RF = float(self.tp.system.get('RF', 1.0)) if self.physical else 1.0
+        # the reference hands system['flow rate'] (a number or a COMSOL expression) to the convection velocity tds.cdm1 "u"
+        # (comsol_model.py:901-903, :919): numbers are carried (pnp_set_convection: + c v in every flux), expressions are refused
+        self.velocity = 0.0
         if self.physical and self.tp.system.get('flow rate') not in (None, 0, 0.0, '0', '0.0'):
-            # the reference adds system['flow rate'] (a number or a COMSOL expression) to the convection velocity tds.u
-            # (comsol_model.py:902-903, :918); the native solver carries no convection term -- refuse instead of ignoring it
-            raise CalculatorError("system['flow rate'] (convection) is not carried by the MI355X transport solver")
+            try:
+                self.velocity = float(self.tp.system['flow rate'])
+            except (TypeError, ValueError):
+                raise CalculatorError("system['flow rate'] = %r: only a constant velocity (a number, m/s) is carried by the MI355X transport "
+                                      "solver, not a COMSOL expression" % (self.tp.system['flow rate'],))
         if not self.physical and not getattr(self.tp, 'mesh_uniform', True):
             raise CalculatorError('the finite-difference integrators need a uniform mesh; graded meshes belong to calc="comsol"')
         if self.mode is None:      # COMSOL studies default to ['stat'] (transport.py:811-812); the FD integrators are transient
@@ -260,6 +265,8 @@ class Calculator(object):
             s.set_grid(xmesh)
         elif not getattr(tp, 'mesh_uniform', True):
             s.set_grid(tp.xmesh)
+        if getattr(self, 'velocity', 0.0):
+            s.set_convection(self.velocity)
         if getattr(tp, 'use_reactions', False) and getattr(tp, 'reactions', None):      # tp.reactions[r]['reactants'], ['rates']
             names = list(tp.species.keys())
             s.set_reactions([([names.index(x) for x in rx['reactants'][0] if x in names],

@@ -46,6 +46,7 @@ struct pnp_handle {
   pnp_newton_params np;
   double Dk[PNP_NEWTON_MAX_SPECIES] = {0}, qk[PNP_NEWTON_MAX_SPECIES] = {0}, volk[PNP_NEWTON_MAX_SPECIES] = {0};
   bool mpb = false;
+  double velocity = 0.0;                 // pnp_set_convection
   double* c_old = nullptr;
   double* work = nullptr;
   double* stash = nullptr;
@@ -649,14 +650,17 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
     a.peq[k] = dx * dx / eps * h->qk[k];
     a.vol[k] = h->volk[k];
     a.rs[k] = dx * dx / h->Dk[k];
+    a.pe[k] = h->velocity * dx / h->Dk[k];
     if (fabs(h->qk[k]) > qmax) qmax = fabs(h->qk[k]);
   }
+  a.convect = h->velocity != 0.0 ? 1 : 0;
   a.vt_inv = beta * qmax;
   a.rt = (h->rt_dev && h->rt.n > 0) ? h->rt_dev : nullptr;
   a.n_wk = h->newton_explicit_kinetics ? 0 : h->n_wk;
   a.lane_mask = h->newton_mask;
-  const bool use_lane2 = newton_lane2_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0));
-  const bool use_lane = !use_lane2 && newton_lane_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0));
+  // (the lane kernels do not carry the convection term: those batches stay with the workgroup-per-point / lane-team kernels)
+  const bool use_lane2 = !a.convect && newton_lane2_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0));
+  const bool use_lane = !a.convect && !use_lane2 && newton_lane_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0));
   if (use_lane2) {
     const size_t per_group = (newton_lane2_rec_doubles(N + 1, nx) + newton_lane2_state_doubles(N + 1, nx)) * sizeof(double);
     if (!h->lane2_buf) {
@@ -771,6 +775,14 @@ int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_
     h->volk[k] = 6.022140857e23 * a * a * a;       // unit_NA, catint/units.py
     if (h->volk[k] != 0.0) h->mpb = true;
   }
+  return PNP_OK;
+}
+
+int pnp_set_convection(pnp_handle* h, double velocity) {
+  if (!h) return PNP_EINVAL;
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_set_convection: physical mode only");
+  if (!(std::fabs(velocity) < 1e300)) return fail(h, PNP_EINVAL, "pnp_set_convection: velocity must be finite");
+  h->velocity = velocity;
   return PNP_OK;
 }
 

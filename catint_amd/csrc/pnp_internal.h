@@ -125,6 +125,8 @@ struct NewtonArgs {
   double peq[PNP_NEWTON_MAX_SPECIES];    // dx^2/eps*q_k
   double vol[PNP_NEWTON_MAX_SPECIES];    // N_A a_k^3   (MPB, comsol_model.py:1041-1063)
   double rs[PNP_NEWTON_MAX_SPECIES];     // dx^2/D_k    (scales the reaction source)
+  double pe[PNP_NEWTON_MAX_SPECIES];     // v dx/D_k    (constant convection velocity v, pnp_set_convection; 0 without)
+  int32_t convect, pad4_;                // v != 0
   const struct ReactionTable* rt;        // device copy of the mass-action table, or null
   int32_t n_wk;                          // first-order surface reactions (pnp_set_wall_kinetics)
   int32_t wk_species[PNP_MAX_WALL_REACTIONS];                     // species whose surface concentration enters, -1: zeroth order

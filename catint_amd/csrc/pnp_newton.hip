@@ -367,8 +367,11 @@ template <int N, int MODE>
 __device__ __forceinline__ void edge_fluxes(const NewtonArgs& A, const Point<N, MODE>& Pl, const Point<N, MODE>& Pr, double w,
                                             Edge (&e)[N]) {
   const double dphi = Pr.phi - Pl.phi, dw = Pr.w - Pl.w;
+  // constant convection velocity (comsol_model.py:902-903: tds.cdm1 "u" = system['flow rate']): flux + c v, i.e. the drift argument of
+  // the edge loses v h_e / D_k = pe_k / w (oracle/pnp_physical.py)
+  const double rw = A.convect ? 1.0 / w : 0.0;
 #pragma unroll
-  for (int k = 0; k < N; ++k) e[k] = edge_flux(A.qb[k] * dphi + dw, Pl.c[k], Pr.c[k], w);
+  for (int k = 0; k < N; ++k) e[k] = edge_flux(A.qb[k] * dphi + dw - A.pe[k] * rw, Pl.c[k], Pr.c[k], w);
 }
 
 // Residual F and Jacobian blocks (L, M, U) of block row i, returned as M and X = [L | U | -F], from the point states
@@ -1197,6 +1200,7 @@ __device__ __forceinline__ void team_assemble_row(const NewtonArgs& A, const New
   constexpr bool MPB = MODE >= 1, REACT = MODE == 2;
   const int nx = A.nx, ldx = A.ldx;
     const int rs_ = spec ? r : 0;
+    const double pe_r = A.pe[rs_];
     const double qb_r = A.qb[rs_], sig_r = A.sig[rs_], fl_r = A.fl[rs_], peq_r = A.peq[rs_], vol_r = A.vol[rs_], rs_r = A.rs[rs_];
     const double flux_r = G.flux[(size_t)b * N + rs_], cb_r = cb[rs_];
     const int im = i > 0 ? i - 1 : 0, ip = i < nx - 1 ? i + 1 : nx - 1;
@@ -1253,8 +1257,8 @@ __device__ __forceinline__ void team_assemble_row(const NewtonArgs& A, const New
       const double wpp = bulk ? 0.0 : 1.0, wmm = (wall || bulk) ? 0.0 : 1.0, ws = bulk ? 0.0 : vi;
       Edge em;
       if (CARRY && carried) em = carry->ep;
-      else em = edge_flux(qb_r * (p0 - pm) + (w0_ - wm_), cm, c0, wem);
-      const Edge ep = edge_flux(qb_r * (pp - p0) + (wp_ - w0_), c0, cp, wep);
+      else em = edge_flux(qb_r * (p0 - pm) + (w0_ - wm_) - (A.convect ? pe_r / wem : 0.0), cm, c0, wem);
+      const Edge ep = edge_flux(qb_r * (pp - p0) + (wp_ - w0_) - (A.convect ? pe_r / wep : 0.0), c0, cp, wep);
       if constexpr (CARRY) carry->ep = ep;
       const double sg = ws * sig_r;
       const double Jp = wpp * ep.J, Jup = wpp * ep.Ju, Jm = wmm * em.J, Jum = wmm * em.Ju;

@@ -203,6 +203,10 @@ typedef struct pnp_newton_params {
 /* mpb_radius[N] (m, nullable = point ions): size-modified drift with phi0 = N_A sum a_k^3 c_k
  * (tp.species[sp]['MPB_radius'], comsol_model.py:1041-1063). */
 int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_radius);
+/* Constant convection velocity v (m/s, along x) of the physical mode: the Nernst-Planck flux gains + c_i v, the reference's
+ * tds.cdm1 "u" = tp.system['flow rate'] (comsol_model.py:901-903, :919; numbers only -- the reference also accepts a COMSOL
+ * expression string there).  0 (default): none.  Batches with convection run on the workgroup-per-point and lane-team kernels. */
+int pnp_set_convection(pnp_handle* h, double velocity);
 /* Non-uniform grid of the physical mode: x[nx] strictly increasing, x[0] = electrode, x[nx-1] = bulk boundary (the reference's
  * COMSOL mesh is refined towards the electrode: hmax = L/grid_factor_domain, lambda_D/grid_factor_bound at the boundaries,
  * comsol_model.py:588,593).  cfg.dx stays the reference length of the equation scaling (use x[1]-x[0]).  Default: x_i = i*dx. */

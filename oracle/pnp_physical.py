@@ -51,7 +51,7 @@ class PhysicalProblem(object):
     Butler-Volmer / Langmuir forms of the user-defined flux equations, docs/source/topics/flux_definition.rst:90-160)."""
 
     def __init__(self, D, charges, beta, eps, dx, nx, c_bulk, phiM, flux=None, phi_bulk=0.0, stern_capacitance=None,
-                 phi_pzc=0.0, mpb_radius=None, reactions=None, wall_kinetics=None, x=None):
+                 phi_pzc=0.0, mpb_radius=None, reactions=None, wall_kinetics=None, x=None, velocity=0.0):
         self.D = np.asarray(D, float)
         self.q = np.asarray(charges, float)        # z*F
         self.beta, self.eps, self.dx, self.nx = float(beta), float(eps), float(dx), int(nx)
@@ -66,6 +66,7 @@ class PhysicalProblem(object):
         self.mpb = bool(np.any(self.vol != 0.0))
         self.reactions = list(reactions or [])
         self.wall_kinetics = list(wall_kinetics or [])
+        self.velocity = float(velocity)                    # constant convection velocity along x (tp.system['flow rate'])
         # grid: uniform x_i = i*dx, or any increasing x[nx] (then dx is only the reference length of the row scaling).
         # w[e] = dx/h_e weights the flux across edge e (between points e and e+1), v[i] = V_i/dx is the control volume
         # (half cells at the ends)
@@ -173,6 +174,8 @@ def residual_and_jacobian(p, c, phi, c_old, dt, want_jacobian=True):
         sig = 0.0 if np.isinf(dt) else dx * dx / (p.D[k] * dt)
         rs = dx * dx / p.D[k]
         u = qb * dphi + dw
+        if p.velocity != 0.0:                                  # + c v in the flux (comsol_model.py:901-903: tds "u" = system['flow rate'])
+            u = u - p.velocity * dx / (p.D[k] * p.w)
         Bp, dBp = bernoulli(u)
         Bm = Bp + u
         cl, cr = c[k, :-1], c[k, 1:]

@@ -46,7 +46,8 @@ def make_lanes(N, nx, B, seed, phi_lo=-0.15, phi_hi=0.15, points_per_debye=6.0, 
     return D, q, cb, dx, phiM
 
 
-def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None, flux=None, reactions=None, wall_kinetics=None, x=None, **lane_kw):
+def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None, flux=None, reactions=None, wall_kinetics=None, x=None,
+             velocity=0.0, **lane_kw):
     newton_kw = dict(newton_kw or {})
     D, q, cb, dx, phiM = make_lanes(N, nx, B, seed, **lane_kw)
     c0 = np.repeat(cb[:, :, None], nx, axis=2)
@@ -60,6 +61,8 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
         s.set_grid(x)
     if reactions:
         s.set_reactions([(r['lhs'], r['rhs'], r['kf'], r['kr']) for r in reactions])
+    if velocity:
+        s.set_convection(velocity)
     s.set_batch(c0, pb, np.zeros(B), fl)
     if wall_kinetics:
         law = any('alpha' in w or 'saturation' in w for w in wall_kinetics)
@@ -84,7 +87,7 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
         p = PH.PhysicalProblem(D=D, charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=cb[b], phiM=phiM[b], flux=fl[b],
                                stern_capacitance=newton_kw.get('stern_capacitance') if newton_kw.get('wall_bc') == 'stern' else None,
                                phi_pzc=newton_kw.get('phi_pzc', 0.0), mpb_radius=newton_kw.get('mpb_radius'), reactions=reactions,
-                               wall_kinetics=[dict(w, k=w['k'][b]) for w in (wall_kinetics or [])], x=x)
+                               wall_kinetics=[dict(w, k=w['k'][b]) for w in (wall_kinetics or [])], x=x, velocity=velocity)
         cc, ph = c0[b].copy(), np.zeros(nx)
         if stationary:
             cc, ph, it, _ = PH.newton_step(p, cc, ph, cc, np.inf, **okw)
@@ -536,3 +539,36 @@ def test_fuzz_case_117_stops_at_the_rounding_floor(kernel, monkeypatch):
     assert (st == 0).all() and rit[0] == 20
     assert abs(int(its[0]) - int(rit[0])) <= 1, (its, rit)
     assert np.abs(c - rc).max() <= 1e-8 * np.abs(rc).max() and np.abs(phi - rphi).max() <= 1e-9
+
+
+# ---- constant convection velocity (tp.system['flow rate'], comsol_model.py:901-903) ------------------------------------------------------
+@pytest.mark.parametrize("N,nx,B,kernel,kw,graded", [
+    (3, 128, 5, None, {}, False),                                                                       # pair kernel
+    (4, 150, 4, None, dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=[4e-10, 3e-10, 0.0, 3.5e-10]), True),
+    (2, 1100, 3, None, {}, False),                                                                      # lane teams (grid too long for the pair kernel)
+    (6, 96, 4, None, dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * 6), True),    # lane teams
+    (6, 96, 9, 'sweep', dict(mpb_radius=[3.5e-10] * 6), False),                                         # one-sided sweep
+    (7, 80, 9, 'both', {}, False),                                                                      # two-sided sweep
+    (3, 130, 4, 'generic', {}, False),                                                                  # row-per-thread kernel
+    (8, 64, 70, 'lane', dict(mpb_radius=[3.5e-10] * 8), False),                                         # lane kernel asked for: refused for convection
+])
+def test_convection_velocity_matches_oracle(N, nx, B, kernel, kw, graded, monkeypatch):
+    """+ c v in every Nernst-Planck flux: the drift argument of an edge loses v h_e / D_k.  Velocities of both signs, of the order of
+    D / L so that the profiles change visibly; stationary and transient; every kernel family that carries the
+    term (a batch the lane kernels would take runs on the lane teams instead)."""
+    # (velocities of D / L: the profiles change by e^3 across the cell -- a velocity of D / dx would pile up e^(nx) at one end)
+    if kernel:
+        monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 21)
+    x = None
+    if graded:
+        x = np.cumsum(np.concatenate([[0.0], np.geomspace(0.4, 2.5, nx - 1)]))
+    Lx = (x[-1] if graded else nx - 1) * dx
+    for v in (3.0 * D.max() / Lx, -2.0 * D.max() / Lx):              # cell Peclet numbers of a few over the whole grid
+        got, ref = run_both(N, nx, B=B, seed=21, newton_kw=kw, x=x, velocity=v)
+        assert_close(got, ref)
+        base, _ = run_both(N, nx, B=B, seed=21, newton_kw=kw, x=x)
+        assert np.abs(got[0] - base[0]).max() > 1e-3 * np.abs(base[0]).max()           # the term is not a no-op
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    got, ref = run_both(N, nx, B=B, seed=22, newton_kw=kw, x=x, velocity=3.0 * D.max() / Lx, dt=dt, nsteps=3, stationary=False)
+    assert_close(got, ref)

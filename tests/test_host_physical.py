@@ -357,8 +357,12 @@ def test_roughness_factor_scales_every_wall_flux_like_the_reference_model():
     assert np.allclose(next(c for c in s.calls if c[0] == 'kinetics')[3], 2.0 * 3.0e-3)
 
 
-def test_convection_is_refused_not_ignored():
-    tp = make_tp([0.1], **{'flow rate': 1e-3})
+def test_convection_velocity_is_carried_and_expressions_are_refused():
+    """system['flow rate'] goes to the COMSOL model's convection velocity (comsol_model.py:901-903): a number reaches the solver
+    (pnp_set_convection), a COMSOL expression string is refused instead of being ignored."""
+    calc = Calculator(transport=make_tp([0.1], **{'flow rate': 1e-3}), calc='comsol')
+    assert calc.velocity == 1e-3
+    assert Calculator(transport=make_tp([0.1], **{'flow rate': '2.5e-4'}), calc='comsol').velocity == 2.5e-4
+    assert Calculator(transport=make_tp([0.1], **{'flow rate': 0.0}), calc='comsol').velocity == 0.0      # a zero velocity is no convection
     with pytest.raises(CalculatorError, match='flow rate'):
-        Calculator(transport=tp, calc='comsol')
-    Calculator(transport=make_tp([0.1], **{'flow rate': 0.0}), calc='comsol')      # a zero velocity is no convection
+        Calculator(transport=make_tp([0.1], **{'flow rate': '1e-3*x/L_cell'}), calc='comsol')

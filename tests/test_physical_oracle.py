@@ -385,3 +385,37 @@ def test_rounding_floor_exit_of_the_newton_iteration():
     F = PH.residual_and_jacobian(p, c, phi, c0, np.inf)[0]
     F0 = PH.residual_and_jacobian(p, c0, np.zeros(nx), c0, np.inf)[0]
     assert np.abs(F).max() < 1e-9 * np.abs(F0).max()
+
+
+def test_convection_velocity_analytic_profile_and_flux_closure():
+    """Constant velocity v along x (tp.system['flow rate'], comsol_model.py:901-903): flux -D c' + c v.  A neutral species with a closed
+    wall relaxes to c(x) = c_L exp(v (x - L) / D); the exponentially fitted edge flux reproduces it to rounding on any grid, for both
+    signs of v.  With a prescribed wall flux j the stationary flux is j everywhere: c(x) = j/v + (c_L - j/v) exp(v (x - L) / D)."""
+    D = np.array([1.5e-9, 2.0e-9])
+    q = np.array([0.0, 0.0])
+    nx, dx = 60, 2e-9
+    x = np.cumsum(np.concatenate([[0.0], np.geomspace(0.5, 2.0, nx - 1)])) * dx
+    L = x[-1]
+    cb = np.array([3.0, 7.0])
+    for v in (0.04, -0.03):
+        for j in (np.zeros(2), np.array([2e-3, -1e-3])):
+            p = PH.PhysicalProblem(D=D, charges=q, beta=BETA, eps=EPS, dx=dx, nx=nx, c_bulk=cb, phiM=0.0, flux=j, x=x, velocity=v)
+            c0 = np.repeat(cb[:, None], nx, axis=1)
+            c, phi, it, _ = PH.newton_step(p, c0, np.zeros(nx), c0, np.inf, tol=1e-12)
+            assert it <= 50
+            for k in range(2):
+                exact = j[k] / v + (cb[k] - j[k] / v) * np.exp(v * (x - L) / D[k])
+                assert np.abs(c[k] - exact).max() < 1e-10 * np.abs(exact).max()
+    # and the Jacobian with the term switched on (finite differences), charged species, steric ions, Stern wall
+    rng = np.random.default_rng(3)
+    p = PH.PhysicalProblem(D=[1.9e-9, 1.2e-9, 5e-9], charges=[PH.F_CONST if hasattr(PH, 'F_CONST') else 96485.33212, -96485.33212, 0.0], beta=BETA,
+                           eps=EPS, dx=dx, nx=24, c_bulk=[5.0, 5.0, 1.0], phiM=0.05, stern_capacitance=0.2, mpb_radius=[4e-10, 3e-10, 0.0],
+                           velocity=0.05)
+    c = np.array([5.0, 5.0, 1.0])[:, None] * (1 + 0.2 * rng.uniform(-1, 1, (3, 24)))
+    phi = 0.02 * rng.uniform(-1, 1, 24)
+    F, Lb, Mb, Ub = PH.residual_and_jacobian(p, c, phi, c, np.inf)
+    i, k, h = 7, 1, 1e-6
+    cp = c.copy(); cp[k, i] += h
+    cm = c.copy(); cm[k, i] -= h
+    dF = (PH.residual(p, cp, phi, c, np.inf) - PH.residual(p, cm, phi, c, np.inf)) / (2 * h)
+    assert np.allclose(dF[:, i], Mb[i, :, k], rtol=1e-6, atol=1e-9) and np.allclose(dF[:, i + 1], Lb[i + 1, :, k], rtol=1e-6, atol=1e-9)
