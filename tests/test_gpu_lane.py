@@ -241,3 +241,17 @@ def test_points_ordered_by_expected_iterations_give_the_same_bits(kernel, N, nx,
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
     assert len(set(outs[0][2])) > 1 and (outs[0][5] == 0).all()       # different counts within the batch: the order is not trivial
+
+
+@pytest.mark.parametrize("kernel,N,nx", [('lane', 3, 96), ('lane', 8, 64), ('lane2', 6, 80), ('lane2', 8, 48)])
+def test_error_estimate_stopping_rule(kernel, N, nx, monkeypatch):
+    """pnp_newton_params.error_estimate: accept an iterate whose quadratic error estimate upd^2 / upd_prev is below the tolerance (saves
+    the iteration that only confirms convergence) -- same rule in the oracle, same iteration counts; fewer than without."""
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    kw = {'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * N} if N >= 6 else {}
+    D, q, cb, dx, phiM = make_lanes(N, nx, 4, 9)
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    got, ref = run_both(N, nx, B=41, seed=9, dt=dt, nsteps=4, stationary=False, newton_kw=dict(kw, error_estimate=True, tol=1e-8))
+    assert_close(got, ref, rtol=2e-7)          # (the accepted iterate is within the tolerance of the fixed point, not at it)
+    plain, _ = run_both(N, nx, B=41, seed=9, dt=dt, nsteps=4, stationary=False, newton_kw=dict(kw, tol=1e-8))
+    assert got[2].sum() < plain[2].sum()
