@@ -80,16 +80,16 @@ def compat_solver(B, N, nx, method, seed, device=0):
     return s, (prob, c0, pb, vz, fl)
 
 
-def newton_solver(B, N, nx, seed, device=0, steric=False):
+def newton_solver(B, N, nx, seed, device=0, steric=False, error_estimate=False):
     from catint_amd import _capi
     from catint_amd.synthetic import make_batch
     prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=seed, phi_max=0.2, dt_factor=0.1)
     pb = np.nan_to_num(pb)
     s = _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=B, device=device)
     if steric:
-        s.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=1e-8, mpb_radius=RADII8[:N])
+        s.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=1e-8, mpb_radius=RADII8[:N], error_estimate=error_estimate)
     else:
-        s.set_newton(tol=1e-8)
+        s.set_newton(tol=1e-8, error_estimate=error_estimate)
     return s, (prob, c0, pb, vz, fl)
 
 
@@ -458,6 +458,20 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
                                                    'arithmetic and the latency of a single wave')
         out['large_batch_8_species_32k'] = lane_record(32768, 8, 512, 4446, 20, 'physical_lane_32k',
                                                        'lane kernel, one wave per SIMD (1024 waves); 20 timesteps in one launch', pmc_steps=6)
+        # the same with the quadratic error estimate as stopping rule (pnp_newton_params.error_estimate: saves the iteration that only
+        # confirms convergence; the default rule is the one every other record uses)
+        se, inpe = newton_solver(32768, 8, 512, 4446, device, steric=True, error_estimate=True)
+        se.set_batch(*inpe[1:])
+        se.step(1)
+        se.synchronize()
+        warm()
+        mse = timed_steps(se, 20, 0)
+        ite = se.newton_iterations()
+        oke = int((se.get_status() == 0).sum())
+        se.close()
+        del inpe
+        out['large_batch_8_species_32k']['with_error_estimate'] = {
+            'timesteps_per_s': 32768 * 20 / (mse * 1e-3), 'mean_newton_iterations_per_step': float(ite.sum()) / (32768 * 20), 'lanes_ok': oke}
     except Exception as e:
         out['large_batch_8_species'] = {'error': str(e)}
     try:      # one GPU's share of BASELINE configs[3] in the coupled-Newton mode

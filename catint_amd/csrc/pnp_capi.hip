@@ -1310,8 +1310,13 @@ static int integrate_explicit_rk(pnp_handle* h, const pnp_ode_params* p, int32_t
       if (rc != PNP_OK) return rc;
       HIP_TRY(h, launch_ode_hinit(a, 1, st));
     }
+    a.slot = (int32_t)(step++ & 63);
+    HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
     HIP_TRY(h, launch_ode_open(a, st));
+    // lanes that enter the step loop of this interval: none (every lane has failed in an earlier interval) -> no step group is enqueued
     int32_t left = 1;
+    HIP_TRY(h, hipMemcpyAsync(&left, a.counters + a.slot, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     // a lane needs at most nmax + 1 attempted steps per interval; the counter is read every `every` steps
     for (int64_t tries = 0; left != 0 && tries <= (int64_t)a.nmax + 1; tries += every) {
       for (int e = 0; e < every; ++e) {
@@ -1448,6 +1453,8 @@ int pnp_integrate_rkc(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const 
     HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
     HIP_TRY(h, launch_rkc_advance(a, st));      // first call: argument = the state; later calls: the next step's first stage
     int32_t left = 1;
+    HIP_TRY(h, hipMemcpyAsync(&left, a.counters + a.slot, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));       // (no lane left -- all failed earlier: no tick is enqueued)
     // a lane needs at most nmax attempted steps of at most mmax + 1 ticks, plus the power iterations (<= 50 per estimate)
     const int64_t limit = ((int64_t)a.nmax + 1) * ((int64_t)a.mmax + 53) + 64;
     for (int64_t tries = 0; left != 0 && tries <= limit; tries += every) {

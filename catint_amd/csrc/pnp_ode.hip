@@ -183,6 +183,7 @@ __global__ __launch_bounds__(TPB) void ode_open_kernel(const OdeArgs A) {
   if (b >= A.B) return;
   if (!A.i[b * ODE_NI + ODE_ACTIVE]) return;
   open_step(A, b);
+  if (A.i[b * ODE_NI + ODE_ACTIVE]) atomicAdd(&A.counters[A.slot], 1);      // lanes that enter the interval's step loop
 }
 
 // Stage argument S = 2..7: out = y + h (a_S1 k1 + ...), one workgroup per row (lane, species).
