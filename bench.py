@@ -498,6 +498,32 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
                                         'lanes_ok': ok4}
     except Exception as e:
         out['small_batch_8_species'] = {'error': str(e)}
+    try:      # BASELINE configs[2]: the reference's CO2R example (7 species, 5 buffer reactions, Stern wall, graded mesh), 4096 voltages
+        import importlib.util
+        ex = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'examples')
+        sys.path.insert(0, ex)
+        spec = importlib.util.spec_from_file_location('co2r_physical_sweep', os.path.join(ex, 'co2r_physical_sweep.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        from catint_amd.calculator import Calculator
+        tp, phis = mod.build(4096, 384)
+        calc = Calculator(transport=tp, calc='comsol', device=device)
+        tp.newton = {'tol': 1e-8, 'maxit': 80}
+        calc.set_surface_kinetics([{'species': 'CO2', 'rate': mod.tafel_rate(tp), 'stoichiometry': {'CO2': -1.0, 'CO': 1.0, 'OH-': 2.0}}])
+        warm()
+        t0 = time.perf_counter()
+        calc.run()
+        t_all = time.perf_counter() - t0
+        out['configs2_co2r_sweep'] = {
+            'workload': 'BASELINE configs[2]: examples/co2r_physical_sweep.py -- the run.py system (%d species, homogeneous buffer reactions, '
+                        'size-modified K+, Stern wall, wall-graded %d-point mesh), 4096 voltages -0.5 ... -2.0 V as one batch, first-order Tafel '
+                        'kinetics coupled implicitly (CatMAP is not available), stationary solves along the continuation ramp'
+                        % (tp.nspecies, tp.nx),
+            'lanes': 4096, 'lanes_converged': int((calc.status == 0).sum()), 'continuation_stages': int(calc.continuation_stages),
+            'transport_solve_seconds': float(calc.solve_seconds), 'seconds_incl_host_result_dictionaries': t_all,
+            'operating_points_per_s': 4096 / float(calc.solve_seconds)}
+    except Exception as e:
+        out['configs2_co2r_sweep'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if with_cpu:
         from oracle import pnp_physical as PH
         nl, ns = 2, 2
