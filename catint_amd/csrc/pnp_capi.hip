@@ -1450,7 +1450,7 @@ int pnp_integrate_rkc(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const 
     a.interval = n;
     HIP_TRY(h, launch_rkc_begin(a, st));
     a.slot = (int32_t)(tick++ & 63);
-    HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
+    HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));   // (the ticks below clear each other's slots)
     HIP_TRY(h, launch_rkc_advance(a, st));      // first call: argument = the state; later calls: the next step's first stage
     int32_t left = 1;
     HIP_TRY(h, hipMemcpyAsync(&left, a.counters + a.slot, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1461,8 +1461,7 @@ int pnp_integrate_rkc(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const 
       for (int e = 0; e < every; ++e) {
         const int rc = eval_mol_rhs(h, a.arg, a.F);
         if (rc != PNP_OK) return rc;
-        a.slot = (int32_t)(tick++ & 63);
-        HIP_TRY(h, hipMemsetAsync(a.counters + a.slot, 0, sizeof(int32_t), st));
+        a.slot = (int32_t)(tick++ & 63);       // (cleared by the advance kernel of the tick before)
         HIP_TRY(h, launch_rkc_advance(a, st));
       }
       HIP_TRY(h, hipMemcpyAsync(&left, a.counters + a.slot, sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -82,6 +82,9 @@ __global__ __launch_bounds__(TPB) void rkc_advance_kernel(const RkcArgs A) {
   const int64_t b = blockIdx.x;
   double* d = A.d + b * RKC_ND;
   int32_t* s = A.i + b * RKC_NI;
+  // the next tick's "lanes left" counter is cleared here (its last use lies 63 ticks back, the host only ever reads the slot of
+  // the tick it enqueued last): no separate memset per tick
+  if (b == 0 && threadIdx.x == 0) A.counters[(A.slot + 1) & 63] = 0;
   if (!s[RKI_ACTIVE]) return;
   const int tid = threadIdx.x;
   const int n = A.N * A.nx;
