@@ -551,6 +551,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # stdout carries exactly ONE line, rank 0's JSON: file descriptor 1 is pointed at stderr for everything else that writes to it
+    # (gloo / RCCL banners come from C++, warnings from libraries), the line itself goes to the descriptor saved here
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     # the cpu_baseline leg's checker library: loaded (and, if stale, rebuilt by `make`) BEFORE this process initialises the GPU --
     # no child process may be started afterwards on the GPU box
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -586,29 +591,36 @@ def main():
     solver, (prob, c0, pb, vz, fl) = compat_solver(B, N, nx, args.method, 1000 + rank, device)
 
     per_rank_wall = []
+    from catint_amd.parallel import aligned_start, gather_numbers
 
-    def barrier():
-        solver.synchronize()
+    def timed_call(s, fn, extra=lambda: ()):
+        """The contract's timed region on solver `s`: barrier + synchronize, a start instant agreed by all ranks (aligned_start: a
+        deadline on the node's common clock instead of barrier exit), fn(), synchronize + barrier.  Wall and HIP-event time are the
+        MAX over ranks; `extra()` numbers of every rank come back as columns 3.. of the table."""
+        s.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-
-    def timed(nsteps, spl):
-        barrier()
-        t0 = time.perf_counter()
-        solver.timer_start()
-        solver.step(nsteps, spl)
-        ev_ms = solver.timer_stop()
-        solver.synchronize()
+        t0, _ = aligned_start(dist, comm_dev)
+        s.timer_start()
+        fn()
+        ev_ms = s.timer_stop()
+        s.synchronize()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         if dist is not None:
-            mine = torch.tensor([wall, ev_ms], device=comm_dev, dtype=torch.float64)
-            every = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(every, mine)
-            per_rank_wall[:] = [float(e[0]) for e in every]
-            wall, ev_ms = max(per_rank_wall), max(float(e[1]) for e in every)       # the contract: MAX over ranks
-        return wall, ev_ms
+            dist.barrier()
+        tab = gather_numbers([t0, wall, ev_ms] + list(extra()), dist, comm_dev)
+        return {'wall': float(tab[:, 1].max()), 'ev_ms': float(tab[:, 2].max()), 'per_rank_wall': [float(v) for v in tab[:, 1]],
+                'start_skew_us': float(tab[:, 0].max() - tab[:, 0].min()) * 1e6, 'table': tab}
+
+    start_skew = []
+
+    def timed(nsteps, spl):
+        t = timed_call(solver, lambda: solver.step(nsteps, spl))
+        per_rank_wall[:] = t['per_rank_wall']
+        start_skew[:] = [t['start_skew_us']]
+        return t['wall'], t['ev_ms']
 
     # ---- settling (untimed, not part of W): code objects loaded, clocks up (a cold GPU's clocks settle over ~0.1 s of load) ---------
     solver.set_batch(c0, pb, vz, fl)
@@ -664,6 +676,64 @@ def main():
             for _ in range(8):                        # (launches of the timed length, like the settling loop: the rocprofv3 --stats
                 solver.step(args.steps, args.steps_per_launch)     # average of the headline kernel stays its per-launch time)
             solver.synchronize()
+
+    # ---- N > 1: one GPU's share of BASELINE configs[3] and configs[4] on EVERY rank (the configurations BASELINE quotes for 8 GPUs),
+    # compat step per launch and coupled-Newton lane kernels, each with the contract's timed region (common start, MAX over ranks) --
+    # the scaling curve on those shapes; at N = 1 the same shapes are the `beyond_cache` / `physical_mode` records below
+    shares = None
+    if world > 1 and not args.no_extras:
+        shares = {}
+
+        def lane_bytes_(N_, nx_):
+            return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + 6 * N_ + 5)
+
+        def compat_share(shape, seed, nsteps):
+            SB, SN, SX = shape
+            s_, inp = compat_solver(SB, SN, SX, args.method, seed + rank, device)
+            s_.set_batch(*inp[1:])
+            del inp
+            s_.step(nsteps, 1)
+            s_.synchronize()
+            warm_clocks()
+            s_.step(nsteps, 1)
+            t = timed_call(s_, lambda: s_.step(nsteps, 1), lambda: [float((s_.get_status() == 0).sum())])
+            s_.close()
+            alg = 16.0 * (SN + 1) * SX * SB
+            return {'workload': 'per GPU: batch=%d, %d species, %d grid points, compat step, one launch per timestep' % (SB, SN, SX),
+                    'value': world * SB * nsteps / t['wall'], 'unit': 'timesteps/s', 'steps': nsteps,
+                    'per_rank_timesteps_per_s': [SB * nsteps / w for w in t['per_rank_wall']], 'start_skew_us': t['start_skew_us'],
+                    'hbm_frac_algorithmic_slowest_rank': alg * nsteps / (t['ev_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'lanes_ok': int(t['table'][:, 3].sum()), 'lanes_total': world * SB}
+
+        def newton_share(shape, seed, nsteps):
+            SB, SN, SX = shape
+            s_, inp = newton_solver(SB, SN, SX, seed + rank, device, steric=True)
+            s_.set_batch(*inp[1:])
+            del inp
+            s_.step(1)
+            s_.synchronize()
+            warm_clocks()
+            t = timed_call(s_, lambda: s_.step(nsteps), lambda: [float(s_.newton_iterations().sum()), float((s_.get_status() == 0).sum())])
+            s_.close()
+            its = t['table'][:, 3]
+            return {'workload': 'per GPU: batch=%d, %d species size-modified, %d points, Stern wall, backward Euler, coupled Newton'
+                                % (SB, SN, SX),
+                    'value': world * SB * nsteps / t['wall'], 'unit': 'timesteps/s', 'steps': nsteps,
+                    'newton_iterations_per_s': float(its.sum()) / t['wall'],
+                    'per_rank_timesteps_per_s': [SB * nsteps / w for w in t['per_rank_wall']], 'start_skew_us': t['start_skew_us'],
+                    'hbm_frac_algorithmic_slowest_rank': lane_bytes_(SN, SX) * float(its.max()) / (t['ev_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'lanes_ok': int(t['table'][:, 4].sum()), 'lanes_total': world * SB}
+
+        div = max(1, int(os.environ.get('CATINT_BENCH_SHARE_DIV', '1')))      # tests: the same records on 1/div of the batch
+        for key, shape, seeds, nst in (('configs3_share', BC_SHAPE, (55, 4447), (8, 10)), ('configs4_share', C4_SHAPE, (56, 4448), (4, 4))):
+            shape = (shape[0] // div, shape[1], shape[2])
+            rec = {}
+            for name, fn, seed, n_ in (('compat_per_step', compat_share, seeds[0], nst[0]), ('newton', newton_share, seeds[1], nst[1])):
+                try:
+                    rec[name] = fn(shape, seed, n_)
+                except Exception as e:      # (every rank takes the same path: a failure here is a failure on all of them)
+                    rec[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+            shares[key] = rec
 
     large = None
     if extras and args.large_batch > 0:
@@ -789,12 +859,17 @@ def main():
         if world > 1:
             out['per_rank_timesteps_per_s'] = [B * args.steps / w for w in per_rank_wall]
             out['n_ranks_launched'] = world
+        if dist is not None:
+            out['start_skew_us'] = start_skew[0] if start_skew else None
+        if shares:
+            out.update(shares)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(prob, c0, pb, vz, fl, args.method, args.cpu_seconds)
             if args.method == 'Crank-Nicolson':
                 cb['reference_faithful_dense_1core'] = cpu_reference_faithful(prob, c0, pb, vz, fl, args.method)
             out['cpu_baseline'] = cb
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
     solver.close()
     if dist is not None:
         dist.barrier()

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -37,9 +38,7 @@ struct pnp_handle {
   int32_t* rkc_i = nullptr;                  // ... per-lane integers [cap][RKC_NI] + 64 counters
   double* stage = nullptr;                   // upload staging [B][N][nx] (pnp_set_batch)
   SpecConst* spec = nullptr;
-  int waves_override = 0;    // CATINT_PNP_WAVES_PER_GRID    (tuning / tests)
-  int species_override = 0;  // CATINT_PNP_SPECIES_PER_WAVE  (tuning / tests)
-  int kernel_override = 0;   // CATINT_PNP_KERNEL = 2 (LDS-staged step_kernel) | 4 (register-resident step_kernel_rr) | 5, 6 (streaming step_kernel_st)
+  Options opt;               // debug / tuning switches: pnp_set_option; defaults from the CATINT_* environment at pnp_create
   int32_t* status = nullptr;
   // physical mode (PNP_METHOD_NEWTON)
   bool newton = false;
@@ -75,7 +74,6 @@ struct pnp_handle {
   std::vector<float> lane_key;           // |phiM - phi_bulk| per operating point (pnp_set_batch / pnp_set_pb): the order of a first call
   std::vector<int32_t> lane_iters_host, lane_perm_host;
   bool iters_valid = false;              // h->iters holds the iteration counts of a Newton call on this batch
-  int lane_order_mode = 1;               // CATINT_LANE_ORDER = 0: slot s holds point s (tests, A/B)
   double* scf_d = nullptr;               // (4N + 5) B doubles
   double* scf_snap = nullptr;            // (N + 1) ldx B doubles: per-lane state of the last converged transport solve
   int32_t* scf_i = nullptr;              // 3 B flags + 65 counters
@@ -88,13 +86,64 @@ struct pnp_handle {
   static constexpr int MAX_STEP_STREAMS = 4;
   hipStream_t aux_stream[MAX_STEP_STREAMS - 1] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_STEP_STREAMS - 1] = {nullptr, nullptr, nullptr};
-  int step_streams_override = 0;   // CATINT_PNP_STEP_STREAMS (tuning / tests)
-  int alternate_rows = -1;         // CATINT_PNP_ALTERNATE_ROWS = 0 | 1 (tuning / tests); -1: by the size of the state
   int64_t dev_bytes = 0;
   std::string err;
 };
 
 static thread_local std::string g_create_error;
+
+// ---- options: key = the name of the environment variable without its CATINT_ prefix (case-insensitive; the prefix is accepted) ----
+static bool option_assign(Options& o, const char* key_in, const char* value) {
+  if (!key_in || !value) return false;
+  std::string key(key_in);
+  for (char& ch : key) ch = (char)toupper((unsigned char)ch);
+  if (key.rfind("CATINT_", 0) == 0) key = key.substr(7);
+  const int iv = atoi(value);
+  if (key == "NEWTON_KERNEL") {
+    std::string v(value);
+    for (char& ch : v) ch = (char)tolower((unsigned char)ch);
+    if (v.empty() || v == "auto") o.newton_kernel = NK_AUTO;
+    else if (v == "lane2") o.newton_kernel = NK_LANE2;
+    else if (v == "lane4") o.newton_kernel = NK_LANE4;
+    else if (v[0] == 'l') o.newton_kernel = NK_LANE;
+    else if (v[0] == 'g') o.newton_kernel = NK_GENERIC;
+    else if (v[0] == 't') o.newton_kernel = NK_TEAM;
+    else if (v[0] == 's') o.newton_kernel = NK_SWEEP;
+    else if (v[0] == 'b') o.newton_kernel = NK_BOTH;
+    else return false;
+  } else if (key == "NEWTON_EXCHANGE") o.newton_exchange_global = (value[0] == 'g' || value[0] == 'G') ? 1 : 0;
+  else if (key == "NEWTON_TEAM_THREADS") o.newton_team_threads = iv;
+  else if (key == "NEWTON_REGS") o.newton_regs = iv;
+  else if (key == "NEWTON_BLOCKS") o.newton_blocks = iv;
+  else if (key == "NEWTON_LANE_GROUPS") o.newton_lane_groups = iv;
+  else if (key == "NEWTON_SWEEP_BLOCKS") o.newton_sweep_blocks = iv;
+  else if (key == "LANE_PIVOT_LIMIT") o.lane_pivot_limit = atof(value);
+  else if (key == "LANE_ORDER") o.lane_order = iv;
+  else if (key == "PNP_KERNEL") o.pnp_kernel = iv;
+  else if (key == "PNP_WAVES_PER_GRID") o.pnp_waves_per_grid = iv;
+  else if (key == "PNP_SPECIES_PER_WAVE") o.pnp_species_per_wave = iv;
+  else if (key == "PNP_STEP_STREAMS") o.pnp_step_streams = iv;
+  else if (key == "PNP_ALTERNATE_ROWS") o.pnp_alternate_rows = value[0] ? (iv != 0 ? 1 : 0) : -1;
+  else if (key == "PNP_ST_WAVES_PER_CU") o.pnp_st_waves_per_cu = iv;
+  else if (key == "PNP_NO_POST_UPLOAD_DISPATCH") o.pnp_no_post_upload_dispatch = iv != 0 || !value[0] ? 1 : 0;
+  else return false;
+  return true;
+}
+
+static const char* const kOptionKeys[] = {"NEWTON_KERNEL", "NEWTON_EXCHANGE", "NEWTON_TEAM_THREADS", "NEWTON_REGS", "NEWTON_BLOCKS",
+                                          "NEWTON_LANE_GROUPS", "NEWTON_SWEEP_BLOCKS", "LANE_PIVOT_LIMIT", "LANE_ORDER", "PNP_KERNEL",
+                                          "PNP_WAVES_PER_GRID", "PNP_SPECIES_PER_WAVE", "PNP_STEP_STREAMS", "PNP_ALTERNATE_ROWS",
+                                          "PNP_ST_WAVES_PER_CU", "PNP_NO_POST_UPLOAD_DISPATCH"};
+
+// the defaults of a new handle: the environment, read once per pnp_create (the only place the library looks at it)
+static Options options_from_environment() {
+  Options o;
+  for (const char* k : kOptionKeys) {
+    const std::string name = std::string("CATINT_") + k;
+    if (const char* e = getenv(name.c_str())) (void)option_assign(o, k, e);
+  }
+  return o;
+}
 
 static int fail(pnp_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg;
@@ -178,6 +227,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, PNP_EINVAL, "pnp_create: bad device ordinal");
 
   pnp_handle* h = new pnp_handle();
+  h->opt = options_from_environment();
   h->cfg = *cfg;
   h->P = P;
   h->newton = newton;
@@ -229,7 +279,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
       HIP_TRYC(hipMemcpy(h->gv, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     const int nb = N + 1;
-    if (!newton_exchange_in_lds(nb, cfg->nx)) {
+    if (!newton_exchange_in_lds(nb, cfg->nx, h->opt)) {
       size_t slice = newton_exchange_doubles(nb, cfg->nx);
       if (nb >= 3 && newton_team_doubles(nb, cfg->nx) > slice) slice = newton_team_doubles(nb, cfg->nx);
       h->work_stride = (int64_t)slice;
@@ -254,12 +304,6 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   HIP_TRYC(dev_alloc(h, &h->status, (size_t)Bc));
   HIP_TRYC(dev_alloc(h, &h->spec, (size_t)PNP_MAX_SPECIES));
 #undef HIP_TRYC
-  if (const char* e = getenv("CATINT_PNP_WAVES_PER_GRID")) h->waves_override = atoi(e);
-  if (const char* e = getenv("CATINT_PNP_SPECIES_PER_WAVE")) h->species_override = atoi(e);
-  if (const char* e = getenv("CATINT_PNP_KERNEL")) h->kernel_override = atoi(e);
-  if (const char* e = getenv("CATINT_PNP_STEP_STREAMS")) h->step_streams_override = atoi(e);
-  if (const char* e = getenv("CATINT_LANE_ORDER")) h->lane_order_mode = atoi(e);
-  if (const char* e = getenv("CATINT_PNP_ALTERNATE_ROWS")) h->alternate_rows = atoi(e) != 0 ? 1 : 0;
   DevArgs& a = h->a;
   a.N = N;
   a.nx = cfg->nx;
@@ -271,6 +315,7 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   a.use_mig = cfg->use_migration ? 1 : 0;
   a.nsteps = 1;
   a.has_rates = 0;
+  a.st_waves_per_cu = h->opt.pnp_st_waves_per_cu;
   a.B = 0;
   a.dx = cfg->dx;
   a.dx2 = cfg->dx * cfg->dx;
@@ -288,6 +333,22 @@ int pnp_create(const pnp_config* cfg, pnp_handle** out) {
   a.spec = h->spec;
   a.rates = nullptr;
   *out = h;
+  return PNP_OK;
+}
+
+int pnp_set_option(pnp_handle* h, const char* key, const char* value) {
+  if (!h || !key || !value) return fail(h, PNP_EINVAL, "pnp_set_option: null argument");
+  Options o = h->opt;
+  if (!option_assign(o, key, value)) return fail(h, PNP_EINVAL, std::string("pnp_set_option: unknown key or value: ") + key + " = " + value);
+  if (o.newton_exchange_global != h->opt.newton_exchange_global)
+    return fail(h, PNP_ESTATE, "pnp_set_option: NEWTON_EXCHANGE sizes the buffers of pnp_create; set CATINT_NEWTON_EXCHANGE before creating the handle");
+  // workspaces sized by an option are allocated on first use: an option set afterwards must not outgrow them
+  if ((h->lane_buf || h->lane2_buf) && o.newton_lane_groups != h->opt.newton_lane_groups)
+    return fail(h, PNP_ESTATE, "pnp_set_option: NEWTON_LANE_GROUPS after the lane workspace was allocated");
+  if (h->sweep && o.newton_sweep_blocks != h->opt.newton_sweep_blocks)
+    return fail(h, PNP_ESTATE, "pnp_set_option: NEWTON_SWEEP_BLOCKS after the sweep workspace was allocated");
+  h->opt = o;
+  h->a.st_waves_per_cu = o.pnp_st_waves_per_cu;
   return PNP_OK;
 }
 
@@ -430,6 +491,11 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_batch = true;
     h->steps_done = 0;
+    // lane kernels: the iteration counters were just zeroed (unpack_state_kernel), so the first solve of this batch deals the
+    // operating points by their wall-to-bulk potential difference
+    h->iters_valid = false;
+    h->lane_key.resize((size_t)B);
+    for (int64_t b = 0; b < B; ++b) h->lane_key[b] = (float)std::fabs(pb[b * 4 + 0] - pb[b * 4 + 1]);
     return PNP_OK;
   }
   h->cur = 0;
@@ -443,7 +509,7 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   // and extra synchronisation change nothing.
   // Only batches that can fill every SIMD in one round were affected (B = 960, 1024 with the headline kernel; B = 512 was not): smaller
   // uploads -- the per-iteration uploads of a small compat SCF loop -- skip the extra dispatch, its buffers and its synchronisation.
-  if (h->B >= 768 && !getenv("CATINT_PNP_NO_POST_UPLOAD_DISPATCH")) {
+  if (h->B >= 768 && !h->opt.pnp_no_post_upload_dispatch) {
     const int rc = ensure_potential_buffers(h);
     if (rc != PNP_OK) return rc;
     HIP_TRY(h, launch_poisson(h->a, h->lapl[0], h->v, h->gradv, h->stream));
@@ -451,11 +517,6 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
   }
   h->have_batch = true;
   h->steps_done = 0;
-  h->iters_valid = false;
-  if (h->newton) {
-    h->lane_key.resize((size_t)B);
-    for (int64_t b = 0; b < B; ++b) h->lane_key[b] = (float)std::fabs(pb[b * 4 + 0] - pb[b * 4 + 1]);
-  }
   return PNP_OK;
 }
 
@@ -505,7 +566,7 @@ static int run_steps_on(pnp_handle* h, int nsteps, int64_t b0, int64_t nb, hipSt
   // One timestep per launch over a state the caches cannot hold: every other launch walks the operating points from the last to
   // the first, starting on the rows the launch before wrote last (still in L2 / MALL).  Measured (tools/probe/step_streams.py,
   // profiles/r03_step_streams.jsonl): +6 % at 335 MB of state, nothing lost or gained at 2.1 GB, -2 % at 42 MB.
-  const bool alternate = h->alternate_rows >= 0 ? h->alternate_rows == 1 : (double)a.B * (a.N + 2) * a.ldx * 8.0 >= 128e6;
+  const bool alternate = h->opt.pnp_alternate_rows >= 0 ? h->opt.pnp_alternate_rows == 1 : (double)a.B * (a.N + 2) * a.ldx * 8.0 >= 128e6;
   a.reverse = (nsteps == 1 && alternate) ? (int)(h->steps_done & 1) : 0;
   if (a.has_rates) a.rates = h->rates;
   if (b0 != 0 || nb != a.B) a = row_chunk(a, b0, nb);
@@ -528,23 +589,23 @@ static int run_steps_on(pnp_handle* h, int nsteps, int64_t b0, int64_t nb, hipSt
   int kind = te ? te->kind : 0, W = te ? te->W : 1, G = te ? te->G : 1;
   const bool direct_ok = step_rr_applicable(a);
   if (kind != 0 && !direct_ok) kind = 0, W = 0;
-  if (h->kernel_override == 2) kind = 0, W = (te && te->kind == 0) ? W : 0;
-  if (h->kernel_override == 4 && direct_ok) kind = 1, W = (te && te->kind == 1) ? W : 1;
-  if (h->kernel_override >= 5 && h->kernel_override <= 7 && direct_ok) kind = 2;
+  if (h->opt.pnp_kernel == 2) kind = 0, W = (te && te->kind == 0) ? W : 0;
+  if (h->opt.pnp_kernel == 4 && direct_ok) kind = 1, W = (te && te->kind == 1) ? W : 1;
+  if (h->opt.pnp_kernel >= 5 && h->opt.pnp_kernel <= 7 && direct_ok) kind = 2;
   if (kind == 2) {
     // 16 points per lane: the gradient row of the step in LDS (two waves per SIMD instead of one: 0.53 -> 0.60 of the roofline per
     // step and 0.68 -> 0.72 fused on one GPU's share of configs[3]); shorter grids: registers only
-    const int st_mode = h->kernel_override == 6 ? 1 : (h->kernel_override == 7 ? 2 : (h->kernel_override == 5 ? 0 : ((h->P == 16 && Bsel >= 2048) ? 2 : 0)));
+    const int st_mode = h->opt.pnp_kernel == 6 ? 1 : (h->opt.pnp_kernel == 7 ? 2 : (h->opt.pnp_kernel == 5 ? 0 : ((h->P == 16 && Bsel >= 2048) ? 2 : 0)));
     HIP_TRY(h, launch_step_st(a, st_mode, stream));
   } else if (kind == 1) {
     int w = W;
-    if (h->waves_override >= 1 && h->waves_override <= 4) w = h->waves_override;
+    if (h->opt.pnp_waves_per_grid >= 1 && h->opt.pnp_waves_per_grid <= 4) w = h->opt.pnp_waves_per_grid;
     HIP_TRY(h, launch_step_rr(a, w, stream));
   } else {
     if (W == 0 || !step_config_supported(W, G)) choose_step_config(a.N, Bsel, h->P, fused, &W, &G);
-    if (h->waves_override >= 1 || h->species_override >= 1) {
-      const int w2 = h->waves_override >= 1 ? h->waves_override : W;
-      const int g2 = h->species_override >= 1 ? h->species_override : 1;
+    if (h->opt.pnp_waves_per_grid >= 1 || h->opt.pnp_species_per_wave >= 1) {
+      const int w2 = h->opt.pnp_waves_per_grid >= 1 ? h->opt.pnp_waves_per_grid : W;
+      const int g2 = h->opt.pnp_species_per_wave >= 1 ? h->opt.pnp_species_per_wave : 1;
       if (step_config_supported(w2, g2)) {
         W = w2;
         G = g2;
@@ -569,7 +630,7 @@ static int run_steps(pnp_handle* h, int nsteps) {
 // chunk no longer fills the chip: -4 % at 2048, -11 % at 1024).
 static int step_streams(const pnp_handle* h, int launches) {
   if (launches < 2) return 1;
-  int S = h->step_streams_override;
+  int S = h->opt.pnp_step_streams;
   if (S < 1) return h->a.B >= 4096 ? 2 : 1;
   if (S > pnp_handle::MAX_STEP_STREAMS) S = pnp_handle::MAX_STEP_STREAMS;
   while (S > 1 && h->a.B / S < 256) --S;
@@ -585,7 +646,7 @@ static int step_streams(const pnp_handle* h, int launches) {
 static int lane_order(pnp_handle* h, NewtonArgs& a) {
   a.lane_perm = nullptr;
   const int64_t B = h->B;
-  if (h->lane_order_mode == 0 || B < 64) return PNP_OK;
+  if (h->opt.lane_order == 0 || B < 64) return PNP_OK;
   if (!h->lane_perm) HIP_TRY(h, dev_alloc(h, &h->lane_perm, (size_t)h->cfg.batch_capacity));
   std::vector<int32_t>& perm = h->lane_perm_host;
   perm.resize((size_t)B);
@@ -658,19 +719,18 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.rt = (h->rt_dev && h->rt.n > 0) ? h->rt_dev : nullptr;
   a.n_wk = h->newton_explicit_kinetics ? 0 : h->n_wk;
   a.lane_mask = h->newton_mask;
-  // (the lane kernels do not carry the convection term: those batches stay with the workgroup-per-point / lane-team kernels)
-  const bool use_lane2 = !a.convect && newton_lane2_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0));
-  const bool use_lane = !a.convect && !use_lane2 && newton_lane_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0));
+  // (kernel variants: 0 point ions, 1 steric ions, 2 + homogeneous reactions and / or the constant convection term)
+  const int variant = (a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0);
+  a.opt = &h->opt;
+  const bool use_lane2 = newton_lane2_preferred(N + 1, nx, h->B, variant, h->opt);
+  const bool use_lane = !use_lane2 && newton_lane_preferred(N + 1, nx, h->B, variant, h->opt);
   if (use_lane2) {
     const size_t per_group = (newton_lane2_rec_doubles(N + 1, nx) + newton_lane2_state_doubles(N + 1, nx)) * sizeof(double);
     if (!h->lane2_buf) {
       int64_t groups = (h->cfg.batch_capacity + 15) / 16;
       const int64_t fit = (int64_t)(((size_t)48 << 30) / per_group);
       if (groups > fit) groups = fit;
-      if (const char* e = getenv("CATINT_NEWTON_LANE_GROUPS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v < groups) groups = v;
-      }
+      if (h->opt.newton_lane_groups >= 1 && h->opt.newton_lane_groups < groups) groups = h->opt.newton_lane_groups;
       if (groups < 1) groups = 1;
       HIP_TRY(h, dev_alloc(h, &h->lane2_buf, (size_t)groups * per_group / sizeof(double)));
       h->lane2_groups = groups;
@@ -689,10 +749,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
       int64_t groups = (h->cfg.batch_capacity + 31) / 32;
       const int64_t fit = (int64_t)(((size_t)48 << 30) / per_group);
       if (groups > fit) groups = fit;
-      if (const char* e = getenv("CATINT_NEWTON_LANE_GROUPS")) {      // tests: force several chunks
-        const int v = atoi(e);
-        if (v >= 1 && v < groups) groups = v;
-      }
+      if (h->opt.newton_lane_groups >= 1 && h->opt.newton_lane_groups < groups) groups = h->opt.newton_lane_groups;      // tests: several chunks
       if (groups < 1) groups = 1;
       HIP_TRY(h, dev_alloc(h, &h->lane_buf, (size_t)groups * per_group / sizeof(double)));
       h->lane_groups = groups;
@@ -703,7 +760,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
     a.lane_xs = a.lane_ts + (size_t)h->lane_groups * vp2 * nx * 32;
     a.lane_tco = a.lane_xs + (size_t)h->lane_groups * vp2 * nx * 32;
     a.lane_rec = a.lane_tco + (size_t)h->lane_groups * cp2 * nx * 32;
-  } else if (newton_sweep_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0))) {
+  } else if (newton_sweep_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0), h->opt)) {
     // one team (N+1 lanes) per operating point, 64/(N+1) per wave; the workspace holds the records of the resident waves: at
     // most four per SIMD, all of the batch capacity, and 32 GiB
     const int64_t tpw = 64 / (N + 1);
@@ -713,10 +770,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
       const int64_t per_wave = (N + 1 >= 6) ? tpw / 2 : tpw;
       int64_t blocks = (h->cfg.batch_capacity + per_wave - 1) / per_wave;
       if (blocks > 4096) blocks = 4096;
-      if (const char* e = getenv("CATINT_NEWTON_SWEEP_BLOCKS")) {      // tests: force several rounds per team
-        const int v = atoi(e);
-        if (v >= 1 && v < blocks) blocks = v;
-      }
+      if (h->opt.newton_sweep_blocks >= 1 && h->opt.newton_sweep_blocks < blocks) blocks = h->opt.newton_sweep_blocks;      // tests: several rounds per team
       const int64_t fit = (int64_t)(((size_t)32 << 30) / per_block);
       if (blocks > fit) blocks = fit;
       if (blocks < 1) blocks = 1;
@@ -743,10 +797,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.status = h->status;
   a.iters = h->iters;
   int blocks = h->nw_blocks;
-  if (const char* e = getenv("CATINT_NEWTON_BLOCKS")) {   // tuning: size of the persistent grid
-    const int v = atoi(e);
-    if (v >= 1 && v < blocks) blocks = v;
-  }
+  if (h->opt.newton_blocks >= 1 && h->opt.newton_blocks < blocks) blocks = h->opt.newton_blocks;      // tuning: size of the persistent grid
   if ((int64_t)blocks > h->B) blocks = (int)h->B;
   if (use_lane2 || use_lane) {
     const int rc = lane_order(h, a);

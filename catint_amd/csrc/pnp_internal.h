@@ -7,6 +7,28 @@
 
 namespace pnp {
 
+// Debug / tuning options of a handle (C-ABI: pnp_set_option).  The CATINT_* environment variables of the same names are read ONCE,
+// in pnp_create, as the defaults of a new handle; nothing in the library reads the environment afterwards.
+enum NewtonKernelChoice { NK_AUTO = 0, NK_GENERIC, NK_TEAM, NK_SWEEP, NK_BOTH, NK_LANE, NK_LANE2, NK_LANE4 };
+struct Options {
+  int newton_kernel = NK_AUTO;       // NEWTON_KERNEL = generic | team | sweep | both | lane | lane2 (tests force a kernel family)
+  int newton_exchange_global = 0;    // NEWTON_EXCHANGE = global: the row-per-thread kernel's buffers in device memory (creation time)
+  int newton_team_threads = 0;       // NEWTON_TEAM_THREADS = 256 | 512 | 1024
+  int newton_regs = 0;               // NEWTON_REGS = 512: the 512-register build of the row-per-thread kernel (N = 5, 6)
+  int newton_blocks = 0;             // NEWTON_BLOCKS: size of the persistent grid of the workgroup-per-point kernels
+  int newton_lane_groups = 0;        // NEWTON_LANE_GROUPS: groups the lane kernels' workspace holds (tests: several chunks)
+  int newton_sweep_blocks = 0;       // NEWTON_SWEEP_BLOCKS: waves the sweep kernels' workspace holds
+  double lane_pivot_limit = 0.0;     // LANE_PIVOT_LIMIT: pivot monitor of the lane kernels (0: PIVOT_GROWTH_LIMIT)
+  int lane_order = 1;                // LANE_ORDER = 0: slot s holds operating point s
+  int pnp_kernel = 0;                // PNP_KERNEL = 2 (LDS-staged step_kernel) | 4 (register-resident) | 5, 6, 7 (streaming)
+  int pnp_waves_per_grid = 0;        // PNP_WAVES_PER_GRID
+  int pnp_species_per_wave = 0;      // PNP_SPECIES_PER_WAVE
+  int pnp_step_streams = 0;          // PNP_STEP_STREAMS: row chunks of a pnp_step call of several launches
+  int pnp_alternate_rows = -1;       // PNP_ALTERNATE_ROWS = 0 | 1; -1: by the size of the state
+  int pnp_st_waves_per_cu = 0;       // PNP_ST_WAVES_PER_CU: resident waves of the streaming kernel
+  int pnp_no_post_upload_dispatch = 0;   // PNP_NO_POST_UPLOAD_DISPATCH = 1 (probes)
+};
+
 // Per-species constants, computed once on the host with the reference's expression order
 // (catint/calculator_old.py:543-547, :1013-1017; catint/transport.py:436) and read by the kernels
 // through scalar loads.
@@ -42,6 +64,7 @@ struct DevArgs {
   int32_t use_mig;
   int32_t nsteps;    // timesteps fused into this launch
   int32_t has_rates; // FTCS: add rates[b][k][i]*dt (computed by rates_kernel before the step)
+  int32_t st_waves_per_cu;   // streaming kernel: resident waves per CU (Options::pnp_st_waves_per_cu; 0: what fits)
   int32_t reverse;   // streaming kernel: walk the operating points from the last to the first (see pnp_step: alternate launches of one
                      // timestep start on the rows the previous launch wrote last, which the caches still hold)
   int64_t B;
@@ -163,28 +186,29 @@ struct NewtonArgs {
                                          // lane_order) so that the lanes of a wave finish together.
   int32_t lane_lg, pad3_;                // operating points per group: 32 (lane kernel) or 16 (lane-pair kernel, pnp_lane2.hip)
   double lane_pivot_limit;               // pivot monitor of the lane kernels (pnp_lane_common.h): multipliers beyond this mark the lane
+  const Options* opt;                    // HOST pointer (the launchers' kernel choice); never dereferenced on the device
 };
 int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);
 size_t newton_team_doubles(int nb, int nx);      // row buffer of the lane-team kernel (N >= 5)
 size_t newton_sweep_doubles(int nb, int nx);     // records of one team of the sweep kernel (block Thomas, large batches)
-bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode);
-bool newton_sweep_two_sided(int nb, int nx, int64_t B, int mode);    // ... with two teams per operating point (elimination from both ends)   // large blocks and enough lanes to fill the chip with teams (mode: 0 point ions, 1 steric, 2 + reactions)
-bool newton_exchange_in_lds(int nb, int nx);
+bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode, const Options& opt);
+bool newton_sweep_two_sided(int nb, int nx, int64_t B, int mode, const Options& opt);    // ... with two teams per operating point (elimination from both ends)   // large blocks and enough lanes to fill the chip with teams (mode: 0 point ions, 1 steric, 2 + reactions)
+bool newton_exchange_in_lds(int nb, int nx, const Options& opt);
 int newton_pair_threads(int nb, int nx);   // threads of the pair kernel, 0 if the shape does not fit it
 int newton_pair_stride(int nb, int nx);    // its compile-time row stride (256 or 512)
 hipError_t launch_newton(const NewtonArgs& a, int blocks, hipStream_t stream);
 // lane kernel (pnp_lane.hip): one operating point per lane, block Thomas from both ends in registers; point / steric ions without
 // homogeneous reactions
 bool newton_lane_supported(int nb, int nx, int mode);
-bool newton_lane_preferred(int nb, int nx, int64_t B, int mode);
+bool newton_lane_preferred(int nb, int nx, int64_t B, int mode, const Options& opt);
 size_t newton_lane_rec_doubles(int nb, int nx);       // records of one group of 32 operating points
 size_t newton_lane_state_doubles(int nb, int nx);     // transposed state + previous time level of one group
 hipError_t launch_newton_lane(const NewtonArgs& a, hipStream_t stream);
 hipError_t launch_lane_transpose(const NewtonArgs& a, int64_t ngroups, bool in, hipStream_t stream);     // a.lane_lg points per group
 // lane-pair kernel (pnp_lane2.hip): four lanes per operating point (two directions x two halves of the block row), N >= 5
 bool newton_lane2_supported(int nb, int nx, int mode);
-bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode);
+bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode, const Options& opt);
 size_t newton_lane2_rec_doubles(int nb, int nx);      // per group of 16 operating points
 size_t newton_lane2_state_doubles(int nb, int nx);
 hipError_t launch_newton_lane2(const NewtonArgs& a, hipStream_t stream);

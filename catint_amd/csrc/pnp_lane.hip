@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   constexpr int N = NB - 1, NREC = NB * NB + NB;
   constexpr int VP = (NB + 1) / 2, CP = (N + 1) / 2, RP = NREC / 2;     // 16-byte pairs per row: state / previous level / record
   constexpr bool MPB = MODE >= 1;
+  constexpr bool FULL = MODE == 2;           // + homogeneous reactions (G.rt) and a constant convection velocity (G.pe); steric code path
   __shared__ double s_cb[N][LG];             // bulk concentrations of the wave's operating points
   // The record a row hands to the next one (T, t) and the LU factors of D' do not both fit the register file next to everything
   // else once the blocks are 8 x 8 or 9 x 9: the first TL columns of T then live in LDS (written as they are solved, read back
@@ -173,6 +174,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   if (lane < PNP_NEWTON_MAX_SPECIES) {
     sP.sig[lane] = G.sig[lane];
     sP.peq[lane] = G.peq[lane];
+    sP.pe[lane] = G.pe[lane];
+    sP.rs[lane] = G.rs[lane];
   }
   __syncthreads();
   // row visited by the lane in forward step s (clamped to a valid row where the lane rests)
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 
   bool have = valid, fresh = true;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
-  double upd_prev = INFINITY;
+  double upd_prev = INFINITY, upd_prev2 = INFINITY;
   double alarm = 0.0;            // pivot monitor (sticky): see PIVOT_GROWTH_LIMIT
 #ifdef PNP_LANE_STAMPS
   double stamp_f = 0.0, stamp_b = 0.0, stamp_u = 0.0, stamp_n = 0.0;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     const bool first = fresh;          // first iteration of a timestep: the previous time level is the state itself
     if (fresh) {
       it = 0;
-      upd_prev = INFINITY;
+      upd_prev = upd_prev2 = INFINITY;
       fresh = false;
     }
     it += 1;
@@ -282,7 +285,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         const double dphi = bphi - hphi, dw = bw - hw;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-          const LEdge e = lane_edge_flux(__builtin_fma(G.qb[k], dphi, dw), hc[k], bc[k], we);     // left: row nx-2, right: the bulk row
+          // (FULL: a constant convection velocity v shifts the drift argument by -v h_e / D_k, comsol_model.py:901-903)
+          const LEdge e = lane_edge_flux(__builtin_fma(G.qb[k], dphi, dw) - (FULL ? sP.pe[k] / we : 0.0), hc[k], bc[k], we);     // left: row nx-2, right: the bulk row
           eJ[k] = e.J;
           eBd[k] = e.Bp;
           eBn[k] = e.Bm;
@@ -350,10 +354,11 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         double aJ[N], aBd[N], aBn[N], aJu[N];
         {
           const double dphi = aphi - hphi, dw = aw - hw;
+          const double rwea = FULL ? 1.0 / wea : 0.0;
 #pragma unroll
           for (int k = 0; k < N; ++k) {
             // the edge is evaluated in its left -> right orientation whichever way the lane walks
-            const double u = sgn * __builtin_fma(G.qb[k], dphi, dw);
+            const double u = sgn * __builtin_fma(G.qb[k], dphi, dw) - (FULL ? P->pe[k] * rwea : 0.0);
             double h_ = hc[k];              // (opaque: a select between elements of two arrays is otherwise turned into one
             asm volatile("" : "+v"(h_));    //  dynamically indexed stack array)
             const double cl = side ? ac[k] : h_, cr = side ? h_ : ac[k];
@@ -452,6 +457,28 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 #pragma unroll
               for (int j = 0; j < N; ++j) D[k][j] -= (j == sp) ? a * dg : 0.0;
               if (al != 0.0) D[k][N] += a * al * gq;
+            }
+          }
+        }
+        // ---- homogeneous reactions (fill_row in pnp_newton.hip): source -(dx^2/D_k) v_i R_k and its Jacobian, a rank-one update of
+        // the species block per reaction side; the stoichiometric weights are table data, so the row tests are scalar branches ------
+        if constexpr (FULL) {
+          if (A.rt) {
+            const ReactionTable* rt = A.rt;
+            const int nr = rt->n;
+            for (int r = 0; r < nr; ++r) {
+              for (int sd = 0; sd < 2; ++sd) {
+                double prod, dprod[N], sw[N];
+                if (!lane_reaction_side<N, MPB>(rt, r, sd, hc, hinv, G.vol, prod, dprod, sw)) continue;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                  if (sw[k] == 0.0) continue;
+                  const double wr = sw[k] * (vi * P->rs[k]);
+                  rhs[k] = __builtin_fma(wr, prod, rhs[k]);
+#pragma unroll
+                  for (int j = 0; j < N; ++j) D[k][j] = __builtin_fma(-wr, dprod[j], D[k][j]);
+                }
+              }
             }
           }
         }
@@ -742,10 +769,11 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       bool accept = false;
       if (lam == 1.0) {
         accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, A.tol);
+              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol);
+        upd_prev2 = upd_prev;
         upd_prev = upd;
       } else {
-        upd_prev = INFINITY;
+        upd_prev = upd_prev2 = INFINITY;
       }
       if (accept || it >= A.maxit) {
         total_it += accept ? it : A.maxit + 1;
@@ -773,14 +801,12 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
-bool newton_lane_supported(int nb, int nx, int mode) { return nb >= 2 && nb <= 9 && nx >= 5 && mode <= 1; }
+// mode 2: homogeneous reactions and / or a constant convection velocity (MODE 2 instances: the steric code path with both terms)
+bool newton_lane_supported(int nb, int nx, int mode) { return nb >= 2 && nb <= 9 && nx >= 5 && mode <= 2; }
 
-bool newton_lane_preferred(int nb, int nx, int64_t B, int mode) {
+bool newton_lane_preferred(int nb, int nx, int64_t B, int mode, const Options& opt) {
   if (!newton_lane_supported(nb, nx, mode)) return false;
-  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) {
-    if (f[0] == 'l') return !(f[1] && f[2] && f[3] && f[4] == '2');      // "lane" (not "lane2": the lane-pair kernel)
-    if (f[0] != 0) return false;           // another kernel is forced (tests, probes)
-  }
+  if (opt.newton_kernel != NK_AUTO) return opt.newton_kernel == NK_LANE;      // a kernel family is forced (tests, probes)
   // Measured (tools/probe/lane_sweep.py -> profiles/r03_lane_sweep.jsonl: transient steps, steric ions, Stern wall; timesteps/s of
   // this kernel over the best of the others).  A lane advances its operating point at a fixed pace whatever the batch (N = 8,
   // nx = 512: 3.4 ms per Newton iteration), so its rate grows with the batch until every SIMD holds a wave (B = 32 768) and is
@@ -806,9 +832,9 @@ hipError_t launch_lane_transpose(const NewtonArgs& a, int64_t ngroups, bool in, 
   return hipGetLastError();
 }
 
-bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode) {
+bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode, const Options& opt) {
   if (!newton_lane2_supported(nb, nx, mode)) return false;
-  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 'l' && f[1] && f[2] && f[3] && f[4] == '2';
+  if (opt.newton_kernel != NK_AUTO) return opt.newton_kernel == NK_LANE2;
   // Measured on one device in one call (tools/probe/lane2_probe.sh; N = 8, nx = 512, timesteps/s, lane pair / lane / lane teams):
   // B = 1024 1.16e5 / 1.00e5 / 1.40e5, 2048 2.40e5 / 1.96e5 / 1.43e5, 4096 4.51e5 / 3.85e5 / 1.44e5, 8192 7.31e5 / 7.07e5 / 1.51e5,
   // 16 384 0.99e6 / 1.03e6.  Twice the waves for the same batch, but the distribution overhead (selects, DPP moves, duplicated
@@ -824,11 +850,12 @@ static hipError_t launch_lane_nb(const NewtonArgs& a0, hipStream_t stream) {
     NewtonArgs a = a0;
     a.lane_group0 = g0;
     a.lane_lg = LG;
-    a.lane_pivot_limit = lane_pivot_limit_from_env();
+    a.lane_pivot_limit = lane_pivot_limit(a.opt);
     const int64_t ng = groups - g0 < cap ? groups - g0 : cap;
     const dim3 tg((unsigned)ng, (unsigned)((a.nx + 63) / 64));
     hipLaunchKernelGGL((lane_transpose_kernel<true>), tg, dim3(256), 0, stream, a);
-    if (a.mpb) hipLaunchKernelGGL((newton_lane_kernel<NB, 1>), dim3((unsigned)ng), dim3(64), 0, stream, a);
+    if (a.rt || a.convect) hipLaunchKernelGGL((newton_lane_kernel<NB, 2>), dim3((unsigned)ng), dim3(64), 0, stream, a);
+    else if (a.mpb) hipLaunchKernelGGL((newton_lane_kernel<NB, 1>), dim3((unsigned)ng), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((newton_lane_kernel<NB, 0>), dim3((unsigned)ng), dim3(64), 0, stream, a);
     hipLaunchKernelGGL((lane_transpose_kernel<false>), tg, dim3(256), 0, stream, a);
   }

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
   constexpr int RP = (NREC + 1) / 2;         // ... in 16-byte pairs
   constexpr int VP = (NB + 1) / 2, CP = (N + 1) / 2;
   constexpr bool MPB = MODE >= 1;
+  constexpr bool FULL = MODE == 2;           // + homogeneous reactions and a constant convection velocity (see pnp_lane.hip)
   __shared__ double s_cb[N][OG];
   __shared__ LaneParams sP;
   const int lane = threadIdx.x, o = lane >> 2;
@@ -93,6 +94,8 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
   if (lane < PNP_NEWTON_MAX_SPECIES) {
     sP.sig[lane] = G.sig[lane];
     sP.peq[lane] = G.peq[lane];
+    sP.pe[lane] = G.pe[lane];
+    sP.rs[lane] = G.rs[lane];
   }
   __syncthreads();
   auto fwd_row = [&](int s) { return side ? (s < n_dn ? nx - 2 - s : m + 1) : (s < m ? s : m); };
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
 
   bool have = valid, fresh = true;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
-  double upd_prev = INFINITY;
+  double upd_prev = INFINITY, upd_prev2 = INFINITY;
   double alarm = 0.0;            // pivot monitor (sticky)
 
   for (;;) {
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
     const bool first = fresh;
     if (fresh) {
       it = 0;
-      upd_prev = INFINITY;
+      upd_prev = upd_prev2 = INFINITY;
       fresh = false;
     }
     it += 1;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
         const double dphi = bphi - hphi, dw = bw - hw;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-          const LEdge e = lane_edge_flux(__builtin_fma(G.qb[k], dphi, dw), hc[k], bc[k], we);
+          const LEdge e = lane_edge_flux(__builtin_fma(G.qb[k], dphi, dw) - (FULL ? sP.pe[k] / we : 0.0), hc[k], bc[k], we);
           eJ[k] = e.J;
           eBd[k] = e.Bp;
           eBn[k] = e.Bm;
@@ -250,12 +253,13 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
         double aJ[N], aBd[N], aBn[N], aJu[N];
         {
           const double dphi = aphi - hphi, dw = aw - hw;
+          const double rwea = FULL ? 1.0 / wea : 0.0;
 #pragma unroll
           for (int kk = 0; kk < (N + 1) / 2; ++kk) {
             const int k0 = 2 * kk, k1 = 2 * kk + 1 < N ? 2 * kk + 1 : 2 * kk;
             const double qb_ = h ? G.qb[k1] : G.qb[k0];
             const double hc_ = h ? hc[k1] : hc[k0], ac_ = h ? ac[k1] : ac[k0];
-            const double u = sgn * __builtin_fma(qb_, dphi, dw);
+            const double u = sgn * __builtin_fma(qb_, dphi, dw) - (FULL ? (h ? P->pe[k1] : P->pe[k0]) * rwea : 0.0);
             const double cl = side ? ac_ : hc_, cr = side ? hc_ : ac_;
             const LEdge e = lane_edge_flux(u, cl, cr, wea);
             const double mJ = sgn * e.J, mBd = side ? e.Bm : e.Bp, mBn = side ? e.Bp : e.Bm, mJu = e.Ju;
@@ -383,6 +387,34 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
                   if (j == N && al != 0.0) Dl[k][jj < CLD ? jj : 0] += a * al * gq;
                 }
                 if (j == NB) Xl[k][jj] += a * gq;
+              }
+            }
+          }
+        }
+        // ---- homogeneous reactions (see pnp_lane.hip): every lane evaluates the rates, each half keeps its own columns -----------------------
+        if constexpr (FULL) {
+          if (A.rt) {
+            const ReactionTable* rt = A.rt;
+            const int nr = rt->n;
+            for (int r = 0; r < nr; ++r) {
+              for (int sd = 0; sd < 2; ++sd) {
+                double prod, dprod[N], sw[N];
+                if (!lane_reaction_side<N, MPB>(rt, r, sd, hc, hinv, G.vol, prod, dprod, sw)) continue;
+                double dl[CL];           // d prod / d c_j of this lane's columns
+#pragma unroll
+                for (int jj = 0; jj < CL; ++jj)
+                  dl[jj] = (2 * jj + 1 < N) ? (h ? dprod[2 * jj + 1 < N ? 2 * jj + 1 : 0] : dprod[2 * jj < N ? 2 * jj : 0])
+                                            : ((2 * jj < N && !h) ? dprod[2 * jj < N ? 2 * jj : 0] : 0.0);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                  if (sw[k] == 0.0) continue;
+                  const double wr = sw[k] * (vi * P->rs[k]);
+#pragma unroll
+                  for (int jj = 0; jj < CL; ++jj) {
+                    if (jj < CLD) Dl[k][jj < CLD ? jj : 0] = __builtin_fma(-wr, dl[jj], Dl[k][jj < CLD ? jj : 0]);
+                    if (col_j(jj) == NB) Xl[k][jj] = __builtin_fma(wr, prod, Xl[k][jj]);
+                  }
+                }
               }
             }
           }
@@ -659,10 +691,11 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
       bool accept = false;
       if (lam == 1.0) {
         accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-                 newton_at_rounding_floor(upd, upd_prev, A.tol);
+                 newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol);
+        upd_prev2 = upd_prev;
         upd_prev = upd;
       } else {
-        upd_prev = INFINITY;
+        upd_prev = upd_prev2 = INFINITY;
       }
       if (accept || it >= A.maxit) {
         total_it += accept ? it : A.maxit + 1;
@@ -689,11 +722,12 @@ static hipError_t launch_lane2_nb(const NewtonArgs& a0, hipStream_t stream) {
     NewtonArgs a = a0;
     a.lane_group0 = g0;
     a.lane_lg = OG;
-    a.lane_pivot_limit = lane_pivot_limit_from_env();
+    a.lane_pivot_limit = lane_pivot_limit(a.opt);
     const int64_t ng = groups - g0 < cap ? groups - g0 : cap;
     hipError_t e = launch_lane_transpose(a, ng, true, stream);
     if (e != hipSuccess) return e;
-    if (a.mpb) hipLaunchKernelGGL((newton_lane2_kernel<NB, 1>), dim3((unsigned)ng), dim3(64), 0, stream, a);
+    if (a.rt || a.convect) hipLaunchKernelGGL((newton_lane2_kernel<NB, 2>), dim3((unsigned)ng), dim3(64), 0, stream, a);
+    else if (a.mpb) hipLaunchKernelGGL((newton_lane2_kernel<NB, 1>), dim3((unsigned)ng), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((newton_lane2_kernel<NB, 0>), dim3((unsigned)ng), dim3(64), 0, stream, a);
     e = launch_lane_transpose(a, ng, false, stream);
     if (e != hipSuccess) return e;
@@ -711,6 +745,6 @@ hipError_t launch_newton_lane2(const NewtonArgs& a, hipStream_t stream) {
   }
 }
 
-bool newton_lane2_supported(int nb, int nx, int mode) { return nb >= 6 && nb <= 9 && nx >= 5 && mode <= 1; }
+bool newton_lane2_supported(int nb, int nx, int mode) { return nb >= 6 && nb <= 9 && nx >= 5 && mode <= 2; }
 
 }  // namespace pnp

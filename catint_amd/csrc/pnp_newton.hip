@@ -596,7 +596,7 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
       for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
-      double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
+      double upd_prev = INFINITY, upd_prev2 = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
         for (int row = tid; row < nx; row += T) {
@@ -690,13 +690,14 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
           // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
           // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
           if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, A.tol)) {
+              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol)) {
             conv = true;
             break;
           }
+          upd_prev2 = upd_prev;
           upd_prev = upd;
         } else {
-          upd_prev = INFINITY;
+          upd_prev = upd_prev2 = INFINITY;
         }
       }
       total_it += conv ? it : A.maxit + 1;
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(NB >= 5 ? 256 : 512) void newton_pair_kernel(const 
       for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
-      double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
+      double upd_prev = INFINITY, upd_prev2 = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
         // The thread index is made opaque once per iteration: the compiler then recomputes the ~100 global addresses that
@@ -1060,13 +1061,14 @@ __global__ __launch_bounds__(NB >= 5 ? 256 : 512) void newton_pair_kernel(const 
           // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
           // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
           if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, A.tol)) {
+              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol)) {
             conv = true;
             break;
           }
+          upd_prev2 = upd_prev;
           upd_prev = upd;
         } else {
-          upd_prev = INFINITY;
+          upd_prev = upd_prev2 = INFINITY;
         }
       }
       total_it += conv ? it : A.maxit + 1;
@@ -1406,7 +1408,7 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
       for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
-      double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
+      double upd_prev = INFINITY, upd_prev2 = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
         // lane coordinates made opaque once per iteration: addresses derived from them are recomputed where they are used
@@ -1614,13 +1616,14 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
           // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
           // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
           if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, A.tol)) {
+              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol)) {
             conv = true;
             break;
           }
+          upd_prev2 = upd_prev;
           upd_prev = upd;
         } else {
-          upd_prev = INFINITY;
+          upd_prev = upd_prev2 = INFINITY;
         }
       }
       total_it += conv ? it : A.maxit + 1;
@@ -1702,7 +1705,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
   int64_t b = 0;                  // ... and its current one (valid memory even while the team has no work)
   bool have = false, fresh = false;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
-  double upd_prev = INFINITY;
+  double upd_prev = INFINITY, upd_prev2 = INFINITY;
 #ifdef PNP_SWEEP_STAMPS
   int stamp_code = 0, stamp_cycles = 0;
 #endif
@@ -1737,7 +1740,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
     }
     if (fresh) {
       it = 0;
-      upd_prev = INFINITY;
+      upd_prev = upd_prev2 = INFINITY;
       fresh = false;
     }
     it += 1;
@@ -1877,10 +1880,11 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
       bool accept = false;
       if (lam == 1.0) {
         accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, A.tol);
+              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol);
+        upd_prev2 = upd_prev;
         upd_prev = upd;
       } else {
-        upd_prev = INFINITY;
+        upd_prev = upd_prev2 = INFINITY;
       }
       if (accept || it >= A.maxit) {
         total_it += accept ? it : A.maxit + 1;
@@ -1957,7 +1961,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep2_kernel(const NewtonArgs G
   int64_t b = 0;
   bool have = false, fresh = false;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
-  double upd_prev = INFINITY;
+  double upd_prev = INFINITY, upd_prev2 = INFINITY;
   for (;;) {      // CONTROL FLOW IS WAVE-UNIFORM, see newton_sweep_kernel
     if (!have && real_team && bnext < G.B) {
       b = bnext;
@@ -1988,7 +1992,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep2_kernel(const NewtonArgs G
     }
     if (fresh) {
       it = 0;
-      upd_prev = INFINITY;
+      upd_prev = upd_prev2 = INFINITY;
       fresh = false;
     }
     it += 1;
@@ -2153,10 +2157,11 @@ __global__ __launch_bounds__(64, 2) void newton_sweep2_kernel(const NewtonArgs G
       bool accept = false;
       if (lam == 1.0) {
         accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, A.tol);
+              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol);
+        upd_prev2 = upd_prev;
         upd_prev = upd;
       } else {
-        upd_prev = INFINITY;
+        upd_prev = upd_prev2 = INFINITY;
       }
       if (accept || it >= A.maxit) {
         total_it += accept ? it : A.maxit + 1;
@@ -2204,9 +2209,8 @@ size_t newton_exchange_doubles(int nb, int nx) {   // the row buffer of one work
   return (size_t)(2 * nb * nb + nb) * rs;
 }
 
-bool newton_exchange_in_lds(int nb, int nx) {
-  const char* e = getenv("CATINT_NEWTON_EXCHANGE");        // "global" keeps the row-per-thread kernel's buffers in device memory (tests)
-  if (e && e[0] == 'g') return false;
+bool newton_exchange_in_lds(int nb, int nx, const Options& opt) {
+  if (opt.newton_exchange_global) return false;            // keeps the row-per-thread kernel's buffers in device memory (tests)
   if (nb >= 5) return false;               // large blocks: always device memory (global instead of flat instructions)
   return newton_exchange_doubles(nb, nx) * sizeof(double) <= kLdsBudget;
 }
@@ -2257,8 +2261,8 @@ static hipError_t launch_team(const NewtonArgs& a, int blocks, hipStream_t strea
   // threads per operating point: a small batch cannot fill the chip with 256-thread workgroups (4 resident per CU), so it
   // gets wider ones (shorter passes over the rows, same registers)
   int T = a.B * 4 <= 1024 ? 1024 : (a.B * 2 <= 1024 ? 512 : 256);
-  if (const char* e = getenv("CATINT_NEWTON_TEAM_THREADS")) {
-    const int v = atoi(e);
+  if (a.opt) {
+    const int v = a.opt->newton_team_threads;
     if (v == 256 || v == 512 || v == 1024) T = v;
   }
   size_t lds = (size_t)(T / 64) * (TL::TPW + 1) * TL::SLT * sizeof(double);
@@ -2302,9 +2306,9 @@ static hipError_t launch_sweep2(const NewtonArgs& a, hipStream_t stream) {
 }
 
 // Two teams per operating point instead of one: when the one-sided sweep would leave the SIMDs with fewer than ~3 waves.
-bool newton_sweep_two_sided(int nb, int nx, int64_t B, int mode) {
+bool newton_sweep_two_sided(int nb, int nx, int64_t B, int mode, const Options& opt) {
   if (nb < 6 || nx < 8) return false;
-  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return f[0] == 'b';      // "both ends" (tests, probes)
+  if (opt.newton_kernel != NK_AUTO) return opt.newton_kernel == NK_BOTH;      // "both ends" (tests, probes)
   // with homogeneous reactions (the 4096-lane CO2R sweep: stationary solves along a continuation, 3...30 iterations per lane) the
   // lane-team kernel stays ahead: 0.48 s against 0.52 s (one-sided sweep 0.83 s)
   if (mode >= 2) return false;
@@ -2318,9 +2322,9 @@ bool newton_sweep_two_sided(int nb, int nx, int64_t B, int mode) {
 }
 
 // Large blocks and a batch that fills the chip with teams on its own (measured): the sweep kernel.
-bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode) {
-  if (const char* f = getenv("CATINT_NEWTON_KERNEL")) return (f[0] == 's' && nb >= 3) || (f[0] == 'b' && nb >= 6 && nx >= 8);
-  if (newton_sweep_two_sided(nb, nx, B, mode)) return true;
+bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode, const Options& opt) {
+  if (opt.newton_kernel != NK_AUTO) return (opt.newton_kernel == NK_SWEEP && nb >= 3) || (opt.newton_kernel == NK_BOTH && nb >= 6 && nx >= 8);
+  if (newton_sweep_two_sided(nb, nx, B, mode, opt)) return true;
   // at least one wave of teams per SIMD (1024 SIMDs): below that the chip is not full and, with uniform control flow, a wave
   // waits for its slowest lane -- the CO2R example (7 species, 4096 lanes, iteration counts 3...30) took 0.84 s instead of 0.51 s
   const int64_t waves = (B + 64 / nb - 1) / (64 / nb);
@@ -2332,18 +2336,20 @@ bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode) {
 
 template <int NB, int TMAX>
 static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t stream) {
-  const char* force = getenv("CATINT_NEWTON_KERNEL");     // "generic" forces the row-per-thread kernel (tests)
-  const int tp = (force && force[0] == 'g') ? 0 : newton_pair_threads(NB, a.nx);
+  static const Options kDefaults;
+  const Options& opt = a.opt ? *a.opt : kDefaults;
+  const bool generic = opt.newton_kernel == NK_GENERIC;     // forces the row-per-thread kernel (tests)
+  const int tp = generic ? 0 : newton_pair_threads(NB, a.nx);
   if constexpr (NB >= 3) {
-    if (a.sweep && a.sweep_blocks > 0 && newton_sweep_preferred(NB, a.nx, a.B, a.rt ? 2 : (a.mpb ? 1 : 0))) {
+    if (a.sweep && a.sweep_blocks > 0 && newton_sweep_preferred(NB, a.nx, a.B, a.rt ? 2 : (a.mpb ? 1 : 0), opt)) {
       if constexpr (NB >= 6) {
-        if (newton_sweep_two_sided(NB, a.nx, a.B, a.rt ? 2 : (a.mpb ? 1 : 0))) return launch_sweep2<NB>(a, stream);
+        if (newton_sweep_two_sided(NB, a.nx, a.B, a.rt ? 2 : (a.mpb ? 1 : 0), opt)) return launch_sweep2<NB>(a, stream);
       }
       return launch_sweep<NB>(a, stream);
     }
   }
   if constexpr (NB >= 3) {     // lane teams: every large block, and the N = 2..4 grids too long for the pair kernel
-    if (a.work && !(force && force[0] == 'g') && (NB >= 6 || tp == 0 || (force && force[0] == 't'))) return launch_team<NB>(a, blocks, stream);
+    if (a.work && !generic && (NB >= 6 || tp == 0 || opt.newton_kernel == NK_TEAM)) return launch_team<NB>(a, blocks, stream);
   }
   if constexpr (NB <= 5) {
     if (tp > 0) {
@@ -2379,8 +2385,7 @@ static hipError_t launch_newton_nb(const NewtonArgs& a, int blocks, hipStream_t 
 }
 
 hipError_t launch_newton(const NewtonArgs& a, int blocks, hipStream_t stream) {
-  const char* rg = getenv("CATINT_NEWTON_REGS");
-  const bool regs512 = rg && atoi(rg) == 512;
+  const bool regs512 = a.opt && a.opt->newton_regs == 512;
   switch (a.N + 1) {
     case 2: return launch_newton_nb<2, 512>(a, blocks, stream);
     case 3: return launch_newton_nb<3, 512>(a, blocks, stream);

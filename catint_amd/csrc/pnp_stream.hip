@@ -429,10 +429,7 @@ static hipError_t launch_st_inst(const DevArgs& a, hipStream_t stream) {
     blocks_per_cu = nb;
   }
   int64_t grid = (int64_t)blocks_per_cu * cus;
-  if (const char* e = getenv("CATINT_PNP_ST_WAVES_PER_CU")) {      // tuning / tests: fewer resident waves
-    const int w = atoi(e);
-    if (w >= 1 && w <= blocks_per_cu) grid = (int64_t)w * cus;
-  }
+  if (a.st_waves_per_cu >= 1 && a.st_waves_per_cu <= blocks_per_cu) grid = (int64_t)a.st_waves_per_cu * cus;      // tuning / tests: fewer resident waves
   if (grid > a.B) grid = a.B;
   hipLaunchKernelGGL((step_kernel_st<P, CN, GL>), dim3((unsigned)grid), dim3(64), lds, stream, a);
   return hipGetLastError();

@@ -73,8 +73,9 @@ def gather_observables(local, B, dist=None, device=None):
     """all_gather of the per-lane observable table [B_local, n_obs] -> [B, n_obs] in lane order on every
     rank.  `dist` is torch.distributed (backend nccl = RCCL over xGMI on the GPU box, gloo in CPU tests)."""
     local = np.ascontiguousarray(local, dtype=np.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return local
+    # (a world of ONE rank still runs the collective: that is how a one-GPU box exercises the RCCL leg -- tests/test_gpu_parallel.py)
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     nmax = max(shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world))
@@ -88,3 +89,32 @@ def gather_observables(local, B, dist=None, device=None):
         lo, hi = shard_bounds(B, world, r)
         parts.append(out[r, :hi - lo])
     return np.concatenate(parts, axis=0)
+
+
+def aligned_start(dist, device=None, margin=0.002):
+    """Start a timed region on every rank at the SAME instant instead of at barrier exit: after the barrier the ranks agree on a
+    deadline (all-reduce MAX of `now + margin`; the ranks of one node read one CLOCK_MONOTONIC) and spin until it has passed.
+    Barrier-exit skew (tens of microseconds between ranks) would otherwise count against a region of a hundred microseconds as lost
+    scaling that is not there.  Returns (t_start of this rank, deadline); without a process group: (now, now)."""
+    import time
+    if dist is None or not dist.is_initialized():
+        t = time.perf_counter()
+        return t, t
+    import torch
+    d = torch.tensor([time.perf_counter() + margin], dtype=torch.float64, device=device)
+    dist.all_reduce(d, op=dist.ReduceOp.MAX)
+    deadline = float(d.cpu()[0])
+    while time.perf_counter() < deadline:
+        pass
+    return time.perf_counter(), deadline
+
+
+def gather_numbers(values, dist, device=None):
+    """[world][len(values)] table of every rank's numbers (all_gather); without a process group: one row."""
+    import torch
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if dist is None or not dist.is_initialized():
+        return mine.cpu().numpy()[None, :]
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return np.stack([e.cpu().numpy() for e in every])

@@ -92,6 +92,15 @@ void pnp_destroy(pnp_handle* h);
 const char* pnp_last_error(const pnp_handle* h); /* h may be NULL: last create() error */
 const char* pnp_version(void);
 
+/* Debug / tuning switch of one handle: which kernel family runs, workspace sizes, probes.  key = the name of the environment variable
+ * without its CATINT_ prefix (NEWTON_KERNEL = auto | generic | team | sweep | both | lane | lane2 | lane4, NEWTON_TEAM_THREADS,
+ * NEWTON_REGS, NEWTON_BLOCKS, NEWTON_LANE_GROUPS, NEWTON_SWEEP_BLOCKS, LANE_PIVOT_LIMIT, LANE_ORDER, PNP_KERNEL, PNP_WAVES_PER_GRID,
+ * PNP_SPECIES_PER_WAVE, PNP_STEP_STREAMS, PNP_ALTERNATE_ROWS, PNP_ST_WAVES_PER_CU, PNP_NO_POST_UPLOAD_DISPATCH).  The environment is
+ * read once, in pnp_create, as the defaults of the new handle; the library never reads it afterwards, so handles in one process
+ * are configured independently.  PNP_EINVAL for an unknown key, PNP_ESTATE for an option that sizes a buffer already allocated.
+ * Results do not depend on these switches beyond the documented rounding differences between kernel families. */
+int pnp_set_option(pnp_handle* h, const char* key, const char* value);
+
 /* ---- problem-wide parameters ------------------------------------------------------------ */
 /* D[N] = tp.D (m^2/s, transport.py:423-434); charges[N] = tp.charges = z*F (transport.py:1271). */
 int pnp_set_species(pnp_handle* h, const double* D, const double* charges);
@@ -197,7 +206,12 @@ typedef struct pnp_newton_params {
                               *    error of the state just computed is < tol -- saves the iteration that only confirms convergence */
   double stern_capacitance;  /* F/m^2 */
   double phi_pzc;            /* V */
-  double tol;                /* scaled update max(|dc|/(c + c_bulk), |dphi| beta max|q|) < tol on an undamped step */
+  double tol;                /* scaled update max(|dc|/(c + c_bulk), |dphi| beta max|q|) < tol on an undamped step.  One more exit
+                              *    reports PNP_STATUS_OK: the ROUNDING FLOOR -- three consecutive undamped iterations whose scaled
+                              *    updates are all < 100 tol, neither of the last two below half its predecessor, and not monotonically
+                              *    decreasing: the noise cond(J) eps of an ill-conditioned Jacobian (stiff reactions), which no further
+                              *    iteration improves; the state is then accurate to that noise (<= 100 tol), not to tol.  A linearly
+                              *    converging iteration (monotone) does not qualify: it runs on to tol or to maxit (PNP_STATUS_MAXIT). */
   double dphi_max;           /* potential limiting per iteration (V); <= 0 disables */
 } pnp_newton_params;
 /* mpb_radius[N] (m, nullable = point ions): size-modified drift with phi0 = N_A sum a_k^3 c_k
@@ -205,7 +219,7 @@ typedef struct pnp_newton_params {
 int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_radius);
 /* Constant convection velocity v (m/s, along x) of the physical mode: the Nernst-Planck flux gains + c_i v, the reference's
  * tds.cdm1 "u" = tp.system['flow rate'] (comsol_model.py:901-903, :919; numbers only -- the reference also accepts a COMSOL
- * expression string there).  0 (default): none.  Batches with convection run on the workgroup-per-point and lane-team kernels. */
+ * expression string there).  0 (default): none. */
 int pnp_set_convection(pnp_handle* h, double velocity);
 /* Non-uniform grid of the physical mode: x[nx] strictly increasing, x[0] = electrode, x[nx-1] = bulk boundary (the reference's
  * COMSOL mesh is refined towards the electrode: hmax = L/grid_factor_domain, lambda_D/grid_factor_bound at the boundaries,

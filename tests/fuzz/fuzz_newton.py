@@ -62,9 +62,10 @@ for case in range(ncase):
         # (tolerance 1e-10 against ~1e-10 of noise) -- counted, reported, not a discrepancy
         if not ok and np.abs(np.asarray(its) - np.asarray(rit)).max() <= 1 and dc < 1e-12 and dp < 1e-12 and np.array_equal(st == 0, np.asarray(rit) <= 60):
             ok, tag = True, 'ok~'
-        # the same further from the floor: counts one or two apart (summed over the timesteps of a transient run), states within the
-        # tolerance of the solves -- the last update of some solve sits AT the tolerance
-        elif not ok and np.abs(np.asarray(its) - np.asarray(rit)).max() <= 2 and dc < 1e-8 and dp < 1e-9:
+        # the same further from the floor: counts one or two apart (summed over the timesteps of a transient run) with the states inside
+        # the bound the -m gpu suite itself asserts (tests/test_gpu_newton.py: assert_close, rtol 2e-9; never laxer than the suite) --
+        # the last update of some solve sits AT the tolerance
+        elif not ok and np.abs(np.asarray(its) - np.asarray(rit)).max() <= 2 and dc < 2e-9 and dp < 2e-9 * max(np.abs(rphi).max(), 0.025):
             ok, tag = True, 'ok~'
             near = globals().get('near', 0) + 1
             globals()['near'] = near

@@ -97,6 +97,46 @@ def test_graded_grid(N, nx, kw):
     assert_close(got, ref)
 
 
+# ---- homogeneous reactions and the convection term in the lane kernels (MODE 2 instances; comsol_model.py:781-867, :901-903) ------------
+RX4 = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [2, 2], 'rhs': [3], 'kf': 3e3, 'kr': 0.0},
+       {'lhs': [0, 1], 'rhs': [3], 'kf': 1e3, 'kr': 2e4}, {'lhs': [], 'rhs': [0, 1], 'kf': 2e3, 'kr': 1.5e2}]      # last: H2O <-> A+ + B-
+RX6 = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [0, 2, 2], 'rhs': [4, 5], 'kf': 5.0, 'kr': 1e2}]
+
+
+@pytest.mark.parametrize("N,nx,B,rx,kw", [
+    (4, 120, 37, RX4, {}),
+    (3, 200, 9, [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [0, 2], 'rhs': [1], 'kf': 2e3, 'kr': 1e4}],
+     dict(wall_bc='stern', stern_capacitance=0.2, mpb_radius=[4.1e-10, 3e-10, 0.0], maxit=60)),
+    (6, 64, 35, RX6, {}),
+    (7, 96, 40, RX6 + [{'lhs': [3, 6], 'rhs': [0], 'kf': 2e2, 'kr': 7e3}], dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * 7)),
+    (8, 51, 33, RX6 + [{'lhs': [6], 'rhs': [7], 'kf': 1e6, 'kr': 3e6}], dict(mpb_radius=[3.5e-10] * 8)),
+])
+def test_homogeneous_reactions_match_oracle(N, nx, B, rx, kw):
+    """Mass-action reactions in activities: source and Jacobian (a rank-one update of the species block per reaction side) in the lane's
+    block row; LU without row exchanges under the pivot monitor.  Stationary from a bulk out of equilibrium, and transient steps."""
+    got, ref = run_both(N, nx, B=B, seed=31 + N, reactions=rx, newton_kw=kw, points_per_debye=2.0 if N == 4 else 6.0,
+                        **(dict(phi_lo=-1.0, phi_hi=0.8, cref=100.0) if N == 3 else {}))
+    assert_close(got, ref)
+    got, ref = run_both(N, nx, B=B, seed=41 + N, reactions=rx, newton_kw=kw, dt=1e-7, nsteps=3, stationary=False)
+    assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx,B,kw,graded", [(3, 128, 37, {}, False), (6, 96, 34, dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * 6), True),
+                                              (8, 64, 70, dict(mpb_radius=[3.5e-10] * 8), False)])
+def test_convection_velocity_matches_oracle(N, nx, B, kw, graded):
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 21)
+    x = np.cumsum(np.concatenate([[0.0], np.geomspace(0.4, 2.5, nx - 1)])) if graded else None
+    Lx = (x[-1] if graded else nx - 1) * dx
+    for v in (3.0 * D.max() / Lx, -2.0 * D.max() / Lx):
+        got, ref = run_both(N, nx, B=B, seed=21, newton_kw=kw, x=x, velocity=v)
+        assert_close(got, ref)
+    base, _ = run_both(N, nx, B=B, seed=21, newton_kw=kw, x=x)
+    assert np.abs(got[0] - base[0]).max() > 1e-3 * np.abs(base[0]).max()           # the term is not a no-op
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    got, ref = run_both(N, nx, B=B, seed=22, newton_kw=kw, x=x, velocity=3.0 * D.max() / Lx, dt=dt, nsteps=3, stationary=False, reactions=RX6 if N >= 6 else None)
+    assert_close(got, ref)
+
+
 @pytest.mark.parametrize("N,nx", [(3, 512), (6, 96), (8, 40)])
 def test_bitwise_reproducible(N, nx):
     a = run_gpu_only(N, nx, 70, 99)

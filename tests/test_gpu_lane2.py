@@ -37,6 +37,36 @@ def test_transient_steric(N):
     assert_close(got, ref)
 
 
+RX6 = [{'lhs': [1], 'rhs': [2], 'kf': 4e5, 'kr': 9e5}, {'lhs': [0, 2, 2], 'rhs': [4, 5], 'kf': 5.0, 'kr': 1e2}]
+
+
+@pytest.mark.parametrize("N,nx,B,rx,kw", [
+    (5, 70, 21, RX6[:1] + [{'lhs': [0, 2], 'rhs': [4], 'kf': 2e3, 'kr': 1e4}, {'lhs': [], 'rhs': [0, 1], 'kf': 2e3, 'kr': 1.5e2}], {}),
+    (6, 64, 35, RX6, {}),
+    (7, 96, 40, RX6 + [{'lhs': [3, 6], 'rhs': [0], 'kf': 2e2, 'kr': 7e3}], dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * 7)),
+    (8, 51, 33, RX6 + [{'lhs': [6], 'rhs': [7], 'kf': 1e6, 'kr': 3e6}], dict(mpb_radius=[3.5e-10] * 8)),
+])
+def test_homogeneous_reactions_match_oracle(N, nx, B, rx, kw):
+    """MODE 2 instances of the lane-pair kernel (see tests/test_gpu_lane.py): reactions, stationary and transient."""
+    got, ref = run_both(N, nx, B=B, seed=31 + N, reactions=rx, newton_kw=kw)
+    assert_close(got, ref)
+    got, ref = run_both(N, nx, B=B, seed=41 + N, reactions=rx, newton_kw=kw, dt=1e-7, nsteps=3, stationary=False)
+    assert_close(got, ref)
+
+
+@pytest.mark.parametrize("N,nx,B,kw", [(6, 96, 34, dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * 6)), (7, 80, 19, {})])
+def test_convection_velocity_matches_oracle(N, nx, B, kw):
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 21)
+    x = np.cumsum(np.concatenate([[0.0], np.geomspace(0.4, 2.5, nx - 1)]))
+    Lx = x[-1] * dx
+    for v in (3.0 * D.max() / Lx, -2.0 * D.max() / Lx):
+        got, ref = run_both(N, nx, B=B, seed=21, newton_kw=kw, x=x, velocity=v)
+        assert_close(got, ref)
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    got, ref = run_both(N, nx, B=B, seed=22, newton_kw=kw, x=x, velocity=3.0 * D.max() / Lx, dt=dt, nsteps=3, stationary=False, reactions=RX6)
+    assert_close(got, ref)
+
+
 def test_wall_fluxes_and_point_ions_transient():
     rng = np.random.default_rng(5)
     B, N = 20, 6

@@ -536,8 +536,10 @@ def test_fuzz_case_117_stops_at_the_rounding_floor(kernel, monkeypatch):
                         points_per_debye=d['points_per_debye'])
     c, phi, its, st = got
     rc, rphi, rit = ref
-    assert (st == 0).all() and rit[0] == 20
-    assert abs(int(its[0]) - int(rit[0])) <= 1, (its, rit)
+    # (round 4: the exit asks for a non-monotone triple of full steps inside the window -- one iteration later than the two-step rule of
+    # round 3, and never for a linearly converging lane.  The floor is noise: the solvers see different triples, within two iterations)
+    assert (st == 0).all() and rit[0] == 21
+    assert abs(int(its[0]) - int(rit[0])) <= 2, (its, rit)
     assert np.abs(c - rc).max() <= 1e-8 * np.abs(rc).max() and np.abs(phi - rphi).max() <= 1e-9
 
 
@@ -550,12 +552,12 @@ def test_fuzz_case_117_stops_at_the_rounding_floor(kernel, monkeypatch):
     (6, 96, 9, 'sweep', dict(mpb_radius=[3.5e-10] * 6), False),                                         # one-sided sweep
     (7, 80, 9, 'both', {}, False),                                                                      # two-sided sweep
     (3, 130, 4, 'generic', {}, False),                                                                  # row-per-thread kernel
-    (8, 64, 70, 'lane', dict(mpb_radius=[3.5e-10] * 8), False),                                         # lane kernel asked for: refused for convection
+    (8, 64, 70, 'team', dict(mpb_radius=[3.5e-10] * 8), False),                                         # lane teams at a batch the lane kernels would take
 ])
 def test_convection_velocity_matches_oracle(N, nx, B, kernel, kw, graded, monkeypatch):
     """+ c v in every Nernst-Planck flux: the drift argument of an edge loses v h_e / D_k.  Velocities of both signs, of the order of
-    D / L so that the profiles change visibly; stationary and transient; every kernel family that carries the
-    term (a batch the lane kernels would take runs on the lane teams instead)."""
+    D / L so that the profiles change visibly; stationary and transient; every workgroup-per-point / lane-team kernel family (the lane
+    kernels: tests/test_gpu_lane.py, tests/test_gpu_lane2.py)."""
     # (velocities of D / L: the profiles change by e^3 across the cell -- a velocity of D / dx would pile up e^(nx) at one end)
     if kernel:
         monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)

@@ -60,6 +60,34 @@ def free_port():
     return p
 
 
+def test_one_rank_rccl_gathers_on_a_device_tensor():
+    """The RCCL leg itself on the one GPU of the test box: backend 'nccl' with a world of ONE rank, started as a fresh process --
+    init_process_group with a device id, gather_observables -> all_gather_into_tensor on a DEVICE fp64 tensor (the helper runs the
+    collective for a single rank too), barrier, destroy_process_group.  What bench.py --gpus N does on every rank
+    (reference: the MPI task farm catint/calculator.py:209-212 and its gather catint/catint_io.py:167-178)."""
+    procs, outs = run_world(48, 'nccl', world=1)
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and 'ok' in o, e[-2000:]
+
+
+def test_bench_two_ranks_print_one_json_line_with_the_8_gpu_shares():
+    """`bench.py --gpus 2` as its own launcher (two gloo ranks on the one GPU; RCCL refuses two ranks on a device): stdout is exactly
+    one JSON line, it carries n_gpus = 2, the start skew of the aligned timed region and one GPU's share of configs[3] / configs[4]
+    per rank (here on 1/16 of the batch)."""
+    import json
+    env = dict(os.environ, CATINT_DIST_BACKEND='gloo', CATINT_BENCH_SHARE_DIV='16', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-pmc',
+                          '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout)                       # the WHOLE of stdout is one JSON document
+    assert d['n_gpus'] == 2 and len(d['per_rank_timesteps_per_s']) == 2 and d['start_skew_us'] >= 0.0
+    for key in ('configs3_share', 'configs4_share'):
+        for leg in ('compat_per_step', 'newton'):
+            r = d[key][leg]
+            assert 'error' not in r, r
+            assert r['lanes_ok'] == r['lanes_total'] and len(r['per_rank_timesteps_per_s']) == 2 and r['value'] > 0
+
+
 def run_world(B, backend, world=2):
     port = free_port()
     procs = []

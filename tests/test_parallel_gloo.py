@@ -54,6 +54,37 @@ def run_world(B, world=2):
     return [o for o, _ in outs]
 
 
+ALIGN_WORKER = r'''
+import os, sys, time
+import torch.distributed as dist
+sys.path.insert(0, %r)
+from catint_amd.parallel import aligned_start, gather_numbers
+dist.init_process_group('gloo')
+rank = dist.get_rank()
+time.sleep(0.05 * rank)                    # the ranks arrive at different times ...
+dist.barrier()
+t0, deadline = aligned_start(dist)         # ... and leave together
+assert t0 >= deadline
+tab = gather_numbers([t0, rank], dist)
+assert tab.shape == (2, 2) and list(tab[:, 1]) == [0.0, 1.0]
+assert tab[:, 0].max() - tab[:, 0].min() < 0.05, tab
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+''' % ROOT
+
+
+def test_aligned_start_of_a_timed_region():
+    """bench.py's timed regions start on a deadline all ranks agree on (same node, same monotonic clock), not on barrier exit."""
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, '-c', ALIGN_WORKER], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                                       MASTER_PORT=str(port))) for r in range(2)]
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0 and 'ok' in o, e[-2000:]
+
+
 def test_shard_bounds_cover_batch():
     for B in (1, 2, 7, 1024, 1025):
         for world in (1, 2, 3, 8):
