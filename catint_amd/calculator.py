@@ -167,7 +167,9 @@ class Calculator(object):
                 wanted = [int(n) for n in itout if n < nt]
                 out = [n - shift for n in wanted if n - shift >= 0]
                 opts = {k: v for k, v in getattr(self, 'ode_options', {}).items() if k in ('rtol', 'atol', 'nsteps', 'max_step', 'check_every')}
-                cdev, idid, self.ode_stats, _ = s.integrate_rkc(nt, out, **opts)
+                # (intervals up to the last requested state only: odeint over tmesh covers nt - 1 of them, and a failure in an interval
+                # nobody asked for must not flag the lane)
+                cdev, idid, self.ode_stats, _ = s.integrate_rkc(max(out) + 1 if out else 1, out, **opts)
                 cout = np.zeros((len(wanted), B, c0.shape[1]))
                 for j, n in enumerate(wanted):
                     cout[j] = c0 if n - shift < 0 else cdev[out.index(n - shift)]

@@ -1457,6 +1457,8 @@ int pnp_integrate_rkc(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const 
   if (!h->ode_buf) {
     HIP_TRY(h, dev_alloc(h, &h->ode_buf, (size_t)nbuf * cnt + (size_t)cap * ODE_ND));
     h->ode_nbuf = nbuf;
+    // the whole workspace once (a later pnp_integrate_dopri5 on this handle finds it allocated and relies on zero row pads everywhere)
+    HIP_TRY(h, hipMemsetAsync(h->ode_buf, 0, ((size_t)nbuf * cnt + (size_t)cap * ODE_ND) * sizeof(double), st));
   }
   HIP_TRY(h, hipMemsetAsync(h->ode_buf, 0, (size_t)5 * cnt * sizeof(double), st));   // pads of the rows stay zero
   if (!h->rkc_d) HIP_TRY(h, dev_alloc(h, &h->rkc_d, (size_t)cap * RKC_ND));
@@ -1497,6 +1499,7 @@ int pnp_integrate_rkc(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const 
   const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
   int next_out = 0;
   int64_t tick = 0;
+  bool budget_exhausted = false;
   for (int n = 0; n < nt; ++n) {
     a.interval = n;
     HIP_TRY(h, launch_rkc_begin(a, st));
@@ -1518,6 +1521,10 @@ int pnp_integrate_rkc(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const 
       HIP_TRY(h, hipMemcpyAsync(&left, a.counters + a.slot, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(h, hipStreamSynchronize(st));
     }
+    if (left != 0) {        // the tick budget ran out with lanes still inside the interval: they are reported as -2 below, nothing is output
+      budget_exhausted = true;
+      break;
+    }
     if (next_out < n_out && itout[next_out] == n) {
       HIP_TRY(h, hipMemcpy2DAsync(cout + (size_t)next_out * B * N * nx, w, a.y, dp, w, (size_t)B * N, hipMemcpyDeviceToHost, st));
       ++next_out;
@@ -1533,7 +1540,7 @@ int pnp_integrate_rkc(pnp_handle* h, const pnp_ode_params* p, int32_t nt, const 
   HIP_TRY(h, hipStreamSynchronize(st));
   for (int64_t b = 0; b < B; ++b) {
     const int32_t* s = ih.data() + b * RKC_NI;
-    if (idid) idid[b] = s[RKI_IDID];
+    if (idid) idid[b] = (budget_exhausted && s[RKI_ACTIVE] != 0) ? -2 : s[RKI_IDID];
     if (t_end) t_end[b] = dh[b * RKC_ND + RKC_T];
     if (stats) {
       stats[b * 7 + 0] = s[RKI_TOT_NSTEP];
