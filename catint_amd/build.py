@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, 'lib')
 LIB = os.path.join(LIB_DIR, 'libcatint_pnp.so')
-SOURCES = ['pnp_kernels.hip', 'pnp_stream.hip', 'pnp_newton.hip', 'pnp_lane.hip', 'pnp_lane2.hip', 'pnp_scf.hip', 'pnp_ode.hip', 'pnp_rkc.hip', 'pnp_capi.hip']
+SOURCES = ['pnp_kernels.hip', 'pnp_stream.hip', 'pnp_newton.hip', 'pnp_lane.hip', 'pnp_lane2.hip', 'pnp_lane4.hip', 'pnp_scf.hip', 'pnp_ode.hip', 'pnp_rkc.hip', 'pnp_capi.hip']
 HEADERS = [os.path.join(CSRC, 'pnp_internal.h'), os.path.join(CSRC, 'pnp_lane_common.h'), os.path.join(CSRC, 'pnp_wave.h'), os.path.join(CSRC, 'pnp_step_table.h'), os.path.join(CSRC, 'pnp_math.h'), os.path.join(CSRC, 'pnp_dop853_coeffs.h'), os.path.join(_HERE, '..', 'include', 'catint_pnp.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-unused-function']

@@ -50,6 +50,8 @@ struct pnp_handle {
   double* work = nullptr;
   double* stash = nullptr;
   ReactionTable* rt_dev = nullptr;
+  ReactionSides* rs_dev = nullptr;          // the table flattened per reaction side (lane kernels)
+  int rs_max_exponent = 0;
   int n_wk = 0;
   int32_t wk_species[PNP_MAX_WALL_REACTIONS] = {0};
   double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES] = {{0}};
@@ -69,6 +71,8 @@ struct pnp_handle {
   int64_t lane_groups = 0;
   double* lane2_buf = nullptr;           // lane-pair kernel: the same for groups of 16
   int64_t lane2_groups = 0;
+  double* lane4_buf = nullptr;           // lane-quad kernel: the same for groups of 8
+  int64_t lane4_groups = 0;
   // lane kernels: which operating point a slot (group, lane) holds -- points ordered by expected Newton iterations, see lane_order
   int32_t* lane_perm = nullptr;          // device [capacity]
   std::vector<float> lane_key;           // |phiM - phi_bulk| per operating point (pnp_set_batch / pnp_set_pb): the order of a first call
@@ -178,7 +182,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->lane2_buf, (void*)h->lane_perm, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int, (void*)h->rkc_d, (void*)h->rkc_i})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->rs_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->lane2_buf, (void*)h->lane4_buf, (void*)h->lane_perm, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int, (void*)h->rkc_d, (void*)h->rkc_i})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -343,7 +347,7 @@ int pnp_set_option(pnp_handle* h, const char* key, const char* value) {
   if (o.newton_exchange_global != h->opt.newton_exchange_global)
     return fail(h, PNP_ESTATE, "pnp_set_option: NEWTON_EXCHANGE sizes the buffers of pnp_create; set CATINT_NEWTON_EXCHANGE before creating the handle");
   // workspaces sized by an option are allocated on first use: an option set afterwards must not outgrow them
-  if ((h->lane_buf || h->lane2_buf) && o.newton_lane_groups != h->opt.newton_lane_groups)
+  if ((h->lane_buf || h->lane2_buf || h->lane4_buf) && o.newton_lane_groups != h->opt.newton_lane_groups)
     return fail(h, PNP_ESTATE, "pnp_set_option: NEWTON_LANE_GROUPS after the lane workspace was allocated");
   if (h->sweep && o.newton_sweep_blocks != h->opt.newton_sweep_blocks)
     return fail(h, PNP_ESTATE, "pnp_set_option: NEWTON_SWEEP_BLOCKS after the sweep workspace was allocated");
@@ -426,6 +430,39 @@ int pnp_set_reactions(pnp_handle* h, int32_t nreactions, const int32_t* n_lhs, c
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (!h->rt_dev) HIP_TRY(h, dev_alloc(h, &h->rt_dev, 1));
     HIP_TRY(h, hipMemcpyAsync(h->rt_dev, &rt, sizeof(rt), hipMemcpyHostToDevice, h->stream));
+    // the same table per reaction side, for the lane kernels (see ReactionSides)
+    static ReactionSides rs;      // (host staging; copied before this call returns)
+    memset(&rs, 0, sizeof(rs));
+    const int N = h->a.N;
+    for (int r = 0; r < nreactions; ++r) {
+      for (int sd = 0; sd < 2; ++sd) {
+        const double kk = sd == 0 ? rt.kf[r] : rt.kr[r];
+        if (kk == 0.0) continue;
+        ReactionSides::Side& S = rs.side[rs.n++];
+        S.k = kk;
+        const int n = sd == 0 ? rt.n_lhs[r] : rt.n_rhs[r];
+        const int32_t* idx = sd == 0 ? rt.lhs[r] : rt.rhs[r];
+        S.order = n;
+        int cnt[PNP_MAX_SPECIES] = {0};
+        for (int a = 0; a < n; ++a) cnt[idx[a]] += 1;
+        for (int k = 0; k < N && k < PNP_NEWTON_MAX_SPECIES; ++k)
+          if (cnt[k] > rs.max_exponent) rs.max_exponent = cnt[k];
+        for (int a = 0; a < PNP_MAX_REACTANTS; ++a) {
+          const uint32_t row = a < n ? (uint32_t)idx[a] : 8u, col = a < n ? (uint32_t)idx[a] : 15u;
+          S.slots |= (row << (4 * a)) | (col << (16 + 4 * a));
+        }
+        const double sg = sd == 0 ? 1.0 : -1.0;                    // forward minus backward
+        for (int a = 0; a < rt.n_lhs[r]; ++a) S.w[rt.lhs[r][a]] -= sg;   // educts lose
+        for (int a = 0; a < rt.n_rhs[r]; ++a) S.w[rt.rhs[r][a]] += sg;   // products gain
+      }
+    }
+    if (rs.n & 1) {       // the kernels walk the sides two at a time (independent dependency chains): pad with a side without a rate
+      ReactionSides::Side& S = rs.side[rs.n++];
+      for (int a = 0; a < PNP_MAX_REACTANTS; ++a) S.slots |= (8u << (4 * a)) | (15u << (16 + 4 * a));
+    }
+    h->rs_max_exponent = rs.max_exponent;
+    if (!h->rs_dev) HIP_TRY(h, dev_alloc(h, &h->rs_dev, 1));
+    HIP_TRY(h, hipMemcpyAsync(h->rs_dev, &rs, sizeof(rs), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return PNP_OK;
   }
@@ -717,14 +754,35 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.convect = h->velocity != 0.0 ? 1 : 0;
   a.vt_inv = beta * qmax;
   a.rt = (h->rt_dev && h->rt.n > 0) ? h->rt_dev : nullptr;
+  a.sides = a.rt ? h->rs_dev : nullptr;
   a.n_wk = h->newton_explicit_kinetics ? 0 : h->n_wk;
   a.lane_mask = h->newton_mask;
   // (kernel variants: 0 point ions, 1 steric ions, 2 + homogeneous reactions and / or the constant convection term)
-  const int variant = (a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0);
+  // (variant 3 is supported by none of the lane kernels: a guard for tables their flattened form could not hold -- none at present,
+  // a side has at most PNP_MAX_REACTANTS reactants and the form keeps them one by one)
+  const int variant = (a.rt && h->rs_max_exponent > PNP_MAX_REACTANTS) ? 3 : ((a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0));
   a.opt = &h->opt;
-  const bool use_lane2 = newton_lane2_preferred(N + 1, nx, h->B, variant, h->opt);
-  const bool use_lane = !use_lane2 && newton_lane_preferred(N + 1, nx, h->B, variant, h->opt);
-  if (use_lane2) {
+  const bool use_lane4 = newton_lane4_preferred(N + 1, nx, h->B, variant, h->opt);
+  const bool use_lane2 = !use_lane4 && newton_lane2_preferred(N + 1, nx, h->B, variant, h->opt);
+  const bool use_lane = !use_lane4 && !use_lane2 && newton_lane_preferred(N + 1, nx, h->B, variant, h->opt);
+  if (use_lane4) {
+    const size_t per_group = (newton_lane4_rec_doubles(N + 1, nx) + newton_lane4_state_doubles(N + 1, nx)) * sizeof(double);
+    if (!h->lane4_buf) {
+      int64_t groups = (h->cfg.batch_capacity + 7) / 8;
+      const int64_t fit = (int64_t)(((size_t)48 << 30) / per_group);
+      if (groups > fit) groups = fit;
+      if (h->opt.newton_lane_groups >= 1 && h->opt.newton_lane_groups < groups) groups = h->opt.newton_lane_groups;
+      if (groups < 1) groups = 1;
+      HIP_TRY(h, dev_alloc(h, &h->lane4_buf, (size_t)groups * per_group / sizeof(double)));
+      h->lane4_groups = groups;
+    }
+    const size_t vp2 = (size_t)((N + 2) / 2 * 2), cp2 = (size_t)((N + 1) / 2 * 2);
+    a.lane_groups = h->lane4_groups;
+    a.lane_ts = h->lane4_buf;
+    a.lane_xs = a.lane_ts + (size_t)h->lane4_groups * vp2 * nx * 8;
+    a.lane_tco = a.lane_xs + (size_t)h->lane4_groups * vp2 * nx * 8;
+    a.lane_rec = a.lane_tco + (size_t)h->lane4_groups * cp2 * nx * 8;
+  } else if (use_lane2) {
     const size_t per_group = (newton_lane2_rec_doubles(N + 1, nx) + newton_lane2_state_doubles(N + 1, nx)) * sizeof(double);
     if (!h->lane2_buf) {
       int64_t groups = (h->cfg.batch_capacity + 15) / 16;
@@ -799,11 +857,12 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   int blocks = h->nw_blocks;
   if (h->opt.newton_blocks >= 1 && h->opt.newton_blocks < blocks) blocks = h->opt.newton_blocks;      // tuning: size of the persistent grid
   if ((int64_t)blocks > h->B) blocks = (int)h->B;
-  if (use_lane2 || use_lane) {
+  if (use_lane4 || use_lane2 || use_lane) {
     const int rc = lane_order(h, a);
     if (rc != PNP_OK) return rc;
   }
-  if (use_lane2) HIP_TRY(h, launch_newton_lane2(a, h->stream));
+  if (use_lane4) HIP_TRY(h, launch_newton_lane4(a, h->stream));
+  else if (use_lane2) HIP_TRY(h, launch_newton_lane2(a, h->stream));
   else if (use_lane) HIP_TRY(h, launch_newton_lane(a, h->stream));
   else HIP_TRY(h, launch_newton(a, blocks, h->stream));
   h->steps_done += nsteps;

@@ -94,6 +94,25 @@ struct ReactionTable {
   double kr[PNP_MAX_REACTIONS];
 };
 
+// The same table flattened for the lane kernels (pnp_lane*.hip): one entry per reaction SIDE that carries a rate, with everything the
+// assembly needs as plain numbers -- no index lists, no trip counts, nothing to branch on.  Side s contributes
+//   rate_s = k_s gam^order_s prod_a c_(i_a)           (a = 0 .. 3: the reactants of that side, repeats allowed; `slots` holds for each a
+//                                                      the row of the kernel's per-row value table in bits 4a .. 4a+3 -- the species,
+//                                                      or 8 = the constant one for an unused slot -- and the species column the
+//                                                      derivative goes to in bits 16+4a .. 16+4a+3, 15 = none)
+// to R_k with the weight w_s[k] = +-(occurrences of k among the products - occurrences among the educts), the sign taking care of
+// "forward minus backward".  Built on the host by pnp_set_reactions, copied into LDS once per kernel.
+struct ReactionSides {
+  int32_t n;                  // sides (even: padded with a side without a rate)
+  int32_t max_exponent;       // largest multiplicity of one species on one side (the lane kernels evaluate up to 2)
+  struct Side {
+    double k;
+    double w[PNP_NEWTON_MAX_SPECIES];
+    int32_t order;            // reactants on this side (power of the activity coefficient)
+    uint32_t slots;
+  } side[2 * PNP_MAX_REACTIONS];
+};
+
 // points-per-lane template instance that covers nx (interior m = nx-2 <= 64*P*waves_per_system); 0 if unsupported
 int points_per_lane(int nx);
 // waves cooperating on one tridiagonal system: 1 up to nx = 1026, 2 up to 2050, 4 up to 4098
@@ -151,6 +170,7 @@ struct NewtonArgs {
   double pe[PNP_NEWTON_MAX_SPECIES];     // v dx/D_k    (constant convection velocity v, pnp_set_convection; 0 without)
   int32_t convect, pad4_;                // v != 0
   const struct ReactionTable* rt;        // device copy of the mass-action table, or null
+  const struct ReactionSides* sides;     // device copy of the flattened table (lane kernels), or null
   int32_t n_wk;                          // first-order surface reactions (pnp_set_wall_kinetics)
   int32_t wk_species[PNP_MAX_WALL_REACTIONS];                     // species whose surface concentration enters, -1: zeroth order
   double wk_nu[PNP_MAX_WALL_REACTIONS][PNP_NEWTON_MAX_SPECIES];   // stoichiometry of the flux INTO the domain
@@ -212,6 +232,12 @@ bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode, const Options& 
 size_t newton_lane2_rec_doubles(int nb, int nx);      // per group of 16 operating points
 size_t newton_lane2_state_doubles(int nb, int nx);
 hipError_t launch_newton_lane2(const NewtonArgs& a, hipStream_t stream);
+// lane-quad kernel (pnp_lane4.hip): eight lanes per operating point (two directions x four column lanes of the block row), N >= 5
+bool newton_lane4_supported(int nb, int nx, int mode);
+bool newton_lane4_preferred(int nb, int nx, int64_t B, int mode, const Options& opt);
+size_t newton_lane4_rec_doubles(int nb, int nx);      // per group of 8 operating points
+size_t newton_lane4_state_doubles(int nb, int nx);
+hipError_t launch_newton_lane4(const NewtonArgs& a, hipStream_t stream);
 
 // ---- kinetics <-> transport SCF loop on the device (pnp_scf.hip; Calculator.run_scf_cycle, calculator.py:294-406) ----
 struct ScfArgs {

@@ -146,6 +146,10 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   // vector-register lanes (600 v_readlane / v_writelane per row).  The two arrays of the inner loops (q_k beta, ion volumes) stay
   // scalar; those used once per row come from LDS (broadcast reads issued early in the row)
   __shared__ LaneParams sP;
+  // MODE 2 only (no LDS in the other instances): the flattened mass-action table and the per-row values its slots point into
+  __shared__ double s_react[FULL ? sizeof(ReactionSides) / sizeof(double) + RC_ROWS * 64 : 1];
+  ReactionSides& sS = *(ReactionSides*)s_react;
+  double (*s_rc)[64] = (double (*)[64])(s_react + sizeof(ReactionSides) / sizeof(double));
   const int lane = threadIdx.x, o = lane & 31;
   const bool side = lane >= 32;              // false: from the wall upwards; true: from the bulk downwards
   const double sgn = side ? -1.0 : 1.0;
@@ -176,6 +180,10 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     sP.peq[lane] = G.peq[lane];
     sP.pe[lane] = G.pe[lane];
     sP.rs[lane] = G.rs[lane];
+  }
+  if constexpr (FULL) {
+    lane_stage_reaction_sides(sS, G.sides, lane);
+    lane_reaction_init(s_rc, lane);
   }
   __syncthreads();
   // row visited by the lane in forward step s (clamped to a valid row where the lane rests)
@@ -463,21 +471,30 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         // ---- homogeneous reactions (fill_row in pnp_newton.hip): source -(dx^2/D_k) v_i R_k and its Jacobian, a rank-one update of
         // the species block per reaction side; the stoichiometric weights are table data, so the row tests are scalar branches ------
         if constexpr (FULL) {
-          if (A.rt) {
-            const ReactionTable* rt = A.rt;
-            const int nr = rt->n;
-            for (int r = 0; r < nr; ++r) {
-              for (int sd = 0; sd < 2; ++sd) {
-                double prod, dprod[N], sw[N];
-                if (!lane_reaction_side<N, MPB>(rt, r, sd, hc, hinv, G.vol, prod, dprod, sw)) continue;
+          const int ns = __builtin_amdgcn_readfirstlane(sS.n);
+          if (ns > 0) {
+            double vrs[N];
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                  if (sw[k] == 0.0) continue;
-                  const double wr = sw[k] * (vi * P->rs[k]);
-                  rhs[k] = __builtin_fma(wr, prod, rhs[k]);
+            for (int k = 0; k < N; ++k) vrs[k] = vi * P->rs[k];
+            lane_reaction_fill<N>(s_rc, lane, hc, hinv);
+            // (two sides per pass: their LDS round trips -- table entry, then the values it points at -- overlap)
+            for (int sd = 0; sd < ns; sd += 2) {
+              const ReactionSides::Side& Sa = sS.side[sd];
+              const ReactionSides::Side& Sb = sS.side[sd + 1];
+              const LaneSide ra = lane_reaction_side<MPB>(Sa, s_rc, lane);
+              const LaneSide rb = lane_reaction_side<MPB>(Sb, s_rc, lane);
+              double da[N], db[N];
 #pragma unroll
-                  for (int j = 0; j < N; ++j) D[k][j] = __builtin_fma(-wr, dprod[j], D[k][j]);
-                }
+              for (int j = 0; j < N; ++j) {
+                da[j] = lane_side_dprod(ra, j, MPB ? G.vol[j] : 0.0);
+                db[j] = lane_side_dprod(rb, j, MPB ? G.vol[j] : 0.0);
+              }
+#pragma unroll
+              for (int k = 0; k < N; ++k) {
+                const double wa = Sa.w[k] * vrs[k], wb = Sb.w[k] * vrs[k];
+                rhs[k] = __builtin_fma(wb, rb.prod, __builtin_fma(wa, ra.prod, rhs[k]));
+#pragma unroll
+                for (int j = 0; j < N; ++j) D[k][j] = __builtin_fma(-wb, db[j], __builtin_fma(-wa, da[j], D[k][j]));
               }
             }
           }

@@ -66,6 +66,10 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
   constexpr bool FULL = MODE == 2;           // + homogeneous reactions and a constant convection velocity (see pnp_lane.hip)
   __shared__ double s_cb[N][OG];
   __shared__ LaneParams sP;
+  // MODE 2 only (no LDS in the other instances): the flattened mass-action table and the per-row values its slots point into
+  __shared__ double s_react[FULL ? sizeof(ReactionSides) / sizeof(double) + RC_ROWS * 64 : 1];
+  ReactionSides& sS = *(ReactionSides*)s_react;
+  double (*s_rc)[64] = (double (*)[64])(s_react + sizeof(ReactionSides) / sizeof(double));
   const int lane = threadIdx.x, o = lane >> 2;
   const int h = lane & 1;                     // half of the block row: owns the columns j with j & 1 == h
   const bool side = (lane & 2) != 0;          // false: from the wall upwards; true: from the bulk downwards
@@ -96,6 +100,10 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
     sP.peq[lane] = G.peq[lane];
     sP.pe[lane] = G.pe[lane];
     sP.rs[lane] = G.rs[lane];
+  }
+  if constexpr (FULL) {
+    lane_stage_reaction_sides(sS, G.sides, lane);
+    lane_reaction_init(s_rc, lane);
   }
   __syncthreads();
   auto fwd_row = [&](int s) { return side ? (s < n_dn ? nx - 2 - s : m + 1) : (s < m ? s : m); };
@@ -393,27 +401,34 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
         }
         // ---- homogeneous reactions (see pnp_lane.hip): every lane evaluates the rates, each half keeps its own columns -----------------------
         if constexpr (FULL) {
-          if (A.rt) {
-            const ReactionTable* rt = A.rt;
-            const int nr = rt->n;
-            for (int r = 0; r < nr; ++r) {
-              for (int sd = 0; sd < 2; ++sd) {
-                double prod, dprod[N], sw[N];
-                if (!lane_reaction_side<N, MPB>(rt, r, sd, hc, hinv, G.vol, prod, dprod, sw)) continue;
-                double dl[CL];           // d prod / d c_j of this lane's columns
+          const int ns = __builtin_amdgcn_readfirstlane(sS.n);
+          if (ns > 0) {
+            double vrs[N];
 #pragma unroll
-                for (int jj = 0; jj < CL; ++jj)
-                  dl[jj] = (2 * jj + 1 < N) ? (h ? dprod[2 * jj + 1 < N ? 2 * jj + 1 : 0] : dprod[2 * jj < N ? 2 * jj : 0])
-                                            : ((2 * jj < N && !h) ? dprod[2 * jj < N ? 2 * jj : 0] : 0.0);
+            for (int k = 0; k < N; ++k) vrs[k] = vi * P->rs[k];
+            lane_reaction_fill<N>(s_rc, lane, hc, hinv);
+            // (two sides per pass: their LDS round trips -- table entry, then the values it points at -- overlap)
+            for (int sd = 0; sd < ns; sd += 2) {
+              const ReactionSides::Side& Sa = sS.side[sd];
+              const ReactionSides::Side& Sb = sS.side[sd + 1];
+              const LaneSide ra = lane_reaction_side<MPB>(Sa, s_rc, lane);
+              const LaneSide rb = lane_reaction_side<MPB>(Sb, s_rc, lane);
+              double dla[CL], dlb[CL];           // d prod / d c_j of this lane's columns
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                  if (sw[k] == 0.0) continue;
-                  const double wr = sw[k] * (vi * P->rs[k]);
+              for (int jj = 0; jj < CL; ++jj) {
+                double volj = 0.0;
+                if constexpr (MPB) volj = (2 * jj + 1 < N) ? (h ? G.vol[2 * jj + 1 < N ? 2 * jj + 1 : 0] : G.vol[2 * jj < N ? 2 * jj : 0])
+                                                           : ((2 * jj < N && !h) ? G.vol[2 * jj < N ? 2 * jj : 0] : 0.0);
+                dla[jj] = col_j(jj) < N ? lane_side_dprod(ra, col_j(jj), volj) : 0.0;
+                dlb[jj] = col_j(jj) < N ? lane_side_dprod(rb, col_j(jj), volj) : 0.0;
+              }
 #pragma unroll
-                  for (int jj = 0; jj < CL; ++jj) {
-                    if (jj < CLD) Dl[k][jj < CLD ? jj : 0] = __builtin_fma(-wr, dl[jj], Dl[k][jj < CLD ? jj : 0]);
-                    if (col_j(jj) == NB) Xl[k][jj] = __builtin_fma(wr, prod, Xl[k][jj]);
-                  }
+              for (int k = 0; k < N; ++k) {
+                const double wa = Sa.w[k] * vrs[k], wb = Sb.w[k] * vrs[k];
+#pragma unroll
+                for (int jj = 0; jj < CL; ++jj) {
+                  if (jj < CLD) Dl[k][jj < CLD ? jj : 0] = __builtin_fma(-wb, dlb[jj], __builtin_fma(-wa, dla[jj], Dl[k][jj < CLD ? jj : 0]));
+                  if (col_j(jj) == NB) Xl[k][jj] = __builtin_fma(wb, rb.prod, __builtin_fma(wa, ra.prod, Xl[k][jj]));
                 }
               }
             }

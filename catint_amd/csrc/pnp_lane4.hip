@@ -42,6 +42,10 @@ template <int Q>
 __device__ __forceinline__ double quad_bcast(double v) {      // the value of column lane Q, in all four lanes of the quad
   return dpp4<Q | (Q << 2) | (Q << 4) | (Q << 6)>(v);
 }
+// (Q known after unrolling: the switch folds to one of the four broadcasts)
+__device__ __forceinline__ double quad_bcast_sel(const int Q, double v) {
+  return Q == 0 ? quad_bcast<0>(v) : (Q == 1 ? quad_bcast<1>(v) : (Q == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+}
 constexpr int DPP_XOR1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);
 constexpr int DPP_XOR2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);
 __device__ __forceinline__ double other_side(double v) { return __shfl_xor(v, 4, 64); }      // the same column lane of the other direction
@@ -69,6 +73,10 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
   constexpr bool FULL = MODE == 2;
   __shared__ double s_cb[N][QG];
   __shared__ LaneParams sP;
+  // MODE 2 only (no LDS in the other instances): the flattened mass-action table and the per-row values its slots point into
+  __shared__ double s_react[FULL ? sizeof(ReactionSides) / sizeof(double) + RC_ROWS * 64 : 1];
+  ReactionSides& sS = *(ReactionSides*)s_react;
+  double (*s_rc)[64] = (double (*)[64])(s_react + sizeof(ReactionSides) / sizeof(double));
   const int lane = threadIdx.x, o = lane >> 3;
   const int q = lane & 3;                     // column lane: owns the columns j with j & 3 == q
   const bool side = (lane & 4) != 0;          // false: from the wall upwards; true: from the bulk downwards
@@ -100,6 +108,10 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     sP.pe[lane] = G.pe[lane];
     sP.rs[lane] = G.rs[lane];
   }
+  if constexpr (FULL) {
+    lane_stage_reaction_sides(sS, G.sides, lane);
+    lane_reaction_init(s_rc, lane);
+  }
   __syncthreads();
   auto fwd_row = [&](int s) { return side ? (s < n_dn ? nx - 2 - s : m + 1) : (s < m ? s : m); };
   auto col_j = [&](const int jj) { return 4 * jj + q; };      // unknown of local column jj (run-time lane, compile-time jj)
@@ -119,9 +131,15 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
   double upd_prev = INFINITY, upd_prev2 = INFINITY;
   double alarm = 0.0;            // pivot monitor (sticky)
+#ifdef PNP_LANE_STAMPS
+  double stamp_f = 0.0, stamp_b = 0.0, stamp_u = 0.0, stamp_n = 0.0;
+#endif
 
   for (;;) {
     if (__ballot(have) == 0ull) break;
+#ifdef PNP_LANE_STAMPS
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
     const NewtonArgs& A = G;
     const bool first = fresh;
     if (fresh) {
@@ -420,25 +438,33 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
         }
         // ---- homogeneous reactions (see pnp_lane.hip): every lane evaluates the rates, each column lane keeps its own columns -----------------
         if constexpr (FULL) {
-          if (A.rt) {
-            const ReactionTable* rt = A.rt;
-            const int nr = rt->n;
-            for (int r = 0; r < nr; ++r) {
-              for (int sd = 0; sd < 2; ++sd) {
-                double prod, dprod[N], sw[N];
-                if (!lane_reaction_side<N, MPB>(rt, r, sd, hc, hinv, G.vol, prod, dprod, sw)) continue;
-                double dl[CL];           // d prod / d c_j of this lane's columns
+          const int ns = __builtin_amdgcn_readfirstlane(sS.n);
+          if (ns > 0) {
+            double vrs[N];
 #pragma unroll
-                for (int jj = 0; jj < CL; ++jj) dl[jj] = pickq([&](int k) { return dprod[k]; }, jj, N);
+            for (int k = 0; k < N; ++k) vrs[k] = vi * P->rs[k];
+            lane_reaction_fill<N>(s_rc, lane, hc, hinv);
+            // (two sides per pass: their LDS round trips -- table entry, then the values it points at -- overlap)
+            for (int sd = 0; sd < ns; sd += 2) {
+              const ReactionSides::Side& Sa = sS.side[sd];
+              const ReactionSides::Side& Sb = sS.side[sd + 1];
+              const LaneSide ra = lane_reaction_side<MPB>(Sa, s_rc, lane);
+              const LaneSide rb = lane_reaction_side<MPB>(Sb, s_rc, lane);
+              double dla[CL], dlb[CL];           // d prod / d c_j of this lane's columns
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                  if (sw[k] == 0.0) continue;
-                  const double wr = sw[k] * (vi * P->rs[k]);
+              for (int jj = 0; jj < CL; ++jj) {
+                double volj = 0.0;
+                if constexpr (MPB) volj = pickq([&](int k) { return G.vol[k]; }, jj, N);
+                dla[jj] = col_j(jj) < N ? lane_side_dprod(ra, col_j(jj), volj) : 0.0;
+                dlb[jj] = col_j(jj) < N ? lane_side_dprod(rb, col_j(jj), volj) : 0.0;
+              }
 #pragma unroll
-                  for (int jj = 0; jj < CL; ++jj) {
-                    if (jj < CLD) Dl[k][jj < CLD ? jj : 0] = __builtin_fma(-wr, dl[jj], Dl[k][jj < CLD ? jj : 0]);
-                    if (col_j(jj) == NB) Xl[k][jj] = __builtin_fma(wr, prod, Xl[k][jj]);
-                  }
+              for (int k = 0; k < N; ++k) {
+                const double wa = Sa.w[k] * vrs[k], wb = Sb.w[k] * vrs[k];
+#pragma unroll
+                for (int jj = 0; jj < CL; ++jj) {
+                  if (jj < CLD) Dl[k][jj < CLD ? jj : 0] = __builtin_fma(-wb, dlb[jj], __builtin_fma(-wa, dla[jj], Dl[k][jj < CLD ? jj : 0]));
+                  if (col_j(jj) == NB) Xl[k][jj] = __builtin_fma(wb, rb.prod, __builtin_fma(wa, ra.prod, Xl[k][jj]));
                 }
               }
             }
@@ -493,7 +519,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
         for (int k = 0; k < NB; ++k) {
           double pc[NB];
 #pragma unroll
-          for (int r = 0; r < NB; ++r) pc[r] = quad_bcast<(k & 3)>(Dl[r][k >> 2]);
+          for (int r = 0; r < NB; ++r) pc[r] = quad_bcast_sel(k & 3, Dl[r][k >> 2]);
           {   // pivot monitor (pnp_lane_common.h): rows k+1 .. of the pivot column against the pivot
             double cmax = 0.0;
 #pragma unroll
@@ -555,6 +581,9 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
         }
       }
     }
+#ifdef PNP_LANE_STAMPS
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
     // =========================== backward ========================================================================================================
     // x_m sits in the upward quad's column lane NB & 3 (local column NB >> 2); the upward quad broadcasts it, the downward quad takes it
     // from its partner lanes
@@ -582,29 +611,43 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     {
       const int nb_ = n_dn > m ? n_dn : m;
       auto bwd_row = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 2) : (s < m ? m - 1 - s : 0); };
-      d2 Rn[RP];
+      // A row of this pass is a few hundred instructions against 14 record loads: with the next row's record requested one row ahead the
+      // pass ran at one memory round trip per row (34 % of the wave's life in s_waitcnt at one wave per SIMD).  The records do not depend
+      // on the solution, so they are requested BD rows ahead into a ring of BD register buffers (compile-time indices: the loop is
+      // unrolled BD times); vector memory operations complete in order, so consuming buffer d waits for its own loads only.
+      constexpr int BD = 4;
+      d2 Rb[BD][RP];
 #pragma unroll
-      for (int p = 0; p < RP; ++p) {       // (pairs of columns that do not exist are never loaded: they stay zero)
-        Rn[p][0] = 0.0;
-        Rn[p][1] = 0.0;
-      }
-      {
-        const int i = bwd_row(0);
+      for (int d = 0; d < BD; ++d)
 #pragma unroll
-        for (int p = 0; p < RP; ++p)
-          if (p < rp_valid) Rn[p] = REC(i, p);
+        for (int p = 0; p < RP; ++p) {       // (pairs of columns that do not exist are never loaded: they stay zero)
+          Rb[d][p][0] = 0.0;
+          Rb[d][p][1] = 0.0;
+        }
+#pragma unroll
+      for (int d = 0; d < BD; ++d) {
+        if (d < nb_) {
+          const int i = bwd_row(d);
+#pragma unroll
+          for (int p = 0; p < RP; ++p)
+            if (p < rp_valid) Rb[d][p] = REC(i, p);
+        }
       }
-      for (int s = 0; s < nb_; ++s) {
+      for (int s0 = 0; s0 < nb_; s0 += BD) {
+#pragma unroll
+       for (int d = 0; d < BD; ++d) {
+        const int s = s0 + d;
+        if (s >= nb_) break;
         const bool act = side ? s < n_dn : s < m;
         const int i = bwd_row(s);
         d2 R[RP];
 #pragma unroll
-        for (int p = 0; p < RP; ++p) R[p] = Rn[p];
-        if (s + 1 < nb_) {
-          const int in = bwd_row(s + 1);
+        for (int p = 0; p < RP; ++p) R[p] = Rb[d][p];
+        if (s + BD < nb_) {
+          const int in = bwd_row(s + BD);
 #pragma unroll
           for (int p = 0; p < RP; ++p)
-            if (p < rp_valid) Rn[p] = REC(in, p);
+            if (p < rp_valid) Rb[d][p] = REC(in, p);
         }
         if (act) {
           // this lane's share of t - T x: its columns (column NB is t itself)
@@ -641,11 +684,15 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
           mphi = fmax(mphi, a);
           if (!(a == a)) mphi = INFINITY;
         }
+       }
       }
     }
     mphi = fmax(mphi, other_side(mphi));
     double lam = 1.0;
     if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+#ifdef PNP_LANE_STAMPS
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
     // =========================== update: the rows of a direction are split between its four column lanes =========================================
     double upd = 0.0;
     {
@@ -653,30 +700,37 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
       const int lo = side ? m + 1 : 0, cnt = side ? n_dn + 1 : m + 1;
       const int nu_ = ((n_dn + 1 > m + 1 ? n_dn + 1 : m + 1) + 3) / 4;
       auto upd_row = [&](int s) { const int z = 4 * s + q; return lo + (z < cnt ? z : cnt - 1); };
-      d2 xn[VP], cn2[VP];
-      {
-        const int i = upd_row(0);
+      // (requested UD rows ahead, like the records of the backward pass)
+      constexpr int UD = 4;
+      d2 xb[UD][VP], cb2[UD][VP];
+#pragma unroll
+      for (int d = 0; d < UD; ++d) {
+        const int i = upd_row(d);          // (clamped to the lane's last row beyond its share: a valid address)
 #pragma unroll
         for (int p = 0; p < VP; ++p) {
-          xn[p] = XS(i, p);
-          cn2[p] = TS(i, p);
+          xb[d][p] = XS(i, p);
+          cb2[d][p] = TS(i, p);
         }
       }
-      for (int s = 0; s < nu_; ++s) {
+      for (int s0 = 0; s0 < nu_; s0 += UD) {
+#pragma unroll
+       for (int d = 0; d < UD; ++d) {
+        const int s = s0 + d;
+        if (s >= nu_) break;
         const bool act = 4 * s + q < cnt;
         const int i = upd_row(s);
         d2 x2[VP], c2[VP];
 #pragma unroll
         for (int p = 0; p < VP; ++p) {
-          x2[p] = xn[p];
-          c2[p] = cn2[p];
+          x2[p] = xb[d][p];
+          c2[p] = cb2[d][p];
         }
-        if (s + 1 < nu_) {
-          const int in = upd_row(s + 1);
+        if (s + UD < nu_) {
+          const int in = upd_row(s + UD);
 #pragma unroll
           for (int p = 0; p < VP; ++p) {
-            xn[p] = XS(in, p);
-            cn2[p] = TS(in, p);
+            xb[d][p] = XS(in, p);
+            cb2[d][p] = TS(in, p);
           }
         }
         if (act) {
@@ -722,6 +776,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
             }
           }
         }
+       }
       }
     }
     upd = fmax(upd, dpp4<DPP_XOR1>(upd));
@@ -729,6 +784,15 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     upd = fmax(upd, other_side(upd));
     upd = fmax(upd, mphi * A.vt_inv);
     alarm = fmax(alarm, other_side(alarm));          // (the four column lanes of a direction saw the same pivots)
+#ifdef PNP_LANE_STAMPS
+    {   // diagnosis build (tools/probe/lane4_stamps.sh): cycles of the three passes of this iteration, summed per wave
+      const unsigned long long ts3 = __builtin_readcyclecounter();
+      stamp_f += (double)(ts1 - ts0);
+      stamp_b += (double)(ts2 - ts1);
+      stamp_u += (double)(ts3 - ts2);
+      stamp_n += 1.0;
+    }
+#endif
     // =========================== bookkeeping (identical in the eight lanes of an operating point) ====================================================
     if (have) {
       bool accept = false;
@@ -755,6 +819,14 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
       }
     }
   }
+#ifdef PNP_LANE_STAMPS
+  if (lane == 0 && slot + 3 < G.B) {      // per wave: mean cycles per iteration of the three passes, in place of four points' iteration counts
+    G.iters[slot + 0] = (int32_t)(stamp_f / stamp_n);
+    G.iters[slot + 1] = (int32_t)(stamp_b / stamp_n);
+    G.iters[slot + 2] = (int32_t)(stamp_u / stamp_n);
+    G.iters[slot + 3] = (int32_t)stamp_n;
+  }
+#endif
 }
 
 template <int NB>
@@ -793,7 +865,12 @@ bool newton_lane4_supported(int nb, int nx, int mode) { return nb >= 6 && nb <= 
 bool newton_lane4_preferred(int nb, int nx, int64_t B, int mode, const Options& opt) {
   if (!newton_lane4_supported(nb, nx, mode)) return false;
   if (opt.newton_kernel != NK_AUTO) return opt.newton_kernel == NK_LANE4;
-  return false;      // (until measured against the lane-pair kernel)
+  // Measured on one device in one process (tools/probe/lane4_probe.py -> profiles/r04_lane4_probe.jsonl; N = 8 steric, nx = 512,
+  // timesteps/s, lane quad / lane pair / lane / lane teams): B = 1024 1.64e5 / 1.22e5 / 1.01e5 / 1.38e5, 2048 3.33e5 / 2.38e5 / 1.98e5 /
+  // 1.41e5, 4096 5.33e5 / 4.54e5 / 3.89e5 / 1.44e5, 8192 8.52e5 / 7.26e5 / 7.34e5, 16 384 0.83e6 / 1.01e6 / 1.09e6; nx = 4096:
+  // B = 2048 3.9e4 / 2.9e4 / 2.5e4, 8192 1.02e5 / 0.93e5 / 0.90e5.  Eight points per wave: the chip is full at 8192 points and the
+  // kernel saturates there (a wave's row costs ~2000 vector instructions for 8 points against ~4200 for the lane kernel's 32).
+  return B >= 896 && B < 12288;
 }
 
 }  // namespace pnp

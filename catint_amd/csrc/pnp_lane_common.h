@@ -54,53 +54,76 @@ struct LaneParams {
   double pe[PNP_NEWTON_MAX_SPECIES], rs[PNP_NEWTON_MAX_SPECIES];      // MODE 2: convection v dx / D_k, reaction scale dx^2 / D_k
 };
 
-// One side (0: educts, forward rate constant; 1: products, backward) of mass-action reaction r at a grid point with concentrations
-// c and activity coefficient gam = 1/(1 - phi0) (comsol_model.py:781-867, :1064-1084; oracle/pnp_physical.py: reaction_rates; the
-// formulas of fill_row in pnp_newton.hip):  prod = k gam^n prod_a c_a,  dprod[j] = d prod / d c_j,  sw[k] = the net stoichiometric
-// weight with which (forward - backward) enters R_k -- table data, i.e. wave-uniform scalars.  Returns false for a side without a rate.
-template <int N, bool MPB>
-__device__ __forceinline__ bool lane_reaction_side(const ReactionTable* rt, const int r, const int side, const double (&c)[N],
-                                                   const double gam, const double* vol, double& prod, double (&dprod)[N],
-                                                   double (&sw)[N]) {
-  const int nl = rt->n_lhs[r], nrh = rt->n_rhs[r];
-  const int n = side == 0 ? nl : nrh;
-  const int32_t* idx = side == 0 ? rt->lhs[r] : rt->rhs[r];
-  const double kk = side == 0 ? rt->kf[r] : rt->kr[r];
-  if (kk == 0.0) return false;             // n = 0 with a rate: constant source (the side consists of excluded species, e.g. H2O)
-  auto pick = [&](int i_) {
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) v = (k == i_) ? c[k] : v;
-    return v;
-  };
-  double pre = kk;
-  for (int a = 0; a < n; ++a) pre *= gam;
-  prod = pre;
-  for (int a = 0; a < n; ++a) prod *= pick(idx[a]);
-#pragma unroll
-  for (int j = 0; j < N; ++j) dprod[j] = MPB ? prod * n * (vol[j] * gam) : 0.0;     // through gam (zero volumes: point ions)
-  for (int a = 0; a < n; ++a) {
-    double rest = pre;
-    for (int b2 = 0; b2 < n; ++b2)
-      if (b2 != a) rest *= pick(idx[b2]);
-    const int ia = idx[a];
-#pragma unroll
-    for (int j = 0; j < N; ++j) dprod[j] += (j == ia) ? rest : 0.0;
+// Copy of the flattened reaction table in LDS (every lane of the wave copies its share of dwords; the caller synchronises).
+__device__ __forceinline__ void lane_stage_reaction_sides(ReactionSides& dst, const ReactionSides* src, int lane) {
+  if (!src) {
+    if (lane == 0) dst.n = 0;
+    return;
   }
-  const double sg = side == 0 ? 1.0 : -1.0;                    // forward minus backward
+  const int32_t* s_ = (const int32_t*)src;
+  int32_t* d_ = (int32_t*)&dst;
+  constexpr int WORDS = (int)(sizeof(ReactionSides) / sizeof(int32_t));
+  for (int w = lane; w < WORDS; w += 64) d_[w] = s_[w];
+}
+
+// Per-row value table of the reaction terms in LDS, one column per lane: rows 0 .. 7 the concentrations at the point, row 8 the
+// constant one (unused reactant slots), rows 9 .. 13 the powers gam^0 .. gam^4 of the activity coefficient.
+constexpr int RC_ONE = 8, RC_GAM = 9, RC_ROWS = 14;
+static_assert(sizeof(ReactionSides) % sizeof(double) == 0, "the value table follows the reaction table in one LDS array of doubles");
+static_assert(PNP_NEWTON_MAX_SPECIES <= RC_ONE && PNP_MAX_REACTANTS == 4, "slot encoding of ReactionSides");
+
+template <int N>
+__device__ __forceinline__ void lane_reaction_fill(double (*rc)[64], int lane, const double (&c)[N], double gam) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) sw[k] = 0.0;
-  for (int a = 0; a < nl; ++a) {
-    const int jsp = rt->lhs[r][a];
+  for (int k = 0; k < N; ++k) rc[k][lane] = c[k];
+  const double g2 = gam * gam;
+  rc[RC_GAM + 1][lane] = gam;
+  rc[RC_GAM + 2][lane] = g2;
+  rc[RC_GAM + 3][lane] = g2 * gam;
+  rc[RC_GAM + 4][lane] = g2 * g2;
+}
+__device__ __forceinline__ void lane_reaction_init(double (*rc)[64], int lane) {      // the rows that never change
+  rc[RC_ONE][lane] = 1.0;
+  rc[RC_GAM][lane] = 1.0;
+}
+
+// One reaction side at the point whose values the table holds (comsol_model.py:781-867, :1064-1084; oracle/pnp_physical.py:
+// reaction_rates): prod = k gam^order prod_a c_(i_a); rest[a] = the product with reactant a left out = its derivative with respect
+// to c_(i_a), to be added to column col[a] (15: none); steric = prod order gam, the factor of vol_j in d prod / d c_j through gam.
+// Branch-free: every side has four reactant slots, unused ones read the constant one.  The side's fields are wave-uniform values in
+// LDS that every lane reads for itself; the species index of a slot selects a table ROW, i.e. an address, not a register.
+struct LaneSide {
+  double prod, rest[PNP_MAX_REACTANTS], steric;
+  int col[PNP_MAX_REACTANTS];
+};
+template <bool MPB>
+__device__ __forceinline__ LaneSide lane_reaction_side(const ReactionSides::Side& S, const double (*rc)[64], int lane) {
+  const uint32_t slots = S.slots;
+  const int order = S.order;
+  const double pre = S.k * rc[RC_GAM + order][lane];
+  double f[PNP_MAX_REACTANTS];
+  LaneSide r;
 #pragma unroll
-    for (int k = 0; k < N; ++k) sw[k] -= (k == jsp) ? sg : 0.0;   // educts lose
+  for (int a = 0; a < PNP_MAX_REACTANTS; ++a) {
+    f[a] = rc[(slots >> (4 * a)) & 15u][lane];
+    r.col[a] = (int)((slots >> (16 + 4 * a)) & 15u);
   }
-  for (int a = 0; a < nrh; ++a) {
-    const int jsp = rt->rhs[r][a];
+  const double p01 = f[0] * f[1], p23 = f[2] * f[3];
+  const double q23 = pre * p23, q01 = pre * p01;
+  r.rest[0] = f[1] * q23;
+  r.rest[1] = f[0] * q23;
+  r.rest[2] = q01 * f[3];
+  r.rest[3] = q01 * f[2];
+  r.prod = q01 * p23;
+  r.steric = MPB ? r.prod * (double)order * rc[RC_GAM + 1][lane] : 0.0;      // through gam: d gam / d c_j = vol_j gam^2
+  return r;
+}
+// d prod / d c_j of a side for species column j
+__device__ __forceinline__ double lane_side_dprod(const LaneSide& r, int j, double vol_j) {
+  double d = r.steric * vol_j;
 #pragma unroll
-    for (int k = 0; k < N; ++k) sw[k] += (k == jsp) ? sg : 0.0;   // products gain
-  }
-  return true;
+  for (int a = 0; a < PNP_MAX_REACTANTS; ++a) d += (r.col[a] == j) ? r.rest[a] : 0.0;
+  return d;
 }
 
 }  // namespace lane

@@ -226,7 +226,7 @@ def test_lane_mask_and_set_lanes(kernel, monkeypatch):
         assert (it2[~even] <= 2).all() and np.abs(c2 - cref).max() <= 1e-8 * np.abs(cref).max()
 
 
-@pytest.mark.parametrize("kernel,N", [('lane', 3), ('lane', 8), ('lane2', 6), ('lane2', 8)])
+@pytest.mark.parametrize("kernel,N", [('lane', 3), ('lane', 8), ('lane2', 6), ('lane2', 8), ('lane4', 5), ('lane4', 8)])
 def test_pivot_monitor_reports_a_lane_as_not_converged(kernel, N, monkeypatch):
     """The lane kernels eliminate without row exchanges; a multiplier beyond 1e8 marks the lane and a marked lane is never reported
     converged (status 1: the rerun ladder then solves it with the pivoting kernels).  On well-posed systems the monitor stays silent
@@ -247,7 +247,7 @@ def test_pivot_monitor_reports_a_lane_as_not_converged(kernel, N, monkeypatch):
 
 
 @pytest.mark.parametrize("kernel,N,nx,B,groups", [('lane', 3, 96, 203, None), ('lane', 8, 64, 150, '2'), ('lane2', 6, 80, 133, None),
-                                                  ('lane2', 8, 48, 97, '3')])
+                                                  ('lane2', 8, 48, 97, '3'), ('lane4', 7, 80, 133, None), ('lane4', 8, 48, 97, '5')])
 def test_points_ordered_by_expected_iterations_give_the_same_bits(kernel, N, nx, B, groups, monkeypatch):
     """The host deals the operating points to the slots (group, lane) in the order of the Newton iterations they are expected to need
     (pnp_capi.hip: lane_order -- first call: wall-to-bulk potential difference; later calls: the previous call's iteration counts), so
@@ -283,7 +283,7 @@ def test_points_ordered_by_expected_iterations_give_the_same_bits(kernel, N, nx,
     assert len(set(outs[0][2])) > 1 and (outs[0][5] == 0).all()       # different counts within the batch: the order is not trivial
 
 
-@pytest.mark.parametrize("kernel,N,nx", [('lane', 3, 96), ('lane', 8, 64), ('lane2', 6, 80), ('lane2', 8, 48)])
+@pytest.mark.parametrize("kernel,N,nx", [('lane', 3, 96), ('lane', 8, 64), ('lane2', 6, 80), ('lane2', 8, 48), ('lane4', 5, 80), ('lane4', 8, 48)])
 def test_error_estimate_stopping_rule(kernel, N, nx, monkeypatch):
     """pnp_newton_params.error_estimate: accept an iterate whose quadratic error estimate upd^2 / upd_prev is below the tolerance (saves
     the iteration that only confirms convergence) -- same rule in the oracle, same iteration counts; fewer than without."""
