@@ -123,13 +123,15 @@ def pmc_child(args):
             item(s, inp, lambda s, w: s.step(6))
             s, inp = newton_solver(BC_SHAPE[0], BC_SHAPE[1], BC_SHAPE[2], 4447, steric=True)
             item(s, inp, lambda s, w: s.step(4))
+            s, inp = newton_solver(C4_SHAPE[0], C4_SHAPE[1], C4_SHAPE[2], 4448, steric=True)
+            item(s, inp, lambda s, w: s.step(2))
         if args.large_batch > 0:
             s, inp = compat_solver(args.large_batch, N, nx, args.method, 77)
             item(s, inp, lambda s, w: s.step(8, 1))
 
 
 PMC_ITEMS = ['headline', 'per_step_launch', 'beyond_cache_per_step', 'beyond_cache_fused', 'physical_pair', 'physical_sweep',
-             'physical_lane_32k', 'physical_lane_config3', 'large_batch']
+             'physical_lane_32k', 'physical_lane_config3', 'physical_lane_config4', 'large_batch']
 
 
 def pmc_items(args):
@@ -138,7 +140,7 @@ def pmc_items(args):
     if not args.no_extras:
         names += ['beyond_cache_per_step', 'beyond_cache_fused']
         if args.physical_steps > 0:
-            names += ['physical_pair', 'physical_sweep', 'physical_lane_32k', 'physical_lane_config3']
+            names += ['physical_pair', 'physical_sweep', 'physical_lane_32k', 'physical_lane_config3', 'physical_lane_config4']
         if args.large_batch > 0:
             names += ['large_batch']
     return names
@@ -213,7 +215,7 @@ def collect_pmc(args):
             # (uncalibrated): for them the x1 figure is kept beside the x2 one as a lower bound.
             rec['hbm_bytes_per_launch'] = (2.0 * rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024.0
             rec['hbm_bytes_per_launch_fetch_x1'] = (rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024.0
-            rec['fetch_correction'] = 'x2 (16-byte lanes)' if ('step_kernel' in rec['kernel'] or 'lane_kernel' in rec['kernel']) else 'x1 ... x2 (8-byte lanes: uncalibrated)' 
+            rec['fetch_correction'] = 'x2 (16-byte lanes)' if ('step_kernel' in rec['kernel'] or 'newton_lane' in rec['kernel']) else 'x1 ... x2 (8-byte lanes: uncalibrated)' 
     return out
 
 
@@ -454,8 +456,7 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
 
     try:
         out['large_batch_8_species'] = lane_record(8192, 8, 512, 4444, 20, 'physical_sweep',
-                                                   'lane-pair kernel, four lanes per operating point: 512 waves on 1024 SIMDs, paced by the '
-                                                   'arithmetic and the latency of a single wave')
+                                                   'lane-quad kernel, eight lanes per operating point: 1024 waves, one per SIMD')
         out['large_batch_8_species_32k'] = lane_record(32768, 8, 512, 4446, 20, 'physical_lane_32k',
                                                        'lane kernel, one wave per SIMD (1024 waves); 20 timesteps in one launch', pmc_steps=6)
         # the same with the quadratic error estimate as stopping rule (pnp_newton_params.error_estimate: saves the iteration that only
@@ -481,7 +482,7 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
     except Exception as e:
         out['config3_share'] = {'error': str(e)}
     try:      # one GPU's share of BASELINE configs[4]: 8192 lanes x 8 species x 4096 points (24 GB of records)
-        out['config4_share'] = lane_record(8192, 8, 4096, 4448, 4, None, "one GPU's share of configs[4] (65536 points over 8 GPUs)")
+        out['config4_share'] = lane_record(8192, 8, 4096, 4448, 4, 'physical_lane_config4', "one GPU's share of configs[4] (65536 points over 8 GPUs)")
     except Exception as e:
         out['config4_share'] = {'error': str(e)}
     try:      # below the lane kernel's crossover: lane teams, two-sided sweep
@@ -523,6 +524,21 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
             'lanes': 4096, 'lanes_converged': int((calc.status == 0).sum()), 'continuation_stages': int(calc.continuation_stages),
             'transport_solve_seconds': float(calc.solve_seconds), 'seconds_incl_host_result_dictionaries': t_all,
             'operating_points_per_s': 4096 / float(calc.solve_seconds)}
+        its2 = float(getattr(calc, 'newton_iterations_total', 0))
+        if its2 > 0:
+            r2 = out['configs2_co2r_sweep']
+            alg2 = lane_bytes(tp.nspecies, tp.nx)
+            r2['newton_iterations'] = its2
+            r2['newton_iterations_per_s'] = its2 / float(calc.solve_seconds)
+            r2['mean_newton_iterations_per_stage'] = its2 / (4096.0 * max(int(calc.continuation_stages), 1))
+            r2['newton_iterations_of_the_slowest_lane_summed_over_stages'] = int(getattr(calc, 'newton_iterations_slowest', 0))
+            r2['lanes_handed_back_by_the_pivot_monitor'] = int(sum(len(e.get('lanes', [])) for e in getattr(calc, 'retry_log', []) or []))
+            r2['roofline'] = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'algorithmic_bytes_per_lane_iteration': alg2,
+                              'achieved': alg2 * its2 / float(calc.solve_seconds) / 1e9, 'frac': alg2 * its2 / float(calc.solve_seconds) / 1e9 / HBM_PEAK_GBS,
+                              'traffic': None,
+                              'note': 'wall time of the eleven stage solves incl. their host calls (uploads of the stage potentials, one '
+                                      'synchronisation per stage); a stage lasts as long as its slowest lane (8-9 iterations against 6.5 on '
+                                      'average) and 4096 points give the lane-quad kernel 512 waves on 1024 SIMDs: latency-, not HBM-bound'}
     except Exception as e:
         out['configs2_co2r_sweep'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if with_cpu:

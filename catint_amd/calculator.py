@@ -439,6 +439,11 @@ class Calculator(object):
                 solver.set_flux(flux * w)
             self._apply_surface_kinetics(solver, pbj[:, 0], lanes=lanes)
             st = solver.solve_stationary()
+            it = solver.newton_iterations()
+            # (what bench.py reports next to the wall time: iterations spent by all lanes, and by the slowest lane of each stage -- a
+            # lane kernel's launch lasts as long as its slowest operating point)
+            self.newton_iterations_total = getattr(self, 'newton_iterations_total', 0) + int(it.sum())
+            self.newton_iterations_slowest = getattr(self, 'newton_iterations_slowest', 0) + int(it.max())
         return st
 
     # ------------------------------------------------------------------------------------------

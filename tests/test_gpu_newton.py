@@ -190,10 +190,16 @@ def test_two_sided_sweep_equals_the_one_sided_sweep(monkeypatch):
 
 
 def test_kernel_choice_for_large_batches_of_large_blocks(monkeypatch):
-    # N >= 5 species and B >= 1280 operating points take the lane kernel (pnp_lane.hip; measured crossover, profiles/r03_lane_sweep.jsonl):
-    # the default equals the forced lane kernel bit for bit; the sweep kernels (one lane team per operating point, one- and two-sided)
-    # stay selectable and give the same answers and iteration counts as the lane-team kernel
-    N, nx, B = 5, 24, 10240
+    # N >= 5 species: 896 <= B < 12 288 operating points take the lane-quad kernel (pnp_lane4.hip), larger batches the lane kernel
+    # (pnp_lane.hip; measured crossovers, profiles/r03_lane_sweep.jsonl, profiles/r04_lane4_probe.jsonl): the default equals the forced
+    # kernel bit for bit; the sweep kernels (one lane team per operating point, one- and two-sided) stay selectable and give the same
+    # answers and iteration counts as the lane-team kernel
+    N, nx, B = 5, 24, 12288
+    monkeypatch.delenv('CATINT_NEWTON_KERNEL', raising=False)
+    q0 = run_gpu_only(N, nx, 2048, 4)
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'lane4')
+    q1 = run_gpu_only(N, nx, 2048, 4)
+    assert np.array_equal(q0[0], q1[0]) and np.array_equal(q0[1], q1[1]) and np.array_equal(q0[2], q1[2])
     monkeypatch.delenv('CATINT_NEWTON_KERNEL', raising=False)
     a = run_gpu_only(N, nx, B, 5)
     monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'lane')

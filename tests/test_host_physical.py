@@ -38,6 +38,9 @@ class FakeSolver(object):
             return np.ones(self.B, np.int32)
         return np.zeros(self.B, np.int32)
 
+    def newton_iterations(self):
+        return np.full(self.B, 4, np.int32)
+
     def step(self, n):
         self.calls.append(('step', n))
 
