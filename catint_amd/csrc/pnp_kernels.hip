@@ -1135,7 +1135,9 @@ __global__ __launch_bounds__(64 * WY, 1) void step_kernel_mw(const DevArgs A) {
         }
         ta[0] = (tid == 0) ? 0.0 : ta[0];
         wg_sync<2>();
+#ifndef MW_NOSOLVE      // (diagnosis build, tools/probe/mw_ceiling.sh: the memory-side ceiling of this kernel's access pattern; results are wrong)
         tridiag_wg<P, WY>(ta, tc, x, XCH, tid);
+#endif
       } else {
         const double sf = S.sf, dm = S.dm, Mf = S.Mf;
         double cc[P + 2], gq[P + 2];
