@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
 }
 
 // ---- the solver ---------------------------------------------------------------------------------------------------------------
-template <int NB, int MODE>
+template <int NB, int MODE, bool FUSED>
 __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   constexpr int N = NB - 1, NREC = NB * NB + NB;
   constexpr int VP = (NB + 1) / 2, CP = (N + 1) / 2, RP = NREC / 2;     // 16-byte pairs per row: state / previous level / record
@@ -166,8 +166,13 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   d2* xs = (d2*)G.lane_xs + (size_t)g * (size_t)nx * VP * LG + o;
   d2* tco = (d2*)G.lane_tco + (size_t)g * (size_t)nx * CP * LG + o;
   d2* rec = (d2*)G.lane_rec + (size_t)g * (size_t)nx * RP * LG + o;
-  auto TS = [&](int i, int p) -> d2& { return ts[((size_t)i * VP + p) * LG]; };
-  auto XS = [&](int i, int p) -> d2& { return xs[((size_t)i * VP + p) * LG]; };
+  // Two copies of the state (G.lane_ts, G.lane_xs): the back-substitution of an iteration reads the current one and writes the updated
+  // state into the other (see "backward" below); `cur` says which one is current for this lane's operating point.
+  int cur = 0;
+  d2 *tsc = ts, *tsn = xs;        // (set at the top of every iteration from `cur`)
+  auto TS = [&](int i, int p) -> d2& { return tsc[((size_t)i * VP + p) * LG]; };      // current state
+  auto TN = [&](int i, int p) -> d2& { return tsn[((size_t)i * VP + p) * LG]; };      // the state being written
+  auto XS = [&](int i, int p) -> d2& { return xs[((size_t)i * VP + p) * LG]; };       // (!FUSED: the Newton update; cur stays 0)
   auto CO = [&](int i, int p) -> d2& { return tco[((size_t)i * CP + p) * LG]; };
   auto REC = [&](int i, int p) -> d2& { return rec[((size_t)i * RP + p) * LG]; };
   const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
@@ -204,6 +209,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     // them were measured on one device in one call, tools/probe/lane_ab.sh, and both LOST: the whole iteration under their exec mask
     // -9 %, every access through a range-checked buffer resource with out-of-range offsets for finished lanes -6 ... -13 %.)
     const NewtonArgs& A = G;
+    tsc = cur ? xs : ts;
+    tsn = cur ? ts : xs;
     const bool first = fresh;          // first iteration of a timestep: the previous time level is the state itself
     if (fresh) {
       it = 0;
@@ -304,12 +311,14 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         t[N] = -(bphi - phiB);
         mphi = fabs(t[N]);
         if (!(mphi == mphi)) mphi = INFINITY;
+        if constexpr (!FUSED) {
 #pragma unroll
-        for (int p = 0; p < VP; ++p) {
-          d2 v;
-          v[0] = t[2 * p];
-          v[1] = 2 * p + 1 < NB ? t[2 * p + 1 < NB ? 2 * p + 1 : 0] : 0.0;
-          XS(nx - 1, p) = v;
+          for (int p = 0; p < VP; ++p) {
+            d2 v;
+            v[0] = t[2 * p];
+            v[1] = 2 * p + 1 < NB ? t[2 * p + 1 < NB ? 2 * p + 1 : 0] : 0.0;
+            XS(nx - 1, p) = v;
+          }
         }
         if (first) {
 #pragma unroll
@@ -598,14 +607,16 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             }
           }
         } else {
-          // the middle row's solution goes where the update pass looks for it; nothing is carried out of this row (fresh
-          // definitions end the live ranges of the old record here)
+          // the middle row's solution stays in t (separate update pass: it also goes where that pass looks for it); nothing else is
+          // carried out of this row (fresh definitions end the live ranges of the old record here)
+          if constexpr (!FUSED) {
 #pragma unroll
-          for (int p = 0; p < VP; ++p) {
-            d2 v;
-            v[0] = rhs[2 * p];
-            v[1] = 2 * p + 1 < NB ? rhs[2 * p + 1 < NB ? 2 * p + 1 : 0] : 0.0;
-            XS(i, p) = v;
+            for (int p = 0; p < VP; ++p) {
+              d2 v;
+              v[0] = rhs[2 * p];
+              v[1] = 2 * p + 1 < NB ? rhs[2 * p + 1 < NB ? 2 * p + 1 : 0] : 0.0;
+              XS(i, p) = v;
+            }
           }
 #pragma unroll
           for (int j = TL; j < NB; ++j)
@@ -631,40 +642,60 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 #ifdef PNP_LANE_STAMPS
     const unsigned long long ts1 = __builtin_readcyclecounter();
 #endif
-    // =========================== backward: x_i = t_i - T_i x_ahead-of-the-elimination, outwards from the middle ============
-    // (t of the middle row IS x_m; the upward half holds it, the downward half gets it from its partner lane)
-    double x[NB];
+    double lam = 1.0, upd = 0.0;
+    if constexpr (FUSED) {
+      // =========================== backward + update: x_i = t_i - T_i x_ahead-of-the-elimination, outwards from the middle ============
+      // The update (damping, clips, oracle/pnp_physical.py: newton_step) is applied row by row as the solution appears: the new state
+      // goes into the OTHER state buffer, the Newton update itself never visits device memory (round 3 wrote it, then read it back
+      // together with the state in a third pass: 18 of 233 doubles per row and iteration).  The damping factor -- |d phi| <= dphi_max
+      // over the whole grid -- is only known at the end, so the pass runs with a full step; an operating point that turns out to need a
+      // shorter one walks its records a second time with the factor it now knows (same x, bit for bit; the buffer it reads was not
+      // touched).  That happens in the first iterations of a solve far from its solution, not in the steps of a transient.
+      // Rows of the pass: upward half m (x_m = t of the middle row, no record), m-1 ... 0; downward half m+1 ... nx-2, then the bulk row
+      // nx-1 (Dirichlet: x = -(state - bulk values), no record).
+      double xm[NB];
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      const double own = side ? 0.0 : t[r];
-      const double other = partner(own);          // (cross-lane: every lane takes part, the select comes afterwards)
-      x[r] = side ? other : own;
-    }
-    if (!side) {
-      mphi = fabs(x[N]);
-      if (!(mphi == mphi)) mphi = INFINITY;
-    }
-    {
-      const int nb_ = n_dn > m ? n_dn : m;
-      auto bwd_row = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 2) : (s < m ? m - 1 - s : 0); };
-      d2 Rn[RP];
-      {
-        const int i = bwd_row(0);
-#pragma unroll
-        for (int p = 0; p < RP; ++p) Rn[p] = REC(i, p);
+      for (int r = 0; r < NB; ++r) {
+        const double own = side ? 0.0 : t[r];
+        const double other = partner(own);          // (cross-lane: every lane takes part, the select comes afterwards)
+        xm[r] = side ? other : own;
       }
-      for (int s = 0; s < nb_; ++s) {
-        const bool act = side ? s < n_dn : s < m;
-        const int i = bwd_row(s);
-        d2 R[RP];
+      const bool have0 = have;
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && __ballot(have0 && lam < 1.0) == 0ull) break;
+        const bool wr = have0 && (pass == 0 || lam < 1.0);
+        const double lm = pass == 0 ? 1.0 : lam;
+        double x[NB];
 #pragma unroll
-        for (int p = 0; p < RP; ++p) R[p] = Rn[p];
-        if (s + 1 < nb_) {
-          const int in = bwd_row(s + 1);
+        for (int r = 0; r < NB; ++r) x[r] = xm[r];
+        double mphi_p = 0.0, upd_p = 0.0;
+        const int nu_ = (n_dn > m ? n_dn : m) + 1;
+        auto row_of = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 1) : (s <= m ? m - s : 0); };
+        auto rec_of = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 2) : (s >= 1 && s <= m ? m - s : 0); };   // (a valid row where none is needed)
+        d2 Rn[RP], cn2[VP];
+        {
+          const int i = row_of(0), ir = rec_of(0);
 #pragma unroll
-          for (int p = 0; p < RP; ++p) Rn[p] = REC(in, p);
+          for (int p = 0; p < RP; ++p) Rn[p] = REC(ir, p);
+#pragma unroll
+          for (int p = 0; p < VP; ++p) cn2[p] = TS(i, p);
         }
-        if (act) {
+        for (int s = 0; s < nu_; ++s) {
+          const bool act = side ? s <= n_dn : s <= m;
+          const bool special = side ? s == n_dn : s == 0;      // the row without a record
+          const int i = row_of(s);
+          d2 R[RP], c2[VP];
+#pragma unroll
+          for (int p = 0; p < RP; ++p) R[p] = Rn[p];
+#pragma unroll
+          for (int p = 0; p < VP; ++p) c2[p] = cn2[p];
+          if (s + 1 < nu_) {
+            const int in = row_of(s + 1), irn = rec_of(s + 1);
+#pragma unroll
+            for (int p = 0; p < RP; ++p) Rn[p] = REC(irn, p);
+#pragma unroll
+            for (int p = 0; p < VP; ++p) cn2[p] = TS(in, p);
+          }
           double y[NB];
 #pragma unroll
           for (int r = 0; r < NB; ++r) y[r] = R[r >> 1][r & 1];
@@ -672,107 +703,213 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < NB; ++r) y[r] = __builtin_fma(-R[(NB + j * NB + r) >> 1][(NB + j * NB + r) & 1], x[j], y[r]);
+          if (act) {
+            double cc_[N], cn[N];
 #pragma unroll
-          for (int r = 0; r < NB; ++r) x[r] = y[r];
+            for (int k = 0; k < N; ++k) cc_[k] = c2[k >> 1][k & 1];
+            const double cphi = c2[N >> 1][N & 1];
 #pragma unroll
-          for (int p = 0; p < VP; ++p) {
-            d2 v;
-            v[0] = y[2 * p];
-            v[1] = 2 * p + 1 < NB ? y[2 * p + 1 < NB ? 2 * p + 1 : 0] : 0.0;
-            XS(i, p) = v;
-          }
-          const double a = fabs(y[N]);
-          mphi = fmax(mphi, a);
-          if (!(a == a)) mphi = INFINITY;
-        }
-      }
-    }
-    mphi = fmax(mphi, partner(mphi));
-    double lam = 1.0;
-    if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
-#ifdef PNP_LANE_STAMPS
-    const unsigned long long ts2 = __builtin_readcyclecounter();
-#endif
-    // =========================== damping, clips, update (oracle/pnp_physical.py: newton_step) ================================
-    double upd = 0.0;
-    {
-      const int nu_ = n_dn + 1 > m + 1 ? n_dn + 1 : m + 1;
-      auto upd_row = [&](int s) { return side ? (s <= n_dn ? m + 1 + s : nx - 1) : (s <= m ? s : m); };
-      d2 xn[VP], cn2[VP];
-      {
-        const int i = upd_row(0);
+            for (int r = 0; r < NB; ++r) {
+              const double sp = side ? (r < N ? -(cc_[r < N ? r : 0] - s_cb[r < N ? r : 0][o]) : -(cphi - phiB)) : xm[r];
+              y[r] = special ? sp : y[r];
+              x[r] = y[r];
+            }
+            const double a = fabs(y[N]);
+            mphi_p = fmax(mphi_p, a);
+            if (!(a == a)) mphi_p = INFINITY;
+            // ---- damping, clips, update of this row --------------------------------------------------------------------------
+            double f_old = 0.0, f_new = 0.0;
 #pragma unroll
-        for (int p = 0; p < VP; ++p) {
-          xn[p] = XS(i, p);
-          cn2[p] = TS(i, p);
-        }
-      }
-      for (int s = 0; s < nu_; ++s) {
-        const bool act = side ? s <= n_dn : s <= m;
-        const int i = upd_row(s);
-        d2 x2[VP], c2[VP];
-#pragma unroll
-        for (int p = 0; p < VP; ++p) {
-          x2[p] = xn[p];
-          c2[p] = cn2[p];
-        }
-        if (s + 1 < nu_) {
-          const int in = upd_row(s + 1);
-#pragma unroll
-          for (int p = 0; p < VP; ++p) {
-            xn[p] = XS(in, p);
-            cn2[p] = TS(in, p);
-          }
-        }
-        if (act) {
-          double du[NB], cc_[N], cn[N];
-#pragma unroll
-          for (int r = 0; r < NB; ++r) du[r] = x2[r >> 1][r & 1];
-          double f_old = 0.0, f_new = 0.0;
-#pragma unroll
-          for (int k = 0; k < N; ++k) {
-            cc_[k] = c2[k >> 1][k & 1];
-            const double rel = fabs(du[k]) / (fabs(cc_[k]) + fabs(s_cb[k][o]) + 1e-300);
-            upd = fmax(upd, rel);
-            if (!(du[k] == du[k])) upd = INFINITY;
-            const double t_ = __builtin_fma(lam, du[k], cc_[k]);
-            const double lo = 0.1 * cc_[k];
-            cn[k] = t_ < lo ? lo : t_;
+            for (int k = 0; k < N; ++k) {
+              const double rel = fabs(y[k]) / (fabs(cc_[k]) + fabs(s_cb[k][o]) + 1e-300);
+              upd_p = fmax(upd_p, rel);
+              if (!(y[k] == y[k])) upd_p = INFINITY;
+              const double t_ = __builtin_fma(lm, y[k], cc_[k]);
+              const double lo = 0.1 * cc_[k];
+              cn[k] = t_ < lo ? lo : t_;
+              if constexpr (MPB) {
+                f_old = __builtin_fma(G.vol[k], cc_[k], f_old);
+                f_new = __builtin_fma(G.vol[k], cn[k], f_new);
+              }
+            }
             if constexpr (MPB) {
-              f_old = __builtin_fma(G.vol[k], cc_[k], f_old);
-              f_new = __builtin_fma(G.vol[k], cn[k], f_new);
+              const double free_ = 1.0 - f_old;
+              const double target = fmax(0.1 * free_, 1e-12);
+              if ((1.0 - f_new) < target) {
+                const double theta = (free_ - target) / (f_new - f_old);
+#pragma unroll
+                for (int k = 0; k < N; ++k) cn[k] = __builtin_fma(theta, cn[k] - cc_[k], cc_[k]);
+              }
+            }
+            if (wr) {
+              double out[2 * VP];
+#pragma unroll
+              for (int k = 0; k < N; ++k) out[k] = cn[k];
+              out[N] = __builtin_fma(lm, y[N], cphi);
+              if (NB < 2 * VP) out[2 * VP - 1] = 0.0;
+#pragma unroll
+              for (int p = 0; p < VP; ++p) {
+                d2 v;
+                v[0] = out[2 * p];
+                v[1] = out[2 * p + 1];
+                TN(i, p) = v;
+              }
             }
           }
-          if constexpr (MPB) {
-            const double free_ = 1.0 - f_old;
-            const double target = fmax(0.1 * free_, 1e-12);
-            if ((1.0 - f_new) < target) {
-              const double theta = (free_ - target) / (f_new - f_old);
+        }
+        if (pass == 0) {
+          mphi = fmax(mphi_p, partner(mphi_p));
+          if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+          upd = fmax(upd_p, partner(upd_p));
+          upd = fmax(upd, mphi * A.vt_inv);
+        }
+      }
+      if (have0) cur ^= 1;            // the state just written is the current one
+    } else {
+      // =========================== backward: x_i = t_i - T_i x_ahead-of-the-elimination, outwards from the middle ============
+      // (t of the middle row IS x_m; the upward half holds it, the downward half gets it from its partner lane)
+      double x[NB];
 #pragma unroll
-              for (int k = 0; k < N; ++k) cn[k] = __builtin_fma(theta, cn[k] - cc_[k], cc_[k]);
-            }
+      for (int r = 0; r < NB; ++r) {
+        const double own = side ? 0.0 : t[r];
+        const double other = partner(own);          // (cross-lane: every lane takes part, the select comes afterwards)
+        x[r] = side ? other : own;
+      }
+      if (!side) {
+        mphi = fabs(x[N]);
+        if (!(mphi == mphi)) mphi = INFINITY;
+      }
+      {
+        const int nb_ = n_dn > m ? n_dn : m;
+        auto bwd_row = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 2) : (s < m ? m - 1 - s : 0); };
+        d2 Rn[RP];
+        {
+          const int i = bwd_row(0);
+#pragma unroll
+          for (int p = 0; p < RP; ++p) Rn[p] = REC(i, p);
+        }
+        for (int s = 0; s < nb_; ++s) {
+          const bool act = side ? s < n_dn : s < m;
+          const int i = bwd_row(s);
+          d2 R[RP];
+#pragma unroll
+          for (int p = 0; p < RP; ++p) R[p] = Rn[p];
+          if (s + 1 < nb_) {
+            const int in = bwd_row(s + 1);
+#pragma unroll
+            for (int p = 0; p < RP; ++p) Rn[p] = REC(in, p);
           }
-          if (have) {
-            double out[2 * VP];
+          if (act) {
+            double y[NB];
 #pragma unroll
-            for (int k = 0; k < N; ++k) out[k] = cn[k];
-            out[N] = __builtin_fma(lam, du[N], c2[N >> 1][N & 1]);
-            if (NB < 2 * VP) out[2 * VP - 1] = 0.0;
+            for (int r = 0; r < NB; ++r) y[r] = R[r >> 1][r & 1];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+              for (int r = 0; r < NB; ++r) y[r] = __builtin_fma(-R[(NB + j * NB + r) >> 1][(NB + j * NB + r) & 1], x[j], y[r]);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) x[r] = y[r];
 #pragma unroll
             for (int p = 0; p < VP; ++p) {
               d2 v;
-              v[0] = out[2 * p];
-              v[1] = out[2 * p + 1];
-              TS(i, p) = v;
+              v[0] = y[2 * p];
+              v[1] = 2 * p + 1 < NB ? y[2 * p + 1 < NB ? 2 * p + 1 : 0] : 0.0;
+              XS(i, p) = v;
+            }
+            const double a = fabs(y[N]);
+            mphi = fmax(mphi, a);
+            if (!(a == a)) mphi = INFINITY;
+          }
+        }
+      }
+      mphi = fmax(mphi, partner(mphi));
+      lam = 1.0;
+      if (A.dphi_max > 0.0 && mphi > A.dphi_max) lam = A.dphi_max / mphi;
+#ifdef PNP_LANE_STAMPS
+      const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
+      // =========================== damping, clips, update (oracle/pnp_physical.py: newton_step) ================================
+      upd = 0.0;
+      {
+        const int nu_ = n_dn + 1 > m + 1 ? n_dn + 1 : m + 1;
+        auto upd_row = [&](int s) { return side ? (s <= n_dn ? m + 1 + s : nx - 1) : (s <= m ? s : m); };
+        d2 xn[VP], cn2[VP];
+        {
+          const int i = upd_row(0);
+#pragma unroll
+          for (int p = 0; p < VP; ++p) {
+            xn[p] = XS(i, p);
+            cn2[p] = TS(i, p);
+          }
+        }
+        for (int s = 0; s < nu_; ++s) {
+          const bool act = side ? s <= n_dn : s <= m;
+          const int i = upd_row(s);
+          d2 x2[VP], c2[VP];
+#pragma unroll
+          for (int p = 0; p < VP; ++p) {
+            x2[p] = xn[p];
+            c2[p] = cn2[p];
+          }
+          if (s + 1 < nu_) {
+            const int in = upd_row(s + 1);
+#pragma unroll
+            for (int p = 0; p < VP; ++p) {
+              xn[p] = XS(in, p);
+              cn2[p] = TS(in, p);
+            }
+          }
+          if (act) {
+            double du[NB], cc_[N], cn[N];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) du[r] = x2[r >> 1][r & 1];
+            double f_old = 0.0, f_new = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              cc_[k] = c2[k >> 1][k & 1];
+              const double rel = fabs(du[k]) / (fabs(cc_[k]) + fabs(s_cb[k][o]) + 1e-300);
+              upd = fmax(upd, rel);
+              if (!(du[k] == du[k])) upd = INFINITY;
+              const double t_ = __builtin_fma(lam, du[k], cc_[k]);
+              const double lo = 0.1 * cc_[k];
+              cn[k] = t_ < lo ? lo : t_;
+              if constexpr (MPB) {
+                f_old = __builtin_fma(G.vol[k], cc_[k], f_old);
+                f_new = __builtin_fma(G.vol[k], cn[k], f_new);
+              }
+            }
+            if constexpr (MPB) {
+              const double free_ = 1.0 - f_old;
+              const double target = fmax(0.1 * free_, 1e-12);
+              if ((1.0 - f_new) < target) {
+                const double theta = (free_ - target) / (f_new - f_old);
+#pragma unroll
+                for (int k = 0; k < N; ++k) cn[k] = __builtin_fma(theta, cn[k] - cc_[k], cc_[k]);
+              }
+            }
+            if (have) {
+              double out[2 * VP];
+#pragma unroll
+              for (int k = 0; k < N; ++k) out[k] = cn[k];
+              out[N] = __builtin_fma(lam, du[N], c2[N >> 1][N & 1]);
+              if (NB < 2 * VP) out[2 * VP - 1] = 0.0;
+#pragma unroll
+              for (int p = 0; p < VP; ++p) {
+                d2 v;
+                v[0] = out[2 * p];
+                v[1] = out[2 * p + 1];
+                TS(i, p) = v;
+              }
             }
           }
         }
       }
+      upd = fmax(upd, partner(upd));
+      upd = fmax(upd, mphi * A.vt_inv);
     }
-    upd = fmax(upd, partner(upd));
-    upd = fmax(upd, mphi * A.vt_inv);
 #ifdef PNP_LANE_STAMPS
-    {   // diagnosis build (tools/probe/lane_stamps.sh): cycles of the three passes of this iteration, summed per lane
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+    {   // diagnosis build (tools/probe/lane_stamps.sh): cycles of the passes of this iteration, summed per lane
       const unsigned long long ts3 = __builtin_readcyclecounter();
       stamp_f += (double)(ts1 - ts0);
       stamp_b += (double)(ts2 - ts1);
@@ -780,8 +917,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       stamp_n += 1.0;
     }
 #endif
-    // =========================== bookkeeping of the lane's operating point (identical in both halves) ========================
     alarm = fmax(alarm, partner(alarm));
+    // =========================== bookkeeping of the lane's operating point (identical in both halves) ========================
     if (have) {
       bool accept = false;
       if (lam == 1.0) {
@@ -804,6 +941,19 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             G.iters[b] = total_it;
           }
         }
+      }
+    }
+  }
+  // An operating point whose current state lives in the second buffer brings it home for the transpose-out kernel (each half its rows;
+  // once per launch: 2 (N+1) doubles per row against the ~215 of every Newton iteration)
+  if (__ballot(cur != 0) != 0ull) {
+    const int lo_ = side ? m + 1 : 0, cnt_ = side ? nx - 1 - m : m + 1;
+    const int nmax_ = (nx - 1 - m > m + 1) ? nx - 1 - m : m + 1;
+    for (int s = 0; s < nmax_; ++s) {
+      if (cur != 0 && s < cnt_) {
+        const int i = lo_ + s;
+#pragma unroll
+        for (int p = 0; p < VP; ++p) ts[((size_t)i * VP + p) * LG] = xs[((size_t)i * VP + p) * LG];
       }
     }
   }
@@ -871,9 +1021,22 @@ static hipError_t launch_lane_nb(const NewtonArgs& a0, hipStream_t stream) {
     const int64_t ng = groups - g0 < cap ? groups - g0 : cap;
     const dim3 tg((unsigned)ng, (unsigned)((a.nx + 63) / 64));
     hipLaunchKernelGGL((lane_transpose_kernel<true>), tg, dim3(256), 0, stream, a);
-    if (a.rt || a.convect) hipLaunchKernelGGL((newton_lane_kernel<NB, 2>), dim3((unsigned)ng), dim3(64), 0, stream, a);
-    else if (a.mpb) hipLaunchKernelGGL((newton_lane_kernel<NB, 1>), dim3((unsigned)ng), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((newton_lane_kernel<NB, 0>), dim3((unsigned)ng), dim3(64), 0, stream, a);
+    // FUSED (update inside the back-substitution, two state copies, no round trip of the Newton update: -8 % of the bytes) where the
+    // kernel is HBM-bound, i.e. from about three waves per CU on; below that the separate passes are faster (shorter dependent chains).
+    // One device, one call, libraries alternated (tools/probe/lane_rate.py; N = 8 steric, nx = 512, timesteps/s separate / fused):
+    // B = 32 768 1.645e6 / 1.727e6, 16 384 1.265e6 / 1.177e6, 8192 7.67e5 / 6.98e5; N = 6, nx = 1024, B = 32 768 1.031e6 / 1.130e6.
+    const bool fused = a.B >= 24576;
+    const int mode = (a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0);
+    const dim3 gk((unsigned)ng), bk(64);
+    if (fused) {
+      if (mode == 2) hipLaunchKernelGGL((newton_lane_kernel<NB, 2, true>), gk, bk, 0, stream, a);
+      else if (mode == 1) hipLaunchKernelGGL((newton_lane_kernel<NB, 1, true>), gk, bk, 0, stream, a);
+      else hipLaunchKernelGGL((newton_lane_kernel<NB, 0, true>), gk, bk, 0, stream, a);
+    } else {
+      if (mode == 2) hipLaunchKernelGGL((newton_lane_kernel<NB, 2, false>), gk, bk, 0, stream, a);
+      else if (mode == 1) hipLaunchKernelGGL((newton_lane_kernel<NB, 1, false>), gk, bk, 0, stream, a);
+      else hipLaunchKernelGGL((newton_lane_kernel<NB, 0, false>), gk, bk, 0, stream, a);
+    }
     hipLaunchKernelGGL((lane_transpose_kernel<false>), tg, dim3(256), 0, stream, a);
   }
   return hipGetLastError();
