@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
     sP.peq[lane] = G.peq[lane];
     sP.pe[lane] = G.pe[lane];
     sP.rs[lane] = G.rs[lane];
+    sP.qb[lane] = G.qb[lane];
   }
   if constexpr (FULL) {
     lane_stage_reaction_sides(sS, G.sides, lane);
@@ -265,9 +266,9 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
 #pragma unroll
           for (int kk = 0; kk < (N + 1) / 2; ++kk) {
             const int k0 = 2 * kk, k1 = 2 * kk + 1 < N ? 2 * kk + 1 : 2 * kk;
-            const double qb_ = h ? G.qb[k1] : G.qb[k0];
+            const double qb_ = P->qb[h ? k1 : k0];
             const double hc_ = h ? hc[k1] : hc[k0], ac_ = h ? ac[k1] : ac[k0];
-            const double u = sgn * __builtin_fma(qb_, dphi, dw) - (FULL ? (h ? P->pe[k1] : P->pe[k0]) * rwea : 0.0);
+            const double u = sgn * __builtin_fma(qb_, dphi, dw) - (FULL ? P->pe[h ? k1 : k0] * rwea : 0.0);
             const double cl = side ? ac_ : hc_, cr = side ? hc_ : ac_;
             const LEdge e = lane_edge_flux(u, cl, cr, wea);
             const double mJ = sgn * e.J, mBd = side ? e.Bm : e.Bp, mBn = side ? e.Bp : e.Bm, mJu = e.Ju;
@@ -501,6 +502,21 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
 #pragma unroll
             for (int r = 0; r < NB; ++r) Xl[r][jj] = r == k ? t_ : __builtin_fma(-pc[r], t_, Xl[r][jj]);
           }
+        }
+        // The next row's inputs (requested at the top of this row) are made to ARRIVE here, before this row's record stores are issued:
+        // vector memory operations retire in order and the compiler's wait-count bookkeeping is conservative across the loop's back
+        // edge -- left to itself it consumes these loads after the stores with s_waitcnt vmcnt(0), i.e. every row waits for its own
+        // record stores to reach memory (+4 k cycles per row at 1024 waves, tools/probe/lane4_stamps.sh with -DL4_NO_REC_STORE).
+        // After a whole row of arithmetic the loads have long landed; the stores then drain behind the next row.  (A sum that needs
+        // every loaded register, handed to an empty asm: values are only READ here -- redefining them under this
+        // block's partial execution mask loses them for the resting lanes.)
+        {
+          double touch = (p_vi + p_wea) + p_web;
+#pragma unroll
+          for (int p = 0; p < VP; ++p) touch += p_a[p][0];
+#pragma unroll
+          for (int p = 0; p < CP; ++p) touch += p_co[p][0];
+          asm volatile("" ::"v"(touch));
         }
         // ---- the record: this lane's columns, in 16-byte pairs ----------------------------------------------------------------------------------
         double held = 0.0;

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     sP.peq[lane] = G.peq[lane];
     sP.pe[lane] = G.pe[lane];
     sP.rs[lane] = G.rs[lane];
+    sP.qb[lane] = G.qb[lane];
   }
   if constexpr (FULL) {
     lane_stage_reaction_sides(sS, G.sides, lane);
@@ -163,7 +164,11 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     d2 p_a[VP], p_co[CP];
     double p_vi, p_wea, p_web;
     auto request = [&](int s) {
+#ifdef L4_NO_REQUEST      // (diagnosis build: every row reads the first one again -- cache hits)
+      const int i = fwd_row(0) + 0 * s;
+#else
       const int i = fwd_row(s);
+#endif
       const int ia = side ? i - 1 : i + 1;
 #pragma unroll
       for (int p = 0; p < VP; ++p) p_a[p] = TS(ia, p);
@@ -290,11 +295,12 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
             // (a group with fewer than four species: the spare lanes recompute its last one)
             auto clampk = [&](int k) { return k < N ? k : N - 1; };
             const int k0 = clampk(4 * kk), k1 = clampk(4 * kk + 1), k2 = clampk(4 * kk + 2), k3 = clampk(4 * kk + 3);
-            const double qb_ = q == 0 ? G.qb[k0] : (q == 1 ? G.qb[k1] : (q == 2 ? G.qb[k2] : G.qb[k3]));
+            const int kq = 4 * kk + q < N ? 4 * kk + q : N - 1;          // this lane's species of the group
+            const double qb_ = P->qb[kq];
             const double hc_ = q == 0 ? hc[k0] : (q == 1 ? hc[k1] : (q == 2 ? hc[k2] : hc[k3]));
             const double ac_ = q == 0 ? ac[k0] : (q == 1 ? ac[k1] : (q == 2 ? ac[k2] : ac[k3]));
             double pe_ = 0.0;
-            if constexpr (FULL) pe_ = q == 0 ? P->pe[k0] : (q == 1 ? P->pe[k1] : (q == 2 ? P->pe[k2] : P->pe[k3]));
+            if constexpr (FULL) pe_ = P->pe[kq];
             const double u = sgn * __builtin_fma(qb_, dphi, dw) - (FULL ? pe_ * rwea : 0.0);
             const double cl = side ? ac_ : hc_, cr = side ? hc_ : ac_;
             const LEdge e = lane_edge_flux(u, cl, cr, wea);
@@ -541,6 +547,21 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
             for (int r = 0; r < NB; ++r) Xl[r][jj] = r == k ? t_ : __builtin_fma(-pc[r], t_, Xl[r][jj]);
           }
         }
+        // The next row's inputs (requested at the top of this row) are made to ARRIVE here, before this row's record stores are issued:
+        // vector memory operations retire in order and the compiler's wait-count bookkeeping is conservative across the loop's back
+        // edge -- left to itself it consumes these loads after the stores with s_waitcnt vmcnt(0), i.e. every row waits for its own
+        // record stores to reach memory (+4 k cycles per row at 1024 waves, tools/probe/lane4_stamps.sh with -DL4_NO_REC_STORE).
+        // After a whole row of arithmetic the loads have long landed; the stores then drain behind the next row.  (A sum that needs
+        // every loaded register, handed to an empty asm: values are only READ here -- redefining them under this
+        // block's partial execution mask loses them for the resting lanes.)
+        {
+          double touch = (p_vi + p_wea) + p_web;
+#pragma unroll
+          for (int p = 0; p < VP; ++p) touch += p_a[p][0];
+#pragma unroll
+          for (int p = 0; p < CP; ++p) touch += p_co[p][0];
+          asm volatile("" ::"v"(touch));
+        }
         // ---- the record: this lane's columns, in 16-byte pairs (pairs of columns that do not exist are skipped) -----------------------------
         double held = 0.0;
 #pragma unroll
@@ -555,13 +576,19 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
                 d2 pr;
                 pr[0] = held;
                 pr[1] = 0.0;
+#ifndef L4_NO_REC_STORE
                 if ((e >> 1) < rp_valid) REC(i, e >> 1) = pr;
+#endif
               }
             } else {
               d2 pr;
               pr[0] = held;
               pr[1] = Xl[r][jj];
+#ifndef L4_NO_REC_STORE      // (diagnosis builds, tools/probe/lane4_stamps.sh: results are wrong)
               if ((e >> 1) < rp_valid) REC(i, e >> 1) = pr;
+#else
+              asm volatile("" :: "v"(pr));
+#endif
             }
           }
         // (middle row: x_m = the solved right-hand side now sits in its owner's t slot Tl[NB >> 2], where the hand-over below takes it;

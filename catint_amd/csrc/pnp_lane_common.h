@@ -52,6 +52,10 @@ inline double lane_pivot_limit(const Options* opt) { return (opt && opt->lane_pi
 struct LaneParams {
   double sig[PNP_NEWTON_MAX_SPECIES], peq[PNP_NEWTON_MAX_SPECIES];
   double pe[PNP_NEWTON_MAX_SPECIES], rs[PNP_NEWTON_MAX_SPECIES];      // MODE 2: convection v dx / D_k, reaction scale dx^2 / D_k
+  double qb[PNP_NEWTON_MAX_SPECIES];      // q_k beta for the lane-DEPENDENT accesses of the lane-pair / lane-quad kernels: a select between
+                                          // kernel-argument entries is turned into a select of ADDRESSES and a vector load from the argument
+                                          // segment -- with an s_waitcnt vmcnt(0) in the middle of every row, behind the prefetched inputs
+                                          // of the next row and the record stores of the previous one; an LDS read by index is neither
 };
 
 // Copy of the flattened reaction table in LDS (every lane of the wave copies its share of dwords; the caller synchronises).

@@ -4,7 +4,7 @@
 N=${1:-8}; NX=${2:-512}; B=${3:-8192}
 R=$PWD; D=/tmp/lane4stamps; mkdir -p $D/catint_amd
 cp -r $R/catint_amd/* $D/catint_amd/ && cp -r $R/tools $R/include $D/
-cd $D && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DPNP_LANE_STAMPS catint_amd/csrc/pnp_lane4.hip -o catint_amd/lib/obj/pnp_lane4.o || exit 1
+cd $D && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DPNP_LANE_STAMPS $EXTRA catint_amd/csrc/pnp_lane4.hip -o catint_amd/lib/obj/pnp_lane4.o || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC catint_amd/lib/obj/*.o -o catint_amd/lib/libcatint_pnp.so || exit 1
 CATINT_NEWTON_KERNEL=lane4 CATINT_LANE_ORDER=0 python3 - $N $NX $B <<'PY'
 import sys, numpy as np
