@@ -83,6 +83,8 @@ struct pnp_handle {
   int32_t* scf_i = nullptr;              // 3 B flags + 65 counters
   const int32_t* newton_mask = nullptr;  // lanes to solve (null: all)
   int32_t* user_mask = nullptr;          // pnp_set_lane_mask's copy
+  std::vector<int32_t> user_mask_host;   // ... and on the host: a masked solve is sized (kernel choice, lane groups) by the lanes it solves
+  int64_t user_mask_count = 0;
   bool newton_explicit_kinetics = false; // the wall-kinetics table feeds the prescribed fluxes instead of the Jacobian
   int cur = 0;  // lapl[cur] = charge row of the current state; lapl[1-cur] = row used by the last step
   // pnp_step with several launches in one call: the batch is cut into row chunks whose launch sequences run on streams of their own
@@ -683,11 +685,14 @@ static int step_streams(const pnp_handle* h, int launches) {
 static int lane_order(pnp_handle* h, NewtonArgs& a) {
   a.lane_perm = nullptr;
   const int64_t B = h->B;
-  if (h->opt.lane_order == 0 || B < 64) return PNP_OK;
+  // a solve restricted by pnp_set_lane_mask (the rerun ladder's confirming solve: a handful of recovered lanes): only the lanes it solves
+  // are dealt to slots, and the launch covers ceil(n / points per group) groups instead of the whole batch
+  const bool masked = h->newton_mask && h->newton_mask == h->user_mask && (int64_t)h->user_mask_host.size() == B && h->user_mask_count < B;
+  if ((h->opt.lane_order == 0 || B < 64) && !masked) return PNP_OK;
   if (!h->lane_perm) HIP_TRY(h, dev_alloc(h, &h->lane_perm, (size_t)h->cfg.batch_capacity));
   std::vector<int32_t>& perm = h->lane_perm_host;
   perm.resize((size_t)B);
-  if (h->iters_valid) {
+  if (h->iters_valid && h->opt.lane_order != 0 && B >= 64) {
     std::vector<int32_t>& it = h->lane_iters_host;
     it.resize((size_t)B);
     HIP_TRY(h, hipMemcpyAsync(it.data(), h->iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -703,12 +708,21 @@ static int lane_order(pnp_handle* h, NewtonArgs& a) {
       const int k = it[b] < 0 ? 0 : (it[b] >= KMAX ? KMAX - 1 : it[b]);
       perm[(size_t)start[KMAX - 1 - k]++] = (int32_t)b;
     }
-  } else if ((int64_t)h->lane_key.size() == B) {
+  } else if ((int64_t)h->lane_key.size() == B && h->opt.lane_order != 0 && B >= 64) {
     for (int64_t b = 0; b < B; ++b) perm[(size_t)b] = (int32_t)b;
     const std::vector<float>& key = h->lane_key;
     std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return key[(size_t)x] > key[(size_t)y]; });
+  } else if (masked) {
+    for (int64_t b = 0; b < B; ++b) perm[(size_t)b] = (int32_t)b;
   } else {
     return PNP_OK;
+  }
+  if (masked) {      // keep the order, drop the lanes that are not solved
+    size_t n = 0;
+    for (int64_t s_ = 0; s_ < B; ++s_)
+      if (h->user_mask_host[(size_t)perm[(size_t)s_]] != 0) perm[n++] = perm[(size_t)s_];
+    for (size_t s_ = n; s_ < (size_t)B; ++s_) perm[s_] = perm[n > 0 ? n - 1 : 0];
+    a.B = (int64_t)n;
   }
   HIP_TRY(h, hipMemcpyAsync(h->lane_perm, perm.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));        // (the host vector may be rewritten by the next call)
@@ -762,9 +776,13 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   // a side has at most PNP_MAX_REACTANTS reactants and the form keeps them one by one)
   const int variant = (a.rt && h->rs_max_exponent > PNP_MAX_REACTANTS) ? 3 : ((a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0));
   a.opt = &h->opt;
-  const bool use_lane4 = newton_lane4_preferred(N + 1, nx, h->B, variant, h->opt);
-  const bool use_lane2 = !use_lane4 && newton_lane2_preferred(N + 1, nx, h->B, variant, h->opt);
-  const bool use_lane = !use_lane4 && !use_lane2 && newton_lane_preferred(N + 1, nx, h->B, variant, h->opt);
+  // (a solve restricted to a few lanes by pnp_set_lane_mask is sized by those lanes: the workgroup-per-point kernels skip masked-out
+  // points at once, the lane kernels would walk every group)
+  const bool host_mask = h->newton_mask && h->newton_mask == h->user_mask && (int64_t)h->user_mask_host.size() == h->B;
+  const int64_t n_eff = host_mask ? (h->user_mask_count > 0 ? h->user_mask_count : 1) : h->B;
+  const bool use_lane4 = newton_lane4_preferred(N + 1, nx, n_eff, variant, h->opt);
+  const bool use_lane2 = !use_lane4 && newton_lane2_preferred(N + 1, nx, n_eff, variant, h->opt);
+  const bool use_lane = !use_lane4 && !use_lane2 && newton_lane_preferred(N + 1, nx, n_eff, variant, h->opt);
   if (use_lane4) {
     const size_t per_group = (newton_lane4_rec_doubles(N + 1, nx) + newton_lane4_state_doubles(N + 1, nx)) * sizeof(double);
     if (!h->lane4_buf) {
@@ -860,6 +878,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   if (use_lane4 || use_lane2 || use_lane) {
     const int rc = lane_order(h, a);
     if (rc != PNP_OK) return rc;
+    if (a.B == 0) return PNP_OK;        // (a mask without a lane: nothing to solve)
   }
   if (use_lane4) HIP_TRY(h, launch_newton_lane4(a, h->stream));
   else if (use_lane2) HIP_TRY(h, launch_newton_lane2(a, h->stream));
@@ -1179,6 +1198,9 @@ int pnp_set_lane_mask(pnp_handle* h, const int32_t* mask) {
     h->newton_mask = nullptr;
     return PNP_OK;
   }
+  h->user_mask_host.assign(mask, mask + h->B);
+  h->user_mask_count = 0;
+  for (int64_t b = 0; b < h->B; ++b) h->user_mask_count += mask[b] != 0 ? 1 : 0;
   if (!h->user_mask) HIP_TRY(h, dev_alloc(h, &h->user_mask, (size_t)h->cfg.batch_capacity));
   HIP_TRY(h, hipMemcpyAsync(h->user_mask, mask, (size_t)h->B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -184,11 +184,12 @@ def test_not_converged_and_nan_are_reported_per_lane():
     assert (its[st == 1] == 4).all()                     # maxit + 1 marks a failed solve
 
 
-@pytest.mark.parametrize("kernel", ['lane', 'team'])
+@pytest.mark.parametrize("kernel", ['lane', 'lane2', 'lane4', 'team'])
 def test_lane_mask_and_set_lanes(kernel, monkeypatch):
     """pnp_set_lane_mask / pnp_set_lanes, the two entry points behind the rerun ladder (reference catint/calculator.py:466-531): a solve
     restricted to some lanes leaves the others bit for bit alone; lanes recovered elsewhere are patched in without touching the rest
-    of the batch and the confirming solve needs one iteration."""
+    of the batch and the confirming solve needs one iteration.  (A masked solve of the lane kernels deals only the lanes it solves to
+    slots and launches the groups they fill -- pnp_capi.hip: lane_order.)"""
     monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
     N, nx, B = 6, 64, 70
     D, q, cb, dx, phiM = make_lanes(N, nx, B, 11)
