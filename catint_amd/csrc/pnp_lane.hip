@@ -1006,7 +1006,10 @@ bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode, const Options& 
   // B = 1024 1.16e5 / 1.00e5 / 1.40e5, 2048 2.40e5 / 1.96e5 / 1.43e5, 4096 4.51e5 / 3.85e5 / 1.44e5, 8192 7.31e5 / 7.07e5 / 1.51e5,
   // 16 384 0.99e6 / 1.03e6.  Twice the waves for the same batch, but the distribution overhead (selects, DPP moves, duplicated
   // assembly) leaves a wave's pace only 1.28 x the lane kernel's and two waves on a CU cost each other ~20 %.
-  return B >= 1280 && B < 10240;
+  // Round 4: below 10 240 points the lane-quad kernel (pnp_lane4.hip) is ahead of both; the pair keeps the window up to the lane
+  // kernel's crossover (profiles/r04_lane4_probe.jsonl: B = 12 288 lane pair 9.96e5 / lane 9.55e5 / lane quad 7.78e5; 16 384 1.05e6 /
+  // 1.10e6 / 0.87e6).
+  return B >= 1280 && B < 14336;
 }
 
 template <int NB>

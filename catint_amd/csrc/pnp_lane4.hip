@@ -893,11 +893,13 @@ bool newton_lane4_preferred(int nb, int nx, int64_t B, int mode, const Options& 
   if (!newton_lane4_supported(nb, nx, mode)) return false;
   if (opt.newton_kernel != NK_AUTO) return opt.newton_kernel == NK_LANE4;
   // Measured on one device in one process (tools/probe/lane4_probe.py -> profiles/r04_lane4_probe.jsonl; N = 8 steric, nx = 512,
-  // timesteps/s, lane quad / lane pair / lane / lane teams): B = 1024 1.64e5 / 1.22e5 / 1.01e5 / 1.38e5, 2048 3.33e5 / 2.38e5 / 1.98e5 /
-  // 1.41e5, 4096 5.33e5 / 4.54e5 / 3.89e5 / 1.44e5, 8192 8.52e5 / 7.26e5 / 7.34e5, 16 384 0.83e6 / 1.01e6 / 1.09e6; nx = 4096:
-  // B = 2048 3.9e4 / 2.9e4 / 2.5e4, 8192 1.02e5 / 0.93e5 / 0.90e5.  Eight points per wave: the chip is full at 8192 points and the
-  // kernel saturates there (a wave's row costs ~2000 vector instructions for 8 points against ~4200 for the lane kernel's 32).
-  return B >= 896 && B < 12288;
+  // timesteps/s, lane quad / lane pair / lane / lane teams): B = 1024 1.66e5 / 1.19e5 / 1.00e5 / 1.38e5, 2048 3.24e5 / 2.32e5 / 1.97e5 /
+  // 1.41e5, 4096 5.61e5 / 4.46e5 / 3.86e5 / 1.45e5, 8192 9.09e5 / 7.43e5 / 7.18e5, 12 288 7.78e5 / 9.96e5 / 9.55e5, 16 384 0.87e6 /
+  // 1.05e6 / 1.10e6; nx = 4096: B = 2048 3.97e4 / 2.86e4 / 2.49e4, 8192 1.10e5 / 0.97e5 / 0.92e5; N = 6, nx = 1024: 8192 6.50e5 / 5.53e5 /
+  // 5.26e5, 16 384 6.98e5 / 8.28e5 / 8.15e5.  Eight points per wave: the chip is full at 8192 points (one wave per SIMD) and the
+  // kernel saturates there; beyond, a second round of waves per SIMD costs more than the lane pair's and the lane kernel's larger
+  // waves (a wave's row: ~2000 vector instructions for 8 points against ~4200 for the lane kernel's 32).
+  return B >= 896 && B < 10240;
 }
 
 }  // namespace pnp

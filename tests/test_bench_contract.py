@@ -41,7 +41,7 @@ def check_line(d, with_cpu=True):
 
 
 def test_committed_bench_line_of_the_drivers_command():
-    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r03_bench_line_steps20.json')).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r04_bench_line_steps20.json')).read().strip().splitlines()[-1])
     check_line(d)
     assert d['steps'] == 20 and d['warmup'] == 5 and d['n_gpus'] == 1 and d['lanes_ok'] == d['lanes_total']
     assert r'configs[1]' in d['config']['workload']
@@ -50,9 +50,25 @@ def test_committed_bench_line_of_the_drivers_command():
     pm, bc = d['physical_mode'], d['beyond_cache']
     for k in ('large_batch_8_species', 'large_batch_8_species_32k', 'config3_share', 'config4_share', 'configs2_co2r_sweep'):
         assert k in pm and 'error' not in pm[k], k
-    assert pm['configs2_co2r_sweep']['lanes_converged'] == 4096
+    c2 = pm['configs2_co2r_sweep']
+    assert c2['lanes_converged'] == 4096 and c2['lanes_handed_back_by_the_pivot_monitor'] == 0
+    assert c2['newton_iterations_per_s'] > 0 and 0.0 < c2['roofline']['frac'] < 1.0
+    assert pm['config4_share']['roofline']['traffic'] is not None      # counters for the configs[4] share
     for k in ('per_step_launch', 'fused_32_steps_per_launch', 'beyond_cache_config4'):
         assert 0.2 < bc[k]['frac'] < 1.0
+
+
+def test_committed_two_rank_line_is_one_json_document():
+    """`CATINT_DIST_BACKEND=gloo python bench.py --gpus 2 ...` on a one-GPU box: the committed stdout is ONE JSON document (gloo / RCCL
+    chatter goes to stderr) with the per-rank shares of configs[3] / configs[4] and the start skew of the aligned timed regions."""
+    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r04_bench_line_gpus2_gloo_rehearsal.json')).read())
+    check_line(d, with_cpu=False)
+    assert d['n_gpus'] == 2 and len(d['per_rank_timesteps_per_s']) == 2 and d['start_skew_us'] < 1000.0
+    for key in ('configs3_share', 'configs4_share'):
+        for leg in ('compat_per_step', 'newton'):
+            r = d[key][leg]
+            assert r['lanes_ok'] == r['lanes_total'] and len(r['per_rank_timesteps_per_s']) == 2
+            assert r['value'] == pytest.approx(sum(r['per_rank_timesteps_per_s']), rel=0.2)
 
 
 @pytest.mark.gpu

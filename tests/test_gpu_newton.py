@@ -190,11 +190,11 @@ def test_two_sided_sweep_equals_the_one_sided_sweep(monkeypatch):
 
 
 def test_kernel_choice_for_large_batches_of_large_blocks(monkeypatch):
-    # N >= 5 species: 896 <= B < 12 288 operating points take the lane-quad kernel (pnp_lane4.hip), larger batches the lane kernel
+    # N >= 5 species: 896 <= B < 10 240 operating points take the lane-quad kernel (pnp_lane4.hip), up to 14 336 the lane pair, larger batches the lane kernel
     # (pnp_lane.hip; measured crossovers, profiles/r03_lane_sweep.jsonl, profiles/r04_lane4_probe.jsonl): the default equals the forced
     # kernel bit for bit; the sweep kernels (one lane team per operating point, one- and two-sided) stay selectable and give the same
     # answers and iteration counts as the lane-team kernel
-    N, nx, B = 5, 24, 12288
+    N, nx, B = 5, 24, 16384
     monkeypatch.delenv('CATINT_NEWTON_KERNEL', raising=False)
     q0 = run_gpu_only(N, nx, 2048, 4)
     monkeypatch.setenv('CATINT_NEWTON_KERNEL', 'lane4')
