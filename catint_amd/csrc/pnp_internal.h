@@ -20,6 +20,8 @@ struct Options {
   int newton_sweep_blocks = 0;       // NEWTON_SWEEP_BLOCKS: waves the sweep kernels' workspace holds
   double lane_pivot_limit = 0.0;     // LANE_PIVOT_LIMIT: pivot monitor of the lane kernels (0: PIVOT_GROWTH_LIMIT)
   int lane_order = 1;                // LANE_ORDER = 0: slot s holds operating point s
+  int lane_stagger = -1;             // LANE_STAGGER: start delay between the four phase groups of the lane-quad kernel's waves, in units of
+                                     // ~4 us (s_sleep 127); -1: the kernel's own choice, 0: none
   int pnp_kernel = 0;                // PNP_KERNEL = 2 (LDS-staged step_kernel) | 4 (register-resident) | 5, 6, 7 (streaming)
   int pnp_waves_per_grid = 0;        // PNP_WAVES_PER_GRID
   int pnp_species_per_wave = 0;      // PNP_SPECIES_PER_WAVE
@@ -207,6 +209,7 @@ struct NewtonArgs {
   int32_t lane_lg, pad3_;                // operating points per group: 32 (lane kernel) or 16 (lane-pair kernel, pnp_lane2.hip)
   double lane_pivot_limit;               // pivot monitor of the lane kernels (pnp_lane_common.h): multipliers beyond this mark the lane
   const Options* opt;                    // HOST pointer (the launchers' kernel choice); never dereferenced on the device
+  int32_t lane_stagger, pad5_;           // lane-quad kernel: wave g starts (g & 3) * lane_stagger sleep periods late (see pnp_lane4.hip)
 };
 int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);

@@ -132,6 +132,11 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
   double upd_prev = INFINITY, upd_prev2 = INFINITY;
   double alarm = 0.0;            // pivot monitor (sticky)
+  // Phase stagger: every wave of a launch starts with a forward pass (writes, ~75 % of an iteration) followed by a back-substitution
+  // that reads its records back at several TB/s -- with one wave per SIMD and equal row times the whole chip is in the same pass at
+  // the same time, the back-substitutions of all 1024 waves hit HBM together (5 TB/s, 2.7 x the cycles per row of a wave alone on the
+  // chip) and the forward passes leave it idle.  Four groups of waves start a quarter of an iteration apart.
+  for (int z = (int)(g & 3) * G.lane_stagger; z > 0; --z) __builtin_amdgcn_s_sleep(127);
 #ifdef PNP_LANE_STAMPS
   double stamp_f = 0.0, stamp_b = 0.0, stamp_u = 0.0, stamp_n = 0.0;
 #endif
@@ -865,6 +870,7 @@ static hipError_t launch_lane4_nb(const NewtonArgs& a0, hipStream_t stream) {
     a.lane_group0 = g0;
     a.lane_lg = QG;
     a.lane_pivot_limit = lane_pivot_limit(a.opt);
+    a.lane_stagger = (a.opt && a.opt->lane_stagger >= 0) ? a.opt->lane_stagger : 0;
     const int64_t ng = groups - g0 < cap ? groups - g0 : cap;
     hipError_t e = launch_lane_transpose(a, ng, true, stream);
     if (e != hipSuccess) return e;
