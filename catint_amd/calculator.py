@@ -262,7 +262,10 @@ class Calculator(object):
         stern = tp.system.get('wall potential', 'stern') == 'stern' and cs > 0
         s.set_newton(wall_bc='stern' if stern else 'dirichlet', stern_capacitance=cs if stern else 0.0,
                      phi_pzc=float(tp.system.get('phiPZC', 0.0)), tol=nk.get('tol', 1e-8), maxit=nk.get('maxit', 50),
-                     dphi_max=nk.get('dphi_max', 0.05), mpb_radius=radii if any(radii) else None)
+                     dphi_max=nk.get('dphi_max', 0.05), mpb_radius=radii if any(radii) else None,
+                     # time-dependent mode: tp.newton['time_order'] = 2 steps with BDF2, the formula the reference's transient study
+                     # asks COMSOL for (comsol_model.py:518-531: BDF, maxorder 2); default backward Euler
+                     time_order=int(nk.get('time_order', 1)))
         if xmesh is not None:
             s.set_grid(xmesh)
         elif not getattr(tp, 'mesh_uniform', True):

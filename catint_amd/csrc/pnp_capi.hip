@@ -50,6 +50,9 @@ struct pnp_handle {
   double* work = nullptr;
   double* stash = nullptr;
   ReactionTable* rt_dev = nullptr;
+  double* c_old2 = nullptr;                 // BDF2 (pnp_newton_params.time_order = 2): the time level before the previous one
+  int32_t* bdf_acc = nullptr;               // ... and per-lane iteration counts / status summed over the launches of one pnp_step call
+  int nw_ext_old = 0;                       // set around a BDF2 step: c_old is prepared, sig carries the factor 3/2
   ReactionSides* rs_dev = nullptr;          // the table flattened per reaction side (lane kernels)
   int rs_max_exponent = 0;
   int n_wk = 0;
@@ -185,7 +188,7 @@ void pnp_destroy(pnp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->c, (void*)h->lapl[0], (void*)h->lapl[1], (void*)h->v, (void*)h->gradv, (void*)h->rates,
                   (void*)h->pb, (void*)h->vzeta, (void*)h->flux, (void*)h->cbulk, (void*)h->csurf, (void*)h->status,
-                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->rs_dev, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->lane2_buf, (void*)h->lane4_buf, (void*)h->lane_perm, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int, (void*)h->rkc_d, (void*)h->rkc_i})
+                  (void*)h->spec, (void*)h->ytmp, (void*)h->ftmp, (void*)h->c_old, (void*)h->work, (void*)h->iters, (void*)h->stash, (void*)h->rt_dev, (void*)h->rs_dev, (void*)h->c_old2, (void*)h->bdf_acc, (void*)h->wk_k, (void*)h->gw, (void*)h->gv, (void*)h->mol_lapl, (void*)h->scf_d, (void*)h->scf_i, (void*)h->scf_snap, (void*)h->stage, (void*)h->sweep, (void*)h->lane_buf, (void*)h->lane2_buf, (void*)h->lane4_buf, (void*)h->lane_perm, (void*)h->user_mask, (void*)h->ode_buf, (void*)h->ode_int, (void*)h->rkc_d, (void*)h->rkc_i})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -731,6 +734,59 @@ static int lane_order(pnp_handle* h, NewtonArgs& a) {
   return PNP_OK;
 }
 
+// ---- BDF2 (pnp_newton_params.time_order = 2; the reference's transient study asks COMSOL for BDF with maxorder 2, comsol_model.py:518-531)
+// (3 c_n+1 - 4 c_n + c_n-1) / (2 dt) = (3/2) (c_n+1 - c*) / dt with c* = (4 c_n - c_n-1) / 3: a backward-Euler step against the
+// combination c* with 1/dt scaled by 3/2.  One launch per timestep: c* is prepared here, the kernels take it as their previous level.
+__global__ void bdf2_prepare_kernel(const double* __restrict__ c, double* __restrict__ c2, double* __restrict__ cstar, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double cn = c[i];
+    cstar[i] = (4.0 * cn - c2[i]) / 3.0;
+    c2[i] = cn;
+  }
+}
+// per-lane bookkeeping over the launches of one call: iteration counts add up, the worst status stays
+__global__ void bdf2_accumulate_kernel(int32_t* __restrict__ acc, int32_t* __restrict__ iters, int32_t* __restrict__ status, int64_t B, int last) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int32_t it = acc[b] + iters[b], st = status[b] > acc[B + b] ? status[b] : acc[B + b];
+  acc[b] = it;
+  acc[B + b] = st;
+  if (last) {
+    iters[b] = it;
+    status[b] = st;
+  }
+}
+
+static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, int maxit);
+
+// nsteps timesteps of the physical mode: one launch (backward Euler), or one launch per step (BDF2)
+static int newton_timesteps(pnp_handle* h, int nsteps) {
+  if (h->np.time_order != 2 || nsteps < 1) return run_newton(h, nsteps, false, 0.0, 0);
+  const size_t n = (size_t)h->B * h->a.N * h->a.ldx;
+  const int64_t B = h->B;
+  if (!h->c_old2) HIP_TRY(h, dev_alloc(h, &h->c_old2, (size_t)h->cfg.batch_capacity * h->a.N * h->a.ldx));
+  if (!h->bdf_acc) HIP_TRY(h, dev_alloc(h, &h->bdf_acc, (size_t)h->cfg.batch_capacity * 2));
+  HIP_TRY(h, hipMemsetAsync(h->bdf_acc, 0, (size_t)B * 2 * sizeof(int32_t), h->stream));
+  for (int s = 0; s < nsteps; ++s) {
+    if (h->steps_done == 0) {      // first step of a trajectory: backward Euler, and c_0 is the level before the next step's previous one
+      HIP_TRY(h, hipMemcpyAsync(h->c_old2, h->c, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      const int rc = run_newton(h, 1, false, 0.0, 0);
+      if (rc != PNP_OK) return rc;
+    } else {
+      hipLaunchKernelGGL(bdf2_prepare_kernel, dim3(2048), dim3(256), 0, h->stream, (const double*)h->c, h->c_old2, h->c_old, n);
+      HIP_TRY(h, hipGetLastError());
+      h->nw_ext_old = 1;
+      const int rc = run_newton(h, 1, false, 0.0, 0);
+      h->nw_ext_old = 0;
+      if (rc != PNP_OK) return rc;
+    }
+    hipLaunchKernelGGL(bdf2_accumulate_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, h->bdf_acc, h->iters, h->status, B,
+                       s + 1 == nsteps ? 1 : 0);
+    HIP_TRY(h, hipGetLastError());
+  }
+  return PNP_OK;
+}
+
 // physical mode: nsteps backward-Euler steps (stationary: one solve with 1/dt = 0) in one launch
 static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, int maxit) {
   NewtonArgs a;
@@ -758,7 +814,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   double qmax = 1.0;
   for (int k = 0; k < N; ++k) {
     a.qb[k] = h->qk[k] * beta;
-    a.sig[k] = stationary ? 0.0 : dx * dx / (h->Dk[k] * dt);
+    a.sig[k] = stationary ? 0.0 : (h->nw_ext_old ? 1.5 : 1.0) * (dx * dx / (h->Dk[k] * dt));
     a.fl[k] = dx / h->Dk[k];
     a.peq[k] = dx * dx / eps * h->qk[k];
     a.vol[k] = h->volk[k];
@@ -776,6 +832,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   // (variant 3 is supported by none of the lane kernels: a guard for tables their flattened form could not hold -- none at present,
   // a side has at most PNP_MAX_REACTANTS reactants and the form keeps them one by one)
   const int variant = (a.rt && h->rs_max_exponent > PNP_MAX_REACTANTS) ? 3 : ((a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0));
+  a.ext_old = (h->nw_ext_old && !stationary) ? 1 : 0;
   a.opt = &h->opt;
   // (a solve restricted to a few lanes by pnp_set_lane_mask is sized by those lanes: the workgroup-per-point kernels skip masked-out
   // points at once, the lane kernels would walk every group)
@@ -897,6 +954,7 @@ int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_
   if (p->wall_bc != 0 && p->wall_bc != 1) return fail(h, PNP_EINVAL, "pnp_set_newton: wall_bc must be 0 (Dirichlet) or 1 (Stern)");
   if (p->wall_bc == 1 && !(p->stern_capacitance > 0)) return fail(h, PNP_EINVAL, "pnp_set_newton: Stern capacitance must be positive");
   if (p->maxit < 1 || !(p->tol > 0)) return fail(h, PNP_EINVAL, "pnp_set_newton: maxit >= 1 and tol > 0 required");
+  if (p->time_order < 0 || p->time_order > 2) return fail(h, PNP_EINVAL, "pnp_set_newton: time_order must be 0, 1 (backward Euler) or 2 (BDF2)");
   h->np = *p;
   h->mpb = false;
   for (int k = 0; k < h->a.N; ++k) {
@@ -1002,7 +1060,7 @@ int pnp_solve_surface(pnp_handle* h, const double* flux, int32_t nsteps, double*
   const int N = h->a.N, ldx = h->a.ldx;
   // everything below is queued on the handle's stream; one synchronisation at the end
   if (flux) HIP_TRY(h, hipMemcpyAsync(h->flux, flux, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  const int rc = run_newton(h, nsteps == 0 ? 1 : nsteps, nsteps == 0, 0.0, 0);
+  const int rc = nsteps == 0 ? run_newton(h, 1, true, 0.0, 0) : newton_timesteps(h, nsteps);
   if (rc != PNP_OK) return rc;
   std::vector<double> p01;
   if (csurf) {
@@ -1216,7 +1274,7 @@ int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch) {
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   if (h->newton) {
     if (nsteps == 0) return PNP_OK;
-    return run_newton(h, nsteps, false, 0.0, 0);
+    return newton_timesteps(h, nsteps);
   }
   int spl = steps_per_launch <= 0 ? 256 : steps_per_launch;   // kernel boundaries cost ~6 us each
   if (h->a.has_rates) spl = 1;

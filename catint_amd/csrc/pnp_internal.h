@@ -209,7 +209,9 @@ struct NewtonArgs {
   int32_t lane_lg, pad3_;                // operating points per group: 32 (lane kernel) or 16 (lane-pair kernel, pnp_lane2.hip)
   double lane_pivot_limit;               // pivot monitor of the lane kernels (pnp_lane_common.h): multipliers beyond this mark the lane
   const Options* opt;                    // HOST pointer (the launchers' kernel choice); never dereferenced on the device
-  int32_t lane_stagger, pad5_;           // lane-quad kernel: wave g starts (g & 3) * lane_stagger sleep periods late (see pnp_lane4.hip)
+  int32_t lane_stagger;
+  int32_t ext_old;                       // 1: c_old holds the previous-level combination of this (single) step, prepared by the caller
+                                         // (BDF2: (4 c_n - c_n-1)/3, with sig scaled by 3/2); the kernels do not overwrite it           // lane-quad kernel: wave g starts (g & 3) * lane_stagger sleep periods late (see pnp_lane4.hip)
 };
 int newton_threads(int nb, int nx);
 size_t newton_exchange_doubles(int nb, int nx);

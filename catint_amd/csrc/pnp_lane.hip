@@ -90,10 +90,30 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
         if (i0 + ii < nx && op < LGr) {
           const double val = tile[op][ii];
           ts[(((size_t)(i0 + ii) * VP + (v >> 1)) * LGr + op) * 2 + (v & 1)] = val;
-          if (v < N) tco[(((size_t)(i0 + ii) * CP + (v >> 1)) * LGr + op) * 2 + (v & 1)] = val;
+          if (v < N && !G.ext_old) tco[(((size_t)(i0 + ii) * CP + (v >> 1)) * LGr + op) * 2 + (v & 1)] = val;
         }
       }
       __syncthreads();
+      if (G.ext_old && v < N) {      // the previous-level combination prepared by the caller (BDF2) instead of the state itself
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int op = rr * 4 + (t >> 6), ii = t & 63;
+          const int64_t slot = b0 + op;
+          double val = 0.0;
+          if (op < LGr && slot < G.B && i0 + ii < nx) {
+            const int64_t b = G.lane_perm ? G.lane_perm[slot] : slot;
+            val = G.c_old[((size_t)b * N + v) * ldx + i0 + ii];
+          }
+          tile[op][ii] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int ii = rr * 8 + (t >> 5), op = t & 31;
+          if (i0 + ii < nx && op < LGr) tco[(((size_t)(i0 + ii) * CP + (v >> 1)) * LGr + op) * 2 + (v & 1)] = tile[op][ii];
+        }
+        __syncthreads();
+      }
     } else {
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
@@ -211,7 +231,8 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     const NewtonArgs& A = G;
     tsc = cur ? xs : ts;
     tsn = cur ? ts : xs;
-    const bool first = fresh;          // first iteration of a timestep: the previous time level is the state itself
+    // first iteration of a timestep: the previous time level is the state itself -- unless the caller prepared it (BDF2: G.ext_old)
+    const bool first = fresh && !G.ext_old;
     if (fresh) {
       it = 0;
       upd_prev = upd_prev2 = INFINITY;

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
     const NewtonArgs& A = G;
-    const bool first = fresh;
+    // first iteration of a timestep: the previous time level is the state itself -- unless the caller prepared it (BDF2: G.ext_old)
+    const bool first = fresh && !G.ext_old;
     if (fresh) {
       it = 0;
       upd_prev = upd_prev2 = INFINITY;

@@ -593,7 +593,8 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
     const double phiM = A.pb[b * 4 + 0], phiB = A.pb[b * 4 + 1];
     int total_it = 0, st = PNP_STATUS_OK;
     for (int step = 0; step < A.nsteps; ++step) {
-      for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
+      if (!A.ext_old)
+        for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
       double upd_prev = INFINITY, upd_prev2 = INFINITY;       // scaled update of the previous full (undamped) iteration
@@ -807,7 +808,8 @@ __global__ __launch_bounds__(NB >= 5 ? 256 : 512) void newton_pair_kernel(const 
     const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
     int total_it = 0, st = PNP_STATUS_OK;
     for (int step = 0; step < A.nsteps; ++step) {
-      for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
+      if (!A.ext_old)
+        for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
       double upd_prev = INFINITY, upd_prev2 = INFINITY;       // scaled update of the previous full (undamped) iteration
@@ -1405,7 +1407,8 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
     const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
     int total_it = 0, st = PNP_STATUS_OK;
     for (int step = 0; step < A.nsteps; ++step) {
-      for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
+      if (!A.ext_old)
+        for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
       double upd_prev = INFINITY, upd_prev2 = INFINITY;       // scaled update of the previous full (undamped) iteration
@@ -1734,7 +1737,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
     if (__ballot(have && fresh) != 0ull) {
       for (int e = r0_; e < N * ldx; e += NB) {
         const double v = c[e];
-        if (have && fresh) co[e] = v;
+        if (have && fresh && !G.ext_old) co[e] = v;
       }
       team_sync();
     }
@@ -1986,7 +1989,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep2_kernel(const NewtonArgs G
     if (__ballot(have && fresh) != 0ull) {      // previous time level: each team of the pair copies every other stripe
       for (int e = r0_ + side * NB; e < N * ldx; e += 2 * NB) {
         const double v = c[e];
-        if (have && fresh) co[e] = v;
+        if (have && fresh && !G.ext_old) co[e] = v;
       }
       team_sync();
     }

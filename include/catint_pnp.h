@@ -213,6 +213,10 @@ typedef struct pnp_newton_params {
                               *    iteration improves; the state is then accurate to that noise (<= 100 tol), not to tol.  A linearly
                               *    converging iteration (monotone) does not qualify: it runs on to tol or to maxit (PNP_STATUS_MAXIT). */
   double dphi_max;           /* potential limiting per iteration (V); <= 0 disables */
+  int32_t time_order;        /* pnp_step: 0 or 1 backward Euler (default); 2 = BDF2, the time stepping the reference asks COMSOL for
+                              *    (comsol_model.py:518-531: tds time solver, "maxorder" 2): (3 c_n+1 - 4 c_n + c_n-1) / (2 dt), the first
+                              *    step of a trajectory (after pnp_set_batch) backward Euler.  One launch per timestep in this mode. */
+  int32_t reserved;          /* 0 */
 } pnp_newton_params;
 /* mpb_radius[N] (m, nullable = point ions): size-modified drift with phi0 = N_A sum a_k^3 c_k
  * (tp.species[sp]['MPB_radius'], comsol_model.py:1041-1063). */

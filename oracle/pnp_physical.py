@@ -358,11 +358,21 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
     return c, phi, maxit + 1, hist
 
 
-def integrate(p, c0, phi0, dt, nsteps, **kw):
+def integrate(p, c0, phi0, dt, nsteps, bdf2=False, **kw):
+    """nsteps implicit timesteps.  Backward Euler, or (bdf2=True) the second-order backward differentiation formula the reference's
+    transient study asks COMSOL for (comsol_model.py:518-531: BDF, maxorder 2): (3 c_n+1 - 4 c_n + c_n-1) / (2 dt) -- a backward-Euler
+    step of length dt / 1.5 against the combination c* = (4 c_n - c_n-1) / 3; the first step is backward Euler."""
     c, phi = c0.copy(), phi0.copy()
+    c_prev = None
     its = []
     for _ in range(nsteps):
-        c, phi, it, _ = newton_step(p, c, phi, c, dt, **kw)
+        if bdf2 and c_prev is not None:
+            cstar = (4.0 * c - c_prev) / 3.0
+            c_prev = c
+            c, phi, it, _ = newton_step(p, c, phi, cstar, dt / 1.5, **kw)
+        else:
+            c_prev = c
+            c, phi, it, _ = newton_step(p, c, phi, c, dt, **kw)
         its.append(it)
     return c, phi, its
 

@@ -93,9 +93,8 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
             cc, ph, it, _ = PH.newton_step(p, cc, ph, cc, np.inf, **okw)
             ref_it[b] = it
         else:
-            for _ in range(nsteps):
-                cc, ph, it, _ = PH.newton_step(p, cc, ph, cc, dt, **okw)
-                ref_it[b] += it
+            cc, ph, its_b = PH.integrate(p, cc, ph, dt, nsteps, bdf2=newton_kw.get('time_order', 1) == 2, **okw)
+            ref_it[b] = sum(its_b)
         ref_c[b], ref_phi[b] = cc, ph
     return (c, phi, its, st), (ref_c, ref_phi, ref_it)
 
@@ -547,6 +546,65 @@ def test_fuzz_case_117_stops_at_the_rounding_floor(kernel, monkeypatch):
     assert (st == 0).all() and rit[0] == 21
     assert abs(int(its[0]) - int(rit[0])) <= 2, (its, rit)
     assert np.abs(c - rc).max() <= 1e-8 * np.abs(rc).max() and np.abs(phi - rphi).max() <= 1e-9
+
+
+# ---- BDF2 timesteps (the reference's transient study: BDF, maxorder 2, comsol_model.py:518-531) -----------------------------------------
+@pytest.mark.parametrize("N,nx,B,kernel,kw", [
+    (3, 128, 5, '', {}),                                                                                 # pair kernel
+    (2, 1100, 3, '', {}),                                                                                # lane teams
+    (3, 130, 4, 'generic', {}),                                                                          # row-per-thread kernel
+    (6, 96, 9, 'sweep', dict(mpb_radius=[3.5e-10] * 6)),                                                 # one-sided sweep
+    (7, 80, 9, 'both', {}),                                                                              # two-sided sweep
+    (6, 96, 40, 'team', dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * 6)),
+    (8, 64, 70, 'lane', dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * 8)),
+    (6, 80, 37, 'lane2', {}),
+    (8, 64, 37, 'lane4', dict(mpb_radius=[3.5e-10] * 8)),
+    (3, 96, 70, 'lane', {}),
+])
+def test_bdf2_timesteps_match_oracle(N, nx, B, kernel, kw, monkeypatch):
+    """pnp_newton_params.time_order = 2: (3 c_n+1 - 4 c_n + c_n-1) / (2 dt), first step backward Euler; every kernel family, states and
+    summed iteration counts against the oracle; the result differs from backward Euler's (the option is not a no-op)."""
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    D, q, cb, dx, phiM = make_lanes(N, nx, 4, 7)
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    got, ref = run_both(N, nx, B=B, seed=7, dt=dt, nsteps=5, stationary=False, newton_kw=dict(kw, time_order=2))
+    assert_close(got, ref)
+    be, _ = run_both(N, nx, B=B, seed=7, dt=dt, nsteps=5, stationary=False, newton_kw=kw)
+    assert np.abs(got[0] - be[0]).max() > 1e-6 * np.abs(be[0]).max()
+
+
+def test_bdf2_steps_split_over_calls_and_second_order_in_time(monkeypatch):
+    """The BDF2 history (c_n-1) lives on the handle: pnp_step(2) + pnp_step(3) == pnp_step(5) to the bit, iteration counts of a call are
+    the sums over its steps.  And the point of the option: halving dt cuts the error of a diffusion-dominated relaxation four-fold
+    (backward Euler: two-fold)."""
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', '')
+    N, nx, B = 3, 96, 6
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 3)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+
+    def run(order, dt_, splits):
+        with _capi.PnpSolver(N, nx, dx, dt_, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+            s.set_newton(time_order=order, tol=1e-12)
+            s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+            its = []
+            for n in splits:
+                s.step(n)
+                its.append(s.newton_iterations())
+            assert (s.get_status() == 0).all()
+            return s.get_state()[0], its
+    a, ia = run(2, dt, [5])
+    b, ib = run(2, dt, [2, 3])
+    assert np.array_equal(a, b) and np.array_equal(ia[0], ib[0] + ib[1])
+    ref, _ = run(2, dt / 16, [8 * 16])
+    err = {}
+    for order in (1, 2):
+        e1 = np.abs(run(order, dt, [8])[0] - ref).max()
+        e2 = np.abs(run(order, dt / 2, [16])[0] - ref).max()
+        err[order] = e1 / e2
+    assert 1.6 < err[1] < 2.6 and 3.0 < err[2] < 5.5, err
 
 
 # ---- constant convection velocity (tp.system['flow rate'], comsol_model.py:901-903) ------------------------------------------------------

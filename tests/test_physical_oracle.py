@@ -406,6 +406,25 @@ def test_rounding_floor_rule_rejects_linear_convergence():
     assert not PH.at_rounding_floor(1e-9, 3e-9, 2.9e-9, tol)
 
 
+def test_bdf2_is_second_order_in_time():
+    """integrate(bdf2=True): the reference's transient study asks COMSOL for BDF with maxorder 2 (comsol_model.py:518-531).  On the
+    relaxation of a double layer the error against a fine-step solution falls four-fold when dt is halved (backward Euler: two-fold)."""
+    from catint_amd.units import unit_F, unit_R, unit_eps0
+    nx = 64
+    D, q, cb = np.array([1.957e-9, 1.185e-9]), np.array([unit_F, -unit_F]), np.array([10.0, 10.0])
+    beta, eps = 1.0 / (unit_R * 298.14), 78.36 * unit_eps0
+    dx = np.sqrt(eps / beta / (q ** 2 * cb).sum()) / 4.0
+    p = PH.PhysicalProblem(D=D, charges=q, beta=beta, eps=eps, dx=dx, nx=nx, c_bulk=cb, phiM=-0.05)
+    c0 = np.repeat(cb[:, None], nx, axis=1)
+    T = 0.5 * (nx * dx) ** 2 / D.max()
+    ref = PH.integrate(p, c0, np.zeros(nx), T / 512, 512, bdf2=True, tol=1e-13)[0]
+    ratio = {}
+    for bdf2 in (False, True):
+        e = [np.abs(PH.integrate(p, c0, np.zeros(nx), T / n, n, bdf2=bdf2, tol=1e-13)[0] - ref).max() for n in (16, 32)]
+        ratio[bdf2] = e[0] / e[1]
+    assert 1.7 < ratio[False] < 2.4 and 3.2 < ratio[True] < 5.0, ratio
+
+
 def test_convection_velocity_analytic_profile_and_flux_closure():
     """Constant velocity v along x (tp.system['flow rate'], comsol_model.py:901-903): flux -D c' + c v.  A neutral species with a closed
     wall relaxes to c(x) = c_L exp(v (x - L) / D); the exponentially fitted edge flux reproduces it to rounding on any grid, for both
