@@ -399,8 +399,12 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
     # large batches of large blocks: the lane kernel (pnp_lane.hip: one operating point per lane, block Thomas from both ends in
     # registers).  Its roofline is HBM: the block-Thomas records (N+1)(N+2) doubles per grid row are written by the forward pass and
     # read by the back-substitution of EVERY Newton iteration; algorithmic bytes per lane-iteration = 8 nx (2 (N+1)(N+2) + 6 N + 5).
-    def lane_bytes(N_, nx_):
-        return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + 6 * N_ + 5)
+    def lane_bytes(N_, nx_, fused=False):
+        # per grid row and Newton iteration, in doubles: records (N+1)(N+2) written by the forward pass and read by the back-substitution;
+        # state: forward reads c, phi, c_old (2N+1); then either the Newton update is written (N+1), read back with the state (2N+2) and
+        # the new state written (N+1) -- three passes, 6N+5 -- or (lane kernel from 24 576 points on: update fused into the
+        # back-substitution, two state copies) the state is read once more and written once: 4N+3
+        return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + (4 * N_ + 3 if fused else 6 * N_ + 5))
 
     def lane_record(LB, LN, LX, seed, steps, pmc_key, what, pmc_steps=2):
         s8, inp = newton_solver(LB, LN, LX, seed, device, steric=True)
@@ -417,7 +421,8 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         it2 = float(s8.newton_iterations().sum())
         s8.close()
         its = float(it8.sum())
-        alg = lane_bytes(LN, LX)
+        fused = LB >= 24576 and LN >= 5          # (pnp_lane.hip: launch_lane_nb)
+        alg = lane_bytes(LN, LX, fused)
         rec = {'workload': 'batch=%d, %d species size-modified, %d points, Stern wall, backward Euler: %s' % (LB, LN, LX, what),
                'timesteps_per_s': LB * steps / (ms8 * 1e-3), 'newton_iterations_per_s': its / (ms8 * 1e-3),
                'mean_newton_iterations_per_step': its / (LB * steps), 'ms_per_step': ms8 / steps, 'lanes_ok': ok8}
@@ -426,6 +431,12 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
                 'achieved_is': 'algorithmic bytes per Newton iteration and operating point (state + block-Thomas records, written by the '
                                'forward pass and read by the back-substitution) x iterations / HIP-event time of the launch'}
         roof['frac'] = roof['achieved'] / HBM_PEAK_GBS
+        # SURVEY 8(d)'s own yardstick beside the design floor: 16 (N+1) nx bytes per lane-TIMESTEP (state read and written once), as if the
+        # block-Thomas records never left the chip -- they do by design (a direct block solve of 9 x 9 blocks over 512 rows holds 47 KB
+        # of records per operating point), which is why the design-floor fraction above is the one the kernel is tuned against
+        roof['survey_8d_bytes_per_lane_timestep'] = 16.0 * (LN + 1) * LX
+        roof['survey_8d_frac'] = 16.0 * (LN + 1) * LX * rec['timesteps_per_s'] / 1e9 / HBM_PEAK_GBS
+        roof['update_fused_into_back_substitution'] = bool(fused)
         pr = pmc.get(pmc_key) if isinstance(pmc, dict) else None
         if pr and 'hbm_bytes_per_launch' in pr:
             roof['kernel'] = pr.get('kernel')
@@ -700,8 +711,8 @@ def main():
     if world > 1 and not args.no_extras:
         shares = {}
 
-        def lane_bytes_(N_, nx_):
-            return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + 6 * N_ + 5)
+        def lane_bytes_(N_, nx_, B_):      # (as lane_bytes of physical_mode: the lane kernel fuses the update from 24 576 points on)
+            return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + (4 * N_ + 3 if (B_ >= 24576 and N_ >= 5) else 6 * N_ + 5))
 
         def compat_share(shape, seed, nsteps):
             SB, SN, SX = shape
@@ -737,7 +748,7 @@ def main():
                     'value': world * SB * nsteps / t['wall'], 'unit': 'timesteps/s', 'steps': nsteps,
                     'newton_iterations_per_s': float(its.sum()) / t['wall'],
                     'per_rank_timesteps_per_s': [SB * nsteps / w for w in t['per_rank_wall']], 'start_skew_us': t['start_skew_us'],
-                    'hbm_frac_algorithmic_slowest_rank': lane_bytes_(SN, SX) * float(its.max()) / (t['ev_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'hbm_frac_algorithmic_slowest_rank': lane_bytes_(SN, SX, SB) * float(its.max()) / (t['ev_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     'lanes_ok': int(t['table'][:, 4].sum()), 'lanes_total': world * SB}
 
         div = max(1, int(os.environ.get('CATINT_BENCH_SHARE_DIV', '1')))      # tests: the same records on 1/div of the batch
