@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
 
   bool have = valid, fresh = true;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
-  double upd_prev = INFINITY, upd_prev2 = INFINITY;
+  double upd_prev = INFINITY;
   double alarm = 0.0;            // pivot monitor (sticky)
 
   for (;;) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
     const bool first = fresh && !G.ext_old;
     if (fresh) {
       it = 0;
-      upd_prev = upd_prev2 = INFINITY;
+      upd_prev = INFINITY;
       fresh = false;
     }
     it += 1;
@@ -723,11 +723,10 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
       bool accept = false;
       if (lam == 1.0) {
         accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-                 newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol);
-        upd_prev2 = upd_prev;
+                 newton_at_rounding_floor(upd, upd_prev, A.tol);
         upd_prev = upd;
       } else {
-        upd_prev = upd_prev2 = INFINITY;
+        upd_prev = INFINITY;
       }
       if (accept || it >= A.maxit) {
         total_it += accept ? it : A.maxit + 1;

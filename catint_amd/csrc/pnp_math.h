@@ -16,20 +16,22 @@ __device__ __forceinline__ double nrcp(double x) {   // v_rcp_f64 + two Newton s
 }
 
 // Third way out of the Newton loop (besides update < tol and the quadratic error estimate): the iteration has reached its rounding
-// floor.  Near the solution a full step contracts quadratically; THREE consecutive full steps within 100 tol, neither of the last two
-// even half its predecessor, and NOT a monotone decrease, are the rounding noise of an ill-conditioned Jacobian (stiff reaction terms:
-// cond(J) eps ~ 3e-9 in the case of tests/golden/fuzz/newton_case117.json), not Newton -- without this rule such a lane iterates
-// until the noise happens to dip below tol (20 iterations on the device, 31 in the oracle, 37 in another kernel for the same state).
-// The monotonicity test keeps a LINEARLY converging iteration (singular Jacobian at the root: every update a fixed fraction of the
-// one before) out of this exit -- its error is upd / (1 - ratio), far above tol; it runs on to tol or to the iteration limit and is
-// then reported as not converged.  Same rule in oracle/pnp_physical.py (at_rounding_floor); contract stated in include/catint_pnp.h.
-__device__ __forceinline__ bool newton_at_rounding_floor(double upd, double upd_prev, double upd_prev2, double tol) {
+// floor.  Near the solution a full step contracts quadratically; two consecutive full steps within 100 tol of which the second is NOT
+// SMALLER than the first are the rounding noise of an ill-conditioned Jacobian (stiff reaction terms: cond(J) eps ~ 3e-9 in the case
+// of tests/golden/fuzz/newton_case117.json), not Newton -- without this rule such a lane iterates until the noise happens to dip below
+// tol (20 iterations on the device, 31 in the oracle, 37 in another kernel for the same state).  Round 3 accepted a pair whose second
+// update was more than HALF the first: that also lets a LINEARLY converging iteration out (singular Jacobian at the root: every update a
+// fixed fraction of the one before, error upd / (1 - ratio), far above tol -- ADVICE r03).  A linearly converging sequence shrinks at
+// every step and never satisfies "not smaller"; it runs on to tol or to the iteration limit and is then reported as not converged.
+// (A rule that asked for a non-monotone TRIPLE was tried first: as safe, but the exits of different linear solvers then lie up to
+// three iterations apart instead of one, and a lane at the iteration limit flips between converged and not.)
+// Same rule in oracle/pnp_physical.py (at_rounding_floor); contract stated in include/catint_pnp.h.
+__device__ __forceinline__ bool newton_at_rounding_floor(double upd, double upd_prev, double tol) {
 #ifdef PNP_NO_ROUNDING_FLOOR_EXIT      // (diagnosis builds)
   return false;
 #else
   const double w = 100.0 * tol;
-  return upd_prev2 < w && upd_prev < w && upd < w && upd_prev > 0.5 * upd_prev2 && upd > 0.5 * upd_prev &&
-         (upd_prev >= upd_prev2 || upd >= upd_prev);
+  return upd_prev < w && upd < w && upd >= upd_prev;
 #endif
 }
 

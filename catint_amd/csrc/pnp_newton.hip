@@ -597,7 +597,7 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
         for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
-      double upd_prev = INFINITY, upd_prev2 = INFINITY;       // scaled update of the previous full (undamped) iteration
+      double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
         for (int row = tid; row < nx; row += T) {
@@ -691,14 +691,13 @@ __global__ __launch_bounds__(TMAX) void newton_kernel(const NewtonArgs A) {
           // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
           // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
           if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol)) {
+              newton_at_rounding_floor(upd, upd_prev, A.tol)) {
             conv = true;
             break;
           }
-          upd_prev2 = upd_prev;
           upd_prev = upd;
         } else {
-          upd_prev = upd_prev2 = INFINITY;
+          upd_prev = INFINITY;
         }
       }
       total_it += conv ? it : A.maxit + 1;
@@ -812,7 +811,7 @@ __global__ __launch_bounds__(NB >= 5 ? 256 : 512) void newton_pair_kernel(const 
         for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
-      double upd_prev = INFINITY, upd_prev2 = INFINITY;       // scaled update of the previous full (undamped) iteration
+      double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
         // The thread index is made opaque once per iteration: the compiler then recomputes the ~100 global addresses that
@@ -1063,14 +1062,13 @@ __global__ __launch_bounds__(NB >= 5 ? 256 : 512) void newton_pair_kernel(const 
           // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
           // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
           if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol)) {
+              newton_at_rounding_floor(upd, upd_prev, A.tol)) {
             conv = true;
             break;
           }
-          upd_prev2 = upd_prev;
           upd_prev = upd;
         } else {
-          upd_prev = upd_prev2 = INFINITY;
+          upd_prev = INFINITY;
         }
       }
       total_it += conv ? it : A.maxit + 1;
@@ -1411,7 +1409,7 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
         for (int e = tid; e < N * ldx; e += T) co[e] = c[e];
       __syncthreads();
       bool conv = false;
-      double upd_prev = INFINITY, upd_prev2 = INFINITY;       // scaled update of the previous full (undamped) iteration
+      double upd_prev = INFINITY;       // scaled update of the previous full (undamped) iteration
       int it = 1;
       for (; it <= A.maxit; ++it) {
         // lane coordinates made opaque once per iteration: addresses derived from them are recomputed where they are used
@@ -1619,14 +1617,13 @@ __global__ __launch_bounds__(1024, 4) void newton_team_kernel(const NewtonArgs G
           // estimate of the state just computed, upd^2/upd_prev (two consecutive contracting full steps), is below tol --
           // the iteration that would only confirm it is skipped (oracle/pnp_physical.py: newton_step(estimate=True))
           if (upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol)) {
+              newton_at_rounding_floor(upd, upd_prev, A.tol)) {
             conv = true;
             break;
           }
-          upd_prev2 = upd_prev;
           upd_prev = upd;
         } else {
-          upd_prev = upd_prev2 = INFINITY;
+          upd_prev = INFINITY;
         }
       }
       total_it += conv ? it : A.maxit + 1;
@@ -1708,7 +1705,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
   int64_t b = 0;                  // ... and its current one (valid memory even while the team has no work)
   bool have = false, fresh = false;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
-  double upd_prev = INFINITY, upd_prev2 = INFINITY;
+  double upd_prev = INFINITY;
 #ifdef PNP_SWEEP_STAMPS
   int stamp_code = 0, stamp_cycles = 0;
 #endif
@@ -1743,7 +1740,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
     }
     if (fresh) {
       it = 0;
-      upd_prev = upd_prev2 = INFINITY;
+      upd_prev = INFINITY;
       fresh = false;
     }
     it += 1;
@@ -1883,11 +1880,10 @@ __global__ __launch_bounds__(64, 2) void newton_sweep_kernel(const NewtonArgs G)
       bool accept = false;
       if (lam == 1.0) {
         accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol);
-        upd_prev2 = upd_prev;
+              newton_at_rounding_floor(upd, upd_prev, A.tol);
         upd_prev = upd;
       } else {
-        upd_prev = upd_prev2 = INFINITY;
+        upd_prev = INFINITY;
       }
       if (accept || it >= A.maxit) {
         total_it += accept ? it : A.maxit + 1;
@@ -1964,7 +1960,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep2_kernel(const NewtonArgs G
   int64_t b = 0;
   bool have = false, fresh = false;
   int step = 0, it = 0, total_it = 0, st = PNP_STATUS_OK;
-  double upd_prev = INFINITY, upd_prev2 = INFINITY;
+  double upd_prev = INFINITY;
   for (;;) {      // CONTROL FLOW IS WAVE-UNIFORM, see newton_sweep_kernel
     if (!have && real_team && bnext < G.B) {
       b = bnext;
@@ -1995,7 +1991,7 @@ __global__ __launch_bounds__(64, 2) void newton_sweep2_kernel(const NewtonArgs G
     }
     if (fresh) {
       it = 0;
-      upd_prev = upd_prev2 = INFINITY;
+      upd_prev = INFINITY;
       fresh = false;
     }
     it += 1;
@@ -2160,11 +2156,10 @@ __global__ __launch_bounds__(64, 2) void newton_sweep2_kernel(const NewtonArgs G
       bool accept = false;
       if (lam == 1.0) {
         accept = upd < A.tol || (A.estimate && upd_prev < INFINITY && upd < 0.1 * upd_prev && upd * (upd / upd_prev) < A.tol) ||
-              newton_at_rounding_floor(upd, upd_prev, upd_prev2, A.tol);
-        upd_prev2 = upd_prev;
+              newton_at_rounding_floor(upd, upd_prev, A.tol);
         upd_prev = upd;
       } else {
-        upd_prev = upd_prev2 = INFINITY;
+        upd_prev = INFINITY;
       }
       if (accept || it >= A.maxit) {
         total_it += accept ? it : A.maxit + 1;

@@ -207,11 +207,11 @@ typedef struct pnp_newton_params {
   double stern_capacitance;  /* F/m^2 */
   double phi_pzc;            /* V */
   double tol;                /* scaled update max(|dc|/(c + c_bulk), |dphi| beta max|q|) < tol on an undamped step.  One more exit
-                              *    reports PNP_STATUS_OK: the ROUNDING FLOOR -- three consecutive undamped iterations whose scaled
-                              *    updates are all < 100 tol, neither of the last two below half its predecessor, and not monotonically
-                              *    decreasing: the noise cond(J) eps of an ill-conditioned Jacobian (stiff reactions), which no further
-                              *    iteration improves; the state is then accurate to that noise (<= 100 tol), not to tol.  A linearly
-                              *    converging iteration (monotone) does not qualify: it runs on to tol or to maxit (PNP_STATUS_MAXIT). */
+                              *    reports PNP_STATUS_OK: the ROUNDING FLOOR -- two consecutive undamped iterations whose scaled updates
+                              *    are both < 100 tol and the second is not smaller than the first: the noise cond(J) eps of an
+                              *    ill-conditioned Jacobian (stiff reactions), which no further iteration improves; the state is then
+                              *    accurate to that noise (<= 100 tol), not to tol.  A linearly converging iteration (every update
+                              *    smaller than the one before) does not qualify: it runs on to tol or to maxit (PNP_STATUS_MAXIT). */
   double dphi_max;           /* potential limiting per iteration (V); <= 0 disables */
   int32_t time_order;        /* pnp_step: 0 or 1 backward Euler (default); 2 = BDF2, the time stepping the reference asks COMSOL for
                               *    (comsol_model.py:518-531: tds time solver, "maxorder" 2): (3 c_n+1 - 4 c_n + c_n-1) / (2 dt), the first

@@ -292,14 +292,13 @@ def solve_block_pcr(L, M, U, rhs):
     return rt.T.copy()
 
 
-def at_rounding_floor(upd, upd_prev, upd_prev2, tol):
-    """The third exit of the Newton loop (newton_at_rounding_floor in catint_amd/csrc/pnp_math.h): three consecutive full steps within
-    100 tol, neither of the last two even half its predecessor, and not a monotone decrease -- near the solution Newton contracts
-    quadratically, so this is the noise of an ill-conditioned Jacobian, not progress.  A linearly converging iteration (every update a
-    fixed fraction of the one before: monotone) never leaves here."""
+def at_rounding_floor(upd, upd_prev, tol):
+    """The third exit of the Newton loop (newton_at_rounding_floor in catint_amd/csrc/pnp_math.h): two consecutive full steps within
+    100 tol, the second NOT SMALLER than the first -- near the solution Newton contracts quadratically, so an update that stops
+    shrinking is the noise of an ill-conditioned Jacobian, not progress.  A linearly converging iteration (every update a fixed
+    fraction of the one before) shrinks at every step and never leaves here."""
     w = 100.0 * tol
-    return (upd_prev2 < w and upd_prev < w and upd < w and upd_prev > 0.5 * upd_prev2 and upd > 0.5 * upd_prev
-            and (upd_prev >= upd_prev2 or upd >= upd_prev))
+    return upd_prev < w and upd < w and upd >= upd_prev
 
 
 def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver=solve_block_tridiagonal,
@@ -314,7 +313,7 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
     N = p.N
     vt = 1.0 / (p.beta * max(np.abs(p.q).max(), 1.0))            # thermal voltage of the highest valence
     hist = []
-    upd_prev = upd_prev2 = np.inf
+    upd_prev = np.inf
     for it in range(1, maxit + 1):
         F, L, M, U = residual_and_jacobian(p, c, phi, c_old, dt)
         if not (np.all(np.isfinite(F)) and np.all(np.isfinite(M))):      # diverged: the device keeps iterating on NaNs and reports
@@ -350,11 +349,11 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
             # upd^2/upd_prev of the error of the state just computed is below tol
             if upd < tol or (estimate and np.isfinite(upd_prev) and upd < 0.1 * upd_prev and upd * (upd / upd_prev) < tol):
                 return c, phi, it, hist
-            if at_rounding_floor(upd, upd_prev, upd_prev2, tol):
+            if at_rounding_floor(upd, upd_prev, tol):
                 return c, phi, it, hist
-            upd_prev2, upd_prev = upd_prev, upd
+            upd_prev = upd
         else:
-            upd_prev = upd_prev2 = np.inf
+            upd_prev = np.inf
     return c, phi, maxit + 1, hist
 
 

@@ -15,7 +15,7 @@ bad = 0
 t0 = time.time()
 
 
-def solve(kernel, env, N, nx, B, D, q, cb, dx, phiM, kw, x, flux, stationary, dt, nsteps, mask):
+def solve(kernel, env, N, nx, B, D, q, cb, dx, phiM, kw, x, flux, stationary, dt, nsteps, mask, rx=None, velocity=0.0):
     for k in ('CATINT_NEWTON_KERNEL', 'CATINT_NEWTON_LANE_GROUPS', 'CATINT_LANE_ORDER'):
         os.environ.pop(k, None)
     os.environ['CATINT_NEWTON_KERNEL'] = kernel
@@ -27,6 +27,10 @@ def solve(kernel, env, N, nx, B, D, q, cb, dx, phiM, kw, x, flux, stationary, dt
         s.set_newton(**kw)
         if x is not None:
             s.set_grid(x * dx)
+        if rx:
+            s.set_reactions(rx)
+        if velocity:
+            s.set_convection(velocity)
         s.set_batch(c0, pb, np.zeros(B), flux)
         if stationary:
             s.solve_stationary()
@@ -47,8 +51,15 @@ def solve(kernel, env, N, nx, B, D, q, cb, dx, phiM, kw, x, flux, stationary, dt
 
 
 for case in range(ncase):
-    kernel = 'lane2' if rng.random() < 0.4 else 'lane'
-    N = int(rng.integers(5, 9)) if kernel == 'lane2' else int(rng.integers(2, 9))
+    kernel = str(rng.choice(['lane4', 'lane2', 'lane'], p=[0.4, 0.25, 0.35]))
+    N = int(rng.integers(5, 9)) if kernel != 'lane' else int(rng.integers(2, 9))
+    rx, velocity = None, 0.0            # (round 4: homogeneous reactions and the convection term run on the lane kernels)
+    if rng.random() < 0.35:
+        rx = []
+        for _ in range(int(rng.integers(1, 4))):
+            nl, nr = int(rng.integers(0, 3)), int(rng.integers(1, 3))
+            rx.append(([int(k) for k in rng.integers(0, N, nl)], [int(k) for k in rng.integers(0, N, nr)], float(10 ** rng.uniform(0, 4)),
+                       float(10 ** rng.uniform(0, 4))))
     nx = int(rng.choice([9, 17, 33, 64, 65, 100, 129, 200, 257]))
     B = int(rng.integers(64, 401))
     kw = {'tol': 1e-10, 'maxit': 60}
@@ -73,8 +84,10 @@ for case in range(ncase):
     if rng.random() < 0.2:
         env['CATINT_LANE_ORDER'] = '0'
     try:
-        got = solve(kernel, env, N, nx, B, D, q, cb, dx, phiM, kw, x, flux, stationary, dt, nsteps, mask)
-        ref = solve('team', {}, N, nx, B, D, q, cb, dx, phiM, kw, x, flux, stationary, dt, nsteps, mask)
+        if rng.random() < 0.2:
+            velocity = float(rng.choice([-2.0, 3.0]) * D.max() / ((nx - 1) * dx))
+        got = solve(kernel, env, N, nx, B, D, q, cb, dx, phiM, kw, x, flux, stationary, dt, nsteps, mask, rx, velocity)
+        ref = solve('team', {}, N, nx, B, D, q, cb, dx, phiM, kw, x, flux, stationary, dt, nsteps, mask, rx, velocity)
         good = (ref[4] == 0) & (got[4] == 0)
         sc = np.abs(ref[0]).max(axis=2, keepdims=True)
         dc = float((np.abs(got[0] - ref[0]) / (sc + 1e-300))[good].max()) if good.any() else 0.0
@@ -83,11 +96,15 @@ for case in range(ncase):
         near = (np.abs(got[2].astype(int) - ref[2]).max() <= 1) and (np.abs(got[3].astype(int) - ref[3])[good].max() <= 1 if good.any() else True)
         ok = np.array_equal(got[4], ref[4]) and dc < 1e-8 and dp < 1e-9 and (same_it or near)
         tag = 'ok ' if ok and same_it else ('ok~' if ok else 'BAD')
+        if not ok and os.environ.get('FUZZ_VERBOSE'):
+            d1 = np.flatnonzero(got[2] != ref[2]); d2 = np.flatnonzero(got[3] != ref[3]); d3 = np.flatnonzero(got[4] != ref[4])
+            print('   first solve: lanes', d1[:8], 'got', got[2][d1[:8]], 'ref', ref[2][d1[:8]], '| second:', d2[:8], got[3][d2[:8]], ref[3][d2[:8]],
+                  '| status:', d3[:8], got[4][d3[:8]], ref[4][d3[:8]], '| mask', None if mask is None else mask[d1[:8]])
     except Exception as e:
         ok, tag, dc, dp, same_it = False, 'EXC', -1, -1, str(e)[:100]
     bad += 0 if ok else 1
     if not ok or tag != 'ok ' or case % 10 == 0:
-        print('%s case %2d %s N=%d nx=%d B=%d stern=%d mpb=%d grid=%d flux=%d stat=%d mask=%d env=%s  dc=%.1e dphi=%.1e same_iterations=%s not_converged=%d' % (
-            tag, case, kernel, N, nx, B, 'wall_bc' in kw, 'mpb_radius' in kw, x is not None, bool(flux.any()), stationary, mask is not None, env, dc, dp, same_it,
+        print('%s case %2d %s rx=%d v=%d N=%d nx=%d B=%d stern=%d mpb=%d grid=%d flux=%d stat=%d mask=%d env=%s  dc=%.1e dphi=%.1e same_iterations=%s not_converged=%d' % (
+            tag, case, kernel, len(rx) if rx else 0, velocity != 0.0, N, nx, B, 'wall_bc' in kw, 'mpb_radius' in kw, x is not None, bool(flux.any()), stationary, mask is not None, env, dc, dp, same_it,
             int((ref[4] != 0).sum()) if tag != 'EXC' else -1), flush=True)
 print('%d cases, %d bad, %.1f s' % (ncase, bad, time.time() - t0))

@@ -541,10 +541,10 @@ def test_fuzz_case_117_stops_at_the_rounding_floor(kernel, monkeypatch):
                         points_per_debye=d['points_per_debye'])
     c, phi, its, st = got
     rc, rphi, rit = ref
-    # (round 4: the exit asks for a non-monotone triple of full steps inside the window -- one iteration later than the two-step rule of
-    # round 3, and never for a linearly converging lane.  The floor is noise: the solvers see different triples, within two iterations)
-    assert (st == 0).all() and rit[0] == 21
-    assert abs(int(its[0]) - int(rit[0])) <= 2, (its, rit)
+    # (round 4: the exit asks for an update that did NOT shrink -- round 3 accepted any pair whose second update was more than half the
+    # first, which also lets a linearly converging lane out; same iteration here)
+    assert (st == 0).all() and rit[0] == 20
+    assert abs(int(its[0]) - int(rit[0])) <= 1, (its, rit)
     assert np.abs(c - rc).max() <= 1e-8 * np.abs(rc).max() and np.abs(phi - rphi).max() <= 1e-9
 
 
