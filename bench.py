@@ -62,6 +62,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline sample length')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='headline only (no per-step / beyond-cache / physical records)')
+    ap.add_argument('--shares-only', action='store_true',
+                    help='with a process group: the per-rank configs[3] / configs[4] share records, but none of the single-GPU extras')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
     ap.add_argument('--large-batch', type=int, default=8192, help='extra timed run at this batch size; 0 = skip')
     ap.add_argument('--physical-steps', type=int, default=20, help='implicit physical mode on the headline shape; 0 = skip')
@@ -672,7 +674,7 @@ def main():
     steps_total = world * B * args.steps
     value = steps_total / wall
 
-    extras = rank == 0 and world == 1 and not args.no_extras
+    extras = rank == 0 and world == 1 and not args.no_extras and not args.shares_only
     per_step = None
     if extras and args.steps_per_launch != 1:
         solver.step(64, 1)
@@ -708,7 +710,7 @@ def main():
     # compat step per launch and coupled-Newton lane kernels, each with the contract's timed region (common start, MAX over ranks) --
     # the scaling curve on those shapes; at N = 1 the same shapes are the `beyond_cache` / `physical_mode` records below
     shares = None
-    if world > 1 and not args.no_extras:
+    if dist is not None and not args.no_extras:          # (world > 1, or CATINT_FORCE_DIST: the RCCL rehearsal of one rank)
         shares = {}
 
         def lane_bytes_(N_, nx_, B_):      # (as lane_bytes of physical_mode: the lane kernel fuses the update from 24 576 points on)

@@ -53,6 +53,8 @@ struct pnp_handle {
   double* c_old2 = nullptr;                 // BDF2 (pnp_newton_params.time_order = 2): the time level before the previous one
   int32_t* bdf_acc = nullptr;               // ... and per-lane iteration counts / status summed over the launches of one pnp_step call
   int nw_ext_old = 0;                       // set around a BDF2 step: c_old is prepared, sig carries the factor 3/2
+  bool bdf_history = false;                 // c_old2 holds the level before the current state (false after an upload, a change of
+                                            // time_order, a stationary solve or patched lanes: the next step is backward Euler)
   ReactionSides* rs_dev = nullptr;          // the table flattened per reaction side (lane kernels)
   int rs_max_exponent = 0;
   int n_wk = 0;
@@ -534,6 +536,7 @@ int pnp_set_batch(pnp_handle* h, int64_t B, const double* c0, const double* pb, 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_batch = true;
     h->steps_done = 0;
+    h->bdf_history = false;
     // lane kernels: the iteration counters were just zeroed (unpack_state_kernel), so the first solve of this batch deals the
     // operating points by their wall-to-bulk potential difference
     h->iters_valid = false;
@@ -768,10 +771,11 @@ static int newton_timesteps(pnp_handle* h, int nsteps) {
   if (!h->bdf_acc) HIP_TRY(h, dev_alloc(h, &h->bdf_acc, (size_t)h->cfg.batch_capacity * 2));
   HIP_TRY(h, hipMemsetAsync(h->bdf_acc, 0, (size_t)B * 2 * sizeof(int32_t), h->stream));
   for (int s = 0; s < nsteps; ++s) {
-    if (h->steps_done == 0) {      // first step of a trajectory: backward Euler, and c_0 is the level before the next step's previous one
+    if (h->steps_done == 0 || !h->bdf_history) {      // first step of a trajectory: backward Euler, and c_0 is the level before the next step's previous one
       HIP_TRY(h, hipMemcpyAsync(h->c_old2, h->c, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       const int rc = run_newton(h, 1, false, 0.0, 0);
       if (rc != PNP_OK) return rc;
+      h->bdf_history = true;
     } else {
       hipLaunchKernelGGL(bdf2_prepare_kernel, dim3(2048), dim3(256), 0, h->stream, (const double*)h->c, h->c_old2, h->c_old, n);
       HIP_TRY(h, hipGetLastError());
@@ -789,6 +793,7 @@ static int newton_timesteps(pnp_handle* h, int nsteps) {
 
 // physical mode: nsteps backward-Euler steps (stationary: one solve with 1/dt = 0) in one launch
 static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, int maxit) {
+  if (stationary) h->bdf_history = false;      // (a stationary solve moves the state off the trajectory)
   NewtonArgs a;
   memset(&a, 0, sizeof(a));
   const int N = h->a.N, nx = h->a.nx;
@@ -955,6 +960,7 @@ int pnp_set_newton(pnp_handle* h, const pnp_newton_params* p, const double* mpb_
   if (p->wall_bc == 1 && !(p->stern_capacitance > 0)) return fail(h, PNP_EINVAL, "pnp_set_newton: Stern capacitance must be positive");
   if (p->maxit < 1 || !(p->tol > 0)) return fail(h, PNP_EINVAL, "pnp_set_newton: maxit >= 1 and tol > 0 required");
   if (p->time_order < 0 || p->time_order > 2) return fail(h, PNP_EINVAL, "pnp_set_newton: time_order must be 0, 1 (backward Euler) or 2 (BDF2)");
+  if (p->time_order != h->np.time_order) h->bdf_history = false;
   h->np = *p;
   h->mpb = false;
   for (int k = 0; k < h->a.N; ++k) {
@@ -1236,6 +1242,7 @@ int pnp_set_lanes(pnp_handle* h, int64_t n, const int64_t* lanes, const double* 
   for (int64_t i = 0; i < n; ++i)
     if (lanes[i] < 0 || lanes[i] >= h->B) return fail(h, PNP_EINVAL, "pnp_set_lanes: lane index out of range");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  h->bdf_history = false;        // (the patched lanes have no previous time level of their own: the next BDF2 step starts over)
   const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx;
   const size_t w = (size_t)nx * sizeof(double), dp = (size_t)ldx * sizeof(double);
   // a handful of lanes: one strided copy per lane (N rows of the concentrations, one of the potential), all on the handle's stream

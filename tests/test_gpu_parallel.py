@@ -70,6 +70,24 @@ def test_one_rank_rccl_gathers_on_a_device_tensor():
         assert p.returncode == 0 and 'ok' in o, e[-2000:]
 
 
+def test_bench_under_rccl_with_one_rank_walks_every_collective_of_the_multi_gpu_line():
+    """bench.py with backend 'nccl' and a process group of ONE rank (CATINT_FORCE_DIST): barrier, the all-reduce of the aligned start,
+    the all-gathers of the timed regions and of the observables, the per-rank configs[3] / configs[4] share records -- every collective
+    of `bench.py --gpus 8`, on DEVICE tensors through RCCL, on the one GPU of the test box."""
+    import json
+    env = dict(os.environ, CATINT_FORCE_DIST='1', CATINT_BENCH_SHARE_DIV='16', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('CATINT_DIST_BACKEND', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '1', '--no-pmc', '--no-cpu-baseline',
+                          '--shares-only'], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout)
+    assert d['n_gpus'] == 1 and d['gather']['backend'] == 'nccl' and d['start_skew_us'] == 0.0
+    for key in ('configs3_share', 'configs4_share'):
+        for leg in ('compat_per_step', 'newton'):
+            assert 'error' not in d[key][leg] and d[key][leg]['lanes_ok'] == d[key][leg]['lanes_total']
+
+
 def test_bench_two_ranks_print_one_json_line_with_the_8_gpu_shares():
     """`bench.py --gpus 2` as its own launcher (two gloo ranks on the one GPU; RCCL refuses two ranks on a device): stdout is exactly
     one JSON line, it carries n_gpus = 2, the start skew of the aligned timed region and one GPU's share of configs[3] / configs[4]
