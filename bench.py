@@ -82,16 +82,17 @@ def compat_solver(B, N, nx, method, seed, device=0):
     return s, (prob, c0, pb, vz, fl)
 
 
-def newton_solver(B, N, nx, seed, device=0, steric=False, error_estimate=False):
+def newton_solver(B, N, nx, seed, device=0, steric=False, error_estimate=False, predictor=False, time_order=1):
     from catint_amd import _capi
     from catint_amd.synthetic import make_batch
     prob, c0, pb, vz, fl = make_batch(B, N, nx, seed=seed, phi_max=0.2, dt_factor=0.1)
     pb = np.nan_to_num(pb)
     s = _capi.PnpSolver(N, nx, prob.dx, prob.dt, prob.beta, prob.eps, prob.D, prob.charges, method='Newton', batch_capacity=B, device=device)
     if steric:
-        s.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=1e-8, mpb_radius=RADII8[:N], error_estimate=error_estimate)
+        s.set_newton(wall_bc='stern', stern_capacitance=0.2, tol=1e-8, mpb_radius=RADII8[:N], error_estimate=error_estimate,
+                     predictor=predictor, time_order=time_order)
     else:
-        s.set_newton(tol=1e-8, error_estimate=error_estimate)
+        s.set_newton(tol=1e-8, error_estimate=error_estimate, predictor=predictor, time_order=time_order)
     return s, (prob, c0, pb, vz, fl)
 
 

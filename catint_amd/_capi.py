@@ -60,7 +60,7 @@ class PnpNewtonParams(C.Structure):
     _fields_ = [
         ('struct_size', C.c_int32), ('wall_bc', C.c_int32), ('maxit', C.c_int32), ('error_estimate', C.c_int32),
         ('stern_capacitance', C.c_double), ('phi_pzc', C.c_double), ('tol', C.c_double), ('dphi_max', C.c_double),
-        ('time_order', C.c_int32), ('reserved', C.c_int32),
+        ('time_order', C.c_int32), ('predictor', C.c_int32),
     ]
 
 
@@ -268,12 +268,13 @@ class PnpSolver(object):
 
     # -- physical mode ---------------------------------------------------------------------
     def set_newton(self, wall_bc='dirichlet', stern_capacitance=0.0, phi_pzc=0.0, tol=1e-10, maxit=50, dphi_max=0.05,
-                   mpb_radius=None, error_estimate=False, time_order=1):
+                   mpb_radius=None, error_estimate=False, time_order=1, predictor=False):
         """Boundary model and Newton controls of the physical mode (tp.system['Stern capacitance'], ['phiPZC'],
         tp.species[sp]['MPB_radius']; comsol_model.py:613,:982,:1041-1063).  time_order=2: BDF2 timesteps (the reference's transient
-        study: BDF, maxorder 2, comsol_model.py:518-531) instead of backward Euler."""
+        study: BDF, maxorder 2, comsol_model.py:518-531) instead of backward Euler; predictor=True: every timestep's Newton iteration
+        starts from the linear extrapolation of the two previous time levels."""
         p = PnpNewtonParams(C.sizeof(PnpNewtonParams), {'dirichlet': 0, 'stern': 1}[wall_bc], int(maxit), int(bool(error_estimate)),
-                            float(stern_capacitance), float(phi_pzc), float(tol), float(dphi_max), int(time_order), 0)
+                            float(stern_capacitance), float(phi_pzc), float(tol), float(dphi_max), int(time_order), int(bool(predictor)))
         r = None if mpb_radius is None else _f64(mpb_radius, (self.N,))
         self._check(self._lib.pnp_set_newton(self._h, C.byref(p), _dptr(r)))
 

@@ -216,7 +216,10 @@ typedef struct pnp_newton_params {
   int32_t time_order;        /* pnp_step: 0 or 1 backward Euler (default); 2 = BDF2, the time stepping the reference asks COMSOL for
                               *    (comsol_model.py:518-531: tds time solver, "maxorder" 2): (3 c_n+1 - 4 c_n + c_n-1) / (2 dt), the first
                               *    step of a trajectory (after pnp_set_batch) backward Euler.  One launch per timestep in this mode. */
-  int32_t reserved;          /* 0 */
+  int32_t predictor;         /* pnp_step: 0 every timestep's Newton iteration starts from the previous state (default); 1 from the linear
+                              *    extrapolation 2 u_n - u_n-1 of the two previous time levels (concentrations and potential), as a BDF
+                              *    time stepper starts its corrector -- same equations and stopping rule, fewer iterations per step.
+                              *    One launch per timestep in this mode; the first step of a trajectory starts from its initial state. */
 } pnp_newton_params;
 /* mpb_radius[N] (m, nullable = point ions): size-modified drift with phi0 = N_A sum a_k^3 c_k
  * (tp.species[sp]['MPB_radius'], comsol_model.py:1041-1063). */

@@ -357,20 +357,31 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
     return c, phi, maxit + 1, hist
 
 
-def integrate(p, c0, phi0, dt, nsteps, bdf2=False, **kw):
+def integrate(p, c0, phi0, dt, nsteps, bdf2=False, predictor=False, **kw):
     """nsteps implicit timesteps.  Backward Euler, or (bdf2=True) the second-order backward differentiation formula the reference's
     transient study asks COMSOL for (comsol_model.py:518-531: BDF, maxorder 2): (3 c_n+1 - 4 c_n + c_n-1) / (2 dt) -- a backward-Euler
-    step of length dt / 1.5 against the combination c* = (4 c_n - c_n-1) / 3; the first step is backward Euler."""
+    step of length dt / 1.5 against the combination c* = (4 c_n - c_n-1) / 3; the first step is backward Euler.
+    predictor=True: from the second step on Newton starts from the linear extrapolation 2 u_n - u_n-1 (concentrations not below a tenth
+    of their value; a point whose extrapolated ions would fill more than 90 % of the volume keeps u_n) -- step_prepare_kernel in
+    catint_amd/csrc/pnp_capi.hip."""
     c, phi = c0.copy(), phi0.copy()
-    c_prev = None
+    c_prev = phi_prev = None
     its = []
     for _ in range(nsteps):
-        if bdf2 and c_prev is not None:
-            cstar = (4.0 * c - c_prev) / 3.0
-            c_prev = c
-            c, phi, it, _ = newton_step(p, c, phi, cstar, dt / 1.5, **kw)
+        if (bdf2 or predictor) and c_prev is not None:
+            c_old = (4.0 * c - c_prev) / 3.0 if bdf2 else c
+            cs, ps = c, phi
+            if predictor:
+                g = 2.0 * c - c_prev
+                g = np.where(g < 0.1 * c, 0.1 * c, g)
+                fill = (p.vol[:, None] * g).sum(axis=0) if p.mpb else np.zeros(c.shape[1])
+                ext = fill < 0.9
+                cs = np.where(ext[None, :], g, c)
+                ps = np.where(ext, 2.0 * phi - phi_prev, phi)
+            c_prev, phi_prev = c, phi
+            c, phi, it, _ = newton_step(p, cs, ps, c_old, dt / 1.5 if bdf2 else dt, **kw)
         else:
-            c_prev = c
+            c_prev, phi_prev = c, phi
             c, phi, it, _ = newton_step(p, c, phi, c, dt, **kw)
         its.append(it)
     return c, phi, its

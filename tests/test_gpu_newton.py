@@ -93,7 +93,8 @@ def run_both(N, nx, B, seed, dt=None, nsteps=1, stationary=True, newton_kw=None,
             cc, ph, it, _ = PH.newton_step(p, cc, ph, cc, np.inf, **okw)
             ref_it[b] = it
         else:
-            cc, ph, its_b = PH.integrate(p, cc, ph, dt, nsteps, bdf2=newton_kw.get('time_order', 1) == 2, **okw)
+            cc, ph, its_b = PH.integrate(p, cc, ph, dt, nsteps, bdf2=newton_kw.get('time_order', 1) == 2,
+                                         predictor=bool(newton_kw.get('predictor', False)), **okw)
             ref_it[b] = sum(its_b)
         ref_c[b], ref_phi[b] = cc, ph
     return (c, phi, its, st), (ref_c, ref_phi, ref_it)
@@ -571,6 +572,31 @@ def test_bdf2_timesteps_match_oracle(N, nx, B, kernel, kw, monkeypatch):
     assert_close(got, ref)
     be, _ = run_both(N, nx, B=B, seed=7, dt=dt, nsteps=5, stationary=False, newton_kw=kw)
     assert np.abs(got[0] - be[0]).max() > 1e-6 * np.abs(be[0]).max()
+
+
+@pytest.mark.parametrize("N,nx,B,kernel,kw", [
+    (3, 128, 5, '', {}),                                                                                 # pair kernel
+    (2, 1100, 3, '', dict(time_order=2)),                                                                # lane teams, with BDF2
+    (3, 130, 4, 'generic', {}),
+    (6, 96, 9, 'sweep', dict(mpb_radius=[3.5e-10] * 6)),
+    (7, 80, 9, 'both', dict(time_order=2)),
+    (6, 96, 40, 'team', dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * 6)),
+    (8, 64, 70, 'lane', dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * 8, time_order=2)),
+    (6, 80, 37, 'lane2', {}),
+    (8, 64, 37, 'lane4', dict(mpb_radius=[3.5e-10] * 8)),
+])
+def test_predictor_matches_oracle_and_saves_iterations(N, nx, B, kernel, kw, monkeypatch):
+    """pnp_newton_params.predictor: from the second step on Newton starts from 2 u_n - u_n-1 (the start of a BDF stepper's corrector).
+    Same equations and stopping rule: GPU and oracle walk the same iterates (identical counts), the trajectory agrees with the one
+    without predictor to the Newton tolerance, and it needs fewer iterations."""
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    D, q, cb, dx, phiM = make_lanes(N, nx, 4, 7)
+    dt = 0.05 * (6 * dx) * (nx * dx) / D.max()
+    got, ref = run_both(N, nx, B=B, seed=7, dt=dt, nsteps=8, stationary=False, newton_kw=dict(kw, predictor=True, tol=1e-10))
+    assert_close(got, ref)
+    plain, _ = run_both(N, nx, B=B, seed=7, dt=dt, nsteps=8, stationary=False, newton_kw=dict(kw, tol=1e-10))
+    assert np.abs(got[0] - plain[0]).max() <= 1e-7 * np.abs(plain[0]).max() and np.abs(got[1] - plain[1]).max() <= 1e-8
+    assert got[2].sum() < plain[2].sum(), (got[2].sum(), plain[2].sum())
 
 
 def test_bdf2_steps_split_over_calls_and_second_order_in_time(monkeypatch):
