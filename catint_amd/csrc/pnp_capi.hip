@@ -86,6 +86,8 @@ struct pnp_handle {
   std::vector<float> lane_key;           // |phiM - phi_bulk| per operating point (pnp_set_batch / pnp_set_pb): the order of a first call
   std::vector<int32_t> lane_iters_host, lane_perm_host;
   bool iters_valid = false;              // h->iters holds the iteration counts of a Newton call on this batch
+  bool lane_perm_keep = false;           // inside one pnp_step call of several launches (BDF2 / predictor): the launches after the first
+  int64_t lane_perm_B = 0;               // keep the first one's order (no read-back, no sort, no synchronisation per timestep)
   double* scf_d = nullptr;               // (4N + 5) B doubles
   double* scf_snap = nullptr;            // (N + 1) ldx B doubles: per-lane state of the last converged transport solve
   int32_t* scf_i = nullptr;              // 3 B flags + 65 counters
@@ -699,6 +701,11 @@ static int lane_order(pnp_handle* h, NewtonArgs& a) {
   // are dealt to slots, and the launch covers ceil(n / points per group) groups instead of the whole batch
   const bool masked = h->newton_mask && h->newton_mask == h->user_mask && (int64_t)h->user_mask_host.size() == B && h->user_mask_count < B;
   if ((h->opt.lane_order == 0 || B < 64) && !masked) return PNP_OK;
+  if (h->lane_perm_keep && h->lane_perm && h->lane_perm_B > 0) {      // the order of this call's first launch
+    a.lane_perm = h->lane_perm;
+    a.B = h->lane_perm_B;
+    return PNP_OK;
+  }
   if (!h->lane_perm) HIP_TRY(h, dev_alloc(h, &h->lane_perm, (size_t)h->cfg.batch_capacity));
   std::vector<int32_t>& perm = h->lane_perm_host;
   perm.resize((size_t)B);
@@ -737,6 +744,7 @@ static int lane_order(pnp_handle* h, NewtonArgs& a) {
   HIP_TRY(h, hipMemcpyAsync(h->lane_perm, perm.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));        // (the host vector may be rewritten by the next call)
   a.lane_perm = h->lane_perm;
+  h->lane_perm_B = a.B;
   return PNP_OK;
 }
 
@@ -812,7 +820,12 @@ static int newton_timesteps(pnp_handle* h, int nsteps) {
   if (pred && h->mpb) HIP_TRY(h, hipMemcpyAsync(h->vol_dev, h->volk, sizeof(double) * PNP_NEWTON_MAX_SPECIES, hipMemcpyHostToDevice, h->stream));
   if (!h->bdf_acc) HIP_TRY(h, dev_alloc(h, &h->bdf_acc, cap * 2));
   HIP_TRY(h, hipMemsetAsync(h->bdf_acc, 0, (size_t)B * 2 * sizeof(int32_t), h->stream));
+  struct KeepPerm {      // (the launches of this call after the first keep its lane order)
+    pnp_handle* h;
+    ~KeepPerm() { h->lane_perm_keep = false; }
+  } keep_guard{h};
   for (int s = 0; s < nsteps; ++s) {
+    h->lane_perm_keep = s > 0;
     if (h->steps_done == 0 || !h->bdf_history) {      // first step of a trajectory: backward Euler from u_0, which becomes the history
       HIP_TRY(h, hipMemcpyAsync(h->c_old2, h->c, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       if (pred) HIP_TRY(h, hipMemcpyAsync(h->phi_old2, h->v, (size_t)B * ldx * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
