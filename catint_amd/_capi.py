@@ -33,7 +33,7 @@ SYMBOLS = [
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_integrate_dopri5', 'pnp_integrate_dop853', 'pnp_integrate_rkc', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_step_row_chunks', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
-    'pnp_set_potential', 'pnp_set_convection', 'pnp_set_option', 'pnp_set_lanes', 'pnp_set_lane_mask', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
+    'pnp_set_potential', 'pnp_set_convection', 'pnp_set_option', 'pnp_get_lane_order', 'pnp_set_lanes', 'pnp_set_lane_mask', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
 ]
 
 
@@ -152,6 +152,8 @@ def load_library():
     lib.pnp_set_convection.restype = C.c_int
     lib.pnp_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.pnp_set_option.restype = C.c_int
+    lib.pnp_get_lane_order.argtypes = [vp, ip]
+    lib.pnp_get_lane_order.restype = C.c_int64
     lib.pnp_solve_surface.argtypes = [vp, dp, C.c_int32, dp, dp, dp, ip]
     lib.pnp_solve_surface.restype = C.c_int
     lib.pnp_scf_cycle.argtypes = [vp, C.POINTER(PnpScfParams), dp, dp, C.POINTER(PnpScfState), ip]
@@ -282,6 +284,14 @@ class PnpSolver(object):
         """Debug / tuning switch of this handle (pnp_set_option): e.g. set_option('NEWTON_KERNEL', 'lane2').  The CATINT_* environment
         variables only provide the defaults at construction."""
         self._check(self._lib.pnp_set_option(self._h, str(key).encode(), str(value).encode()))
+
+    def lane_order(self):
+        """Debug: operating point of every slot of the most recent lane-kernel launch (pnp_get_lane_order); empty if none was used."""
+        n = int(self._lib.pnp_get_lane_order(self._h, None))
+        perm = np.zeros(max(n, 0), np.int32)
+        if n > 0:
+            self._lib.pnp_get_lane_order(self._h, _iptr(perm))
+        return perm
 
     def set_convection(self, velocity):
         """Constant convection velocity (m/s) of the physical mode: tp.system['flow rate'] (comsol_model.py:901-903)."""

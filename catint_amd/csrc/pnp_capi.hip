@@ -369,6 +369,16 @@ int pnp_set_option(pnp_handle* h, const char* key, const char* value) {
   return PNP_OK;
 }
 
+int64_t pnp_get_lane_order(pnp_handle* h, int32_t* perm) {
+  if (!h) return PNP_EINVAL;
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_get_lane_order: the handle was not created with PNP_METHOD_NEWTON");
+  const int64_t n = h->lane_perm_B;
+  if ((int64_t)h->lane_perm_host.size() < n) return 0;
+  if (perm)
+    for (int64_t s_ = 0; s_ < n; ++s_) perm[s_] = h->lane_perm_host[(size_t)s_];
+  return n;
+}
+
 int pnp_set_species(pnp_handle* h, const double* D, const double* charges) {
   if (!h || !D || !charges) return fail(h, PNP_EINVAL, "pnp_set_species: null argument");
   SpecConst sc[PNP_MAX_SPECIES];
@@ -697,6 +707,7 @@ static int step_streams(const pnp_handle* h, int launches) {
 static int lane_order(pnp_handle* h, NewtonArgs& a) {
   a.lane_perm = nullptr;
   const int64_t B = h->B;
+  if (!h->lane_perm_keep) h->lane_perm_B = 0;
   // a solve restricted by pnp_set_lane_mask (the rerun ladder's confirming solve: a handful of recovered lanes): only the lanes it solves
   // are dealt to slots, and the launch covers ceil(n / points per group) groups instead of the whole batch
   const bool masked = h->newton_mask && h->newton_mask == h->user_mask && (int64_t)h->user_mask_host.size() == B && h->user_mask_count < B;

@@ -313,6 +313,12 @@ int pnp_set_lanes(pnp_handle* h, int64_t n, const int64_t* lanes, const double* 
  * mask[b] (the others keep state, status and iteration counters); mask == NULL: all lanes again.  The mask is copied. */
 int pnp_set_lane_mask(pnp_handle* h, const int32_t* mask /* [B] or NULL */);
 
+/* Debug: the order in which the most recent lane-kernel launch of this handle dealt the operating points to its slots (slot s = group *
+ * points per group + lane holds operating point perm[s]; most expected Newton iterations first, pnp_capi.hip: lane_order).  Returns the
+ * number of slots filled (0: the last solve did not use an order -- another kernel family, fewer than 64 points, LANE_ORDER = 0);
+ * perm[that many] (nullable). */
+int64_t pnp_get_lane_order(pnp_handle* h, int32_t* perm);
+
 /* ---- read-back ------------------------------------------------------------------------------ */
 /* Any pointer may be NULL. c[B][N][nx]; v, grad_v, lapl_v [B][nx] are the Poisson solve of the
  * most recent step = tp.potential, -tp.efield, -tp.total_charge/eps (calculator_old.py:816-818). */

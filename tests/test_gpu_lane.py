@@ -284,6 +284,43 @@ def test_points_ordered_by_expected_iterations_give_the_same_bits(kernel, N, nx,
     assert len(set(outs[0][2])) > 1 and (outs[0][5] == 0).all()       # different counts within the batch: the order is not trivial
 
 
+def test_first_solve_after_an_upload_is_ordered_by_the_potential_difference_and_options_are_per_handle(monkeypatch):
+    """pnp_set_batch returned before it reset the lane order of a Newton handle, so the first solve after an upload ran in
+    batch order.  pnp_get_lane_order shows the order of the last launch: after an upload the points are dealt by |phiM - phi_bulk|,
+    largest first; after a solve by the iteration counts of that solve; after the next upload by the potential difference again.
+    And pnp_set_option: two handles of one process run different kernel families (the environment is only read by pnp_create), an
+    unknown key is refused."""
+    monkeypatch.delenv('CATINT_NEWTON_KERNEL', raising=False)
+    N, nx, B = 6, 64, 200
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 19)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    by_potential = np.argsort(-np.abs(phiM).astype(np.float32), kind='stable')
+    with _capi.PnpSolver(N, nx, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s, \
+            _capi.PnpSolver(N, nx, dx, 1.0, BETA, EPS, D, q, method='Newton', batch_capacity=B) as t:
+        s.set_option('NEWTON_KERNEL', 'lane')
+        t.set_option('newton_kernel', 'team')
+        with pytest.raises(_capi.PnpError):
+            s.set_option('NO_SUCH_SWITCH', '1')
+        for solver in (s, t):
+            solver.set_newton()
+            solver.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+        assert len(s.lane_order()) == 0                          # nothing launched yet
+        st = s.solve_stationary()
+        assert (st == 0).all() and np.array_equal(s.lane_order(), by_potential)
+        its = s.newton_iterations()
+        t.solve_stationary()
+        assert len(t.lane_order()) == 0 and np.array_equal(t.newton_iterations(), its)      # lane teams: no order; same counts
+        assert not np.array_equal(s.get_state()[0], t.get_state()[0])                       # ... from another linear solver
+        s.solve_stationary()                                     # warm: ordered by the counts of the solve before
+        o2 = s.lane_order()
+        assert np.array_equal(np.sort(o2), np.arange(B)) and (np.diff(its[o2]) <= 0).all()
+        s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))      # a new upload: the counts are gone, the key is the potential again
+        s.solve_stationary()
+        assert np.array_equal(s.lane_order(), by_potential)
+
+
 @pytest.mark.parametrize("kernel,N,nx", [('lane', 3, 96), ('lane', 8, 64), ('lane2', 6, 80), ('lane2', 8, 48), ('lane4', 5, 80), ('lane4', 8, 48)])
 def test_error_estimate_stopping_rule(kernel, N, nx, monkeypatch):
     """pnp_newton_params.error_estimate: accept an iterate whose quadratic error estimate upd^2 / upd_prev is below the tolerance (saves
