@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             d2 pr;
             pr[0] = held;
             pr[1] = v;
-            REC(i, e >> 1) = pr;
+            __builtin_nontemporal_store(pr, &REC(i, e >> 1));      // (read back a whole pass later: no reason to keep the line)
           }
         };
         solve(rhs, 0);
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         {
           const int i = row_of(0), ir = rec_of(0);
 #pragma unroll
-          for (int p = 0; p < RP; ++p) Rn[p] = REC(ir, p);
+          for (int p = 0; p < RP; ++p) Rn[p] = __builtin_nontemporal_load(&REC(ir, p));
 #pragma unroll
           for (int p = 0; p < VP; ++p) cn2[p] = TS(i, p);
         }
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           if (s + 1 < nu_) {
             const int in = row_of(s + 1), irn = rec_of(s + 1);
 #pragma unroll
-            for (int p = 0; p < RP; ++p) Rn[p] = REC(irn, p);
+            for (int p = 0; p < RP; ++p) Rn[p] = __builtin_nontemporal_load(&REC(irn, p));
 #pragma unroll
             for (int p = 0; p < VP; ++p) cn2[p] = TS(in, p);
           }
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         {
           const int i = bwd_row(0);
 #pragma unroll
-          for (int p = 0; p < RP; ++p) Rn[p] = REC(i, p);
+          for (int p = 0; p < RP; ++p) Rn[p] = __builtin_nontemporal_load(&REC(i, p));
         }
         for (int s = 0; s < nb_; ++s) {
           const bool act = side ? s < n_dn : s < m;
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           if (s + 1 < nb_) {
             const int in = bwd_row(s + 1);
 #pragma unroll
-            for (int p = 0; p < RP; ++p) Rn[p] = REC(in, p);
+            for (int p = 0; p < RP; ++p) Rn[p] = __builtin_nontemporal_load(&REC(in, p));
           }
           if (act) {
             double y[NB];

@@ -533,13 +533,13 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
                 d2 pr;
                 pr[0] = held;
                 pr[1] = 0.0;
-                REC(i, e >> 1) = pr;
+                __builtin_nontemporal_store(pr, &REC(i, e >> 1));
               }
             } else {
               d2 pr;
               pr[0] = held;
               pr[1] = Xl[r][jj];
-              REC(i, e >> 1) = pr;
+              __builtin_nontemporal_store(pr, &REC(i, e >> 1));
             }
           }
         // (middle row: x_m = the solved right-hand side now sits in its owner's t slot Tl[NB >> 1], where the hand-over below takes it;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
       {
         const int i = bwd_row(0);
 #pragma unroll
-        for (int p = 0; p < RP; ++p) Rn[p] = REC(i, p);
+        for (int p = 0; p < RP; ++p) Rn[p] = __builtin_nontemporal_load(&REC(i, p));
       }
       for (int s = 0; s < nb_; ++s) {
         const bool act = side ? s < n_dn : s < m;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
         if (s + 1 < nb_) {
           const int in = bwd_row(s + 1);
 #pragma unroll
-          for (int p = 0; p < RP; ++p) Rn[p] = REC(in, p);
+          for (int p = 0; p < RP; ++p) Rn[p] = __builtin_nontemporal_load(&REC(in, p));
         }
         if (act) {
           // this lane's share of t - T x: its columns (column NB is t itself)

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
                 pr[0] = held;
                 pr[1] = 0.0;
 #ifndef L4_NO_REC_STORE
-                if ((e >> 1) < rp_valid) REC(i, e >> 1) = pr;
+                if ((e >> 1) < rp_valid) __builtin_nontemporal_store(pr, &REC(i, e >> 1));
 #endif
               }
             } else {
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
               pr[0] = held;
               pr[1] = Xl[r][jj];
 #ifndef L4_NO_REC_STORE      // (diagnosis builds, tools/probe/lane4_stamps.sh: results are wrong)
-              if ((e >> 1) < rp_valid) REC(i, e >> 1) = pr;
+              if ((e >> 1) < rp_valid) __builtin_nontemporal_store(pr, &REC(i, e >> 1));
 #else
               asm volatile("" :: "v"(pr));
 #endif
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
           const int i = bwd_row(d);
 #pragma unroll
           for (int p = 0; p < RP; ++p)
-            if (p < rp_valid) Rb[d][p] = REC(i, p);
+            if (p < rp_valid) Rb[d][p] = __builtin_nontemporal_load(&REC(i, p));
         }
       }
       for (int s0 = 0; s0 < nb_; s0 += BD) {
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
           const int in = bwd_row(s + BD);
 #pragma unroll
           for (int p = 0; p < RP; ++p)
-            if (p < rp_valid) Rb[d][p] = REC(in, p);
+            if (p < rp_valid) Rb[d][p] = __builtin_nontemporal_load(&REC(in, p));
         }
         if (act) {
           // this lane's share of t - T x: its columns (column NB is t itself)
