@@ -610,10 +610,12 @@ def main():
     if world > 1 or os.environ.get('CATINT_FORCE_DIST'):     # the env hook lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         torch.cuda.set_device(device)
+        import datetime
+        # (a collective that one rank never joins -- a rank that failed on its own -- raises after five minutes instead of hanging)
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', device))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device), timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
     torch.cuda.set_device(device)
     comm_dev = torch.device('cuda', device) if backend == 'nccl' else torch.device('cpu')
 
