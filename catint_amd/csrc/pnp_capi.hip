@@ -56,6 +56,7 @@ struct pnp_handle {
   double* vol_dev = nullptr;                // ... and the ion volumes for its crowding guard
   int nw_ext_old = 0;                       // set around a prepared step: c_old is given (BDF2 combination or c_n under the predictor)
   double nw_sig_scale = 1.0;                // ... and 1/dt carries the factor 3/2 of BDF2
+  int nw_bdf2_inline = 0, nw_bdf_hist0 = 0; // set around a launch of several BDF2 steps by a lane kernel, which keeps the history itself
   bool bdf_history = false;                 // c_old2 holds the level before the current state (false after an upload, a change of
                                             // time_order, a stationary solve or patched lanes: the next step is backward Euler)
   ReactionSides* rs_dev = nullptr;          // the table flattened per reaction side (lane kernels)
@@ -817,6 +818,30 @@ __global__ void bdf2_accumulate_kernel(int32_t* __restrict__ acc, int32_t* __res
 
 static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, int maxit);
 
+// kernel variant of the handle's physics: 0 point ions, 1 steric ions, 2 + homogeneous reactions and / or the constant convection term
+// (variant 3 is supported by none of the lane kernels: a guard for tables their flattened form could not hold -- none at present,
+// a side has at most PNP_MAX_REACTANTS reactants and the form keeps them one by one)
+static int newton_variant(const pnp_handle* h) {
+  const bool rt = h->rt_dev && h->rt.n > 0;
+  if (rt && h->rs_max_exponent > PNP_MAX_REACTANTS) return 3;
+  return (rt || h->velocity != 0.0) ? 2 : (h->mpb ? 1 : 0);
+}
+
+// (a solve restricted to a few lanes by pnp_set_lane_mask is sized by those lanes: the workgroup-per-point kernels skip masked-out
+// points at once, the lane kernels would walk every group)
+static int64_t newton_effective_batch(const pnp_handle* h) {
+  const bool host_mask = h->newton_mask && h->newton_mask == h->user_mask && (int64_t)h->user_mask_host.size() == h->B;
+  return host_mask ? (h->user_mask_count > 0 ? h->user_mask_count : 1) : h->B;
+}
+
+// will run_newton hand this batch to one of the lane kernels (which take BDF2 steps inside one launch)?
+static bool newton_lane_family(const pnp_handle* h) {
+  const int nb = h->a.N + 1, nx = h->a.nx, variant = newton_variant(h);
+  const int64_t n_eff = newton_effective_batch(h);
+  return newton_lane4_preferred(nb, nx, n_eff, variant, h->opt) || newton_lane2_preferred(nb, nx, n_eff, variant, h->opt) ||
+         newton_lane_preferred(nb, nx, n_eff, variant, h->opt);
+}
+
 // nsteps timesteps of the physical mode: one launch (backward Euler), or one launch per step (BDF2 and / or the predictor)
 static int newton_timesteps(pnp_handle* h, int nsteps) {
   const bool bdf2 = h->np.time_order == 2, pred = h->np.predictor == 1;
@@ -826,6 +851,18 @@ static int newton_timesteps(pnp_handle* h, int nsteps) {
   const int64_t B = h->B;
   const size_t cap = (size_t)h->cfg.batch_capacity;
   if (!h->c_old2) HIP_TRY(h, dev_alloc(h, &h->c_old2, cap * N * ldx));
+  if (bdf2 && !pred && newton_lane_family(h)) {
+    // the lane kernels keep the history themselves: ONE launch for all nsteps (the first step of a trajectory is backward Euler
+    // from u_0, which becomes the history -- as below), c_old2 is the history's home between launches
+    h->nw_bdf2_inline = 1;
+    h->nw_bdf_hist0 = (h->steps_done == 0 || !h->bdf_history) ? 0 : 1;
+    const int rc = run_newton(h, nsteps, false, 0.0, 0);
+    h->nw_bdf2_inline = 0;
+    h->nw_bdf_hist0 = 0;
+    if (rc != PNP_OK) return rc;
+    h->bdf_history = true;
+    return PNP_OK;
+  }
   if (pred && !h->phi_old2) HIP_TRY(h, dev_alloc(h, &h->phi_old2, cap * ldx));
   if (pred && h->mpb && !h->vol_dev) HIP_TRY(h, dev_alloc(h, &h->vol_dev, (size_t)PNP_NEWTON_MAX_SPECIES));
   if (pred && h->mpb) HIP_TRY(h, hipMemcpyAsync(h->vol_dev, h->volk, sizeof(double) * PNP_NEWTON_MAX_SPECIES, hipMemcpyHostToDevice, h->stream));
@@ -903,16 +940,13 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.sides = a.rt ? h->rs_dev : nullptr;
   a.n_wk = h->newton_explicit_kinetics ? 0 : h->n_wk;
   a.lane_mask = h->newton_mask;
-  // (kernel variants: 0 point ions, 1 steric ions, 2 + homogeneous reactions and / or the constant convection term)
-  // (variant 3 is supported by none of the lane kernels: a guard for tables their flattened form could not hold -- none at present,
-  // a side has at most PNP_MAX_REACTANTS reactants and the form keeps them one by one)
-  const int variant = (a.rt && h->rs_max_exponent > PNP_MAX_REACTANTS) ? 3 : ((a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0));
+  const int variant = newton_variant(h);
   a.ext_old = (h->nw_ext_old && !stationary) ? 1 : 0;
+  a.bdf2 = (h->nw_bdf2_inline && !stationary) ? 1 : 0;
+  a.bdf_hist0 = a.bdf2 ? h->nw_bdf_hist0 : 0;
+  a.c_old2 = a.bdf2 ? h->c_old2 : nullptr;
   a.opt = &h->opt;
-  // (a solve restricted to a few lanes by pnp_set_lane_mask is sized by those lanes: the workgroup-per-point kernels skip masked-out
-  // points at once, the lane kernels would walk every group)
-  const bool host_mask = h->newton_mask && h->newton_mask == h->user_mask && (int64_t)h->user_mask_host.size() == h->B;
-  const int64_t n_eff = host_mask ? (h->user_mask_count > 0 ? h->user_mask_count : 1) : h->B;
+  const int64_t n_eff = newton_effective_batch(h);
   const bool use_lane4 = newton_lane4_preferred(N + 1, nx, n_eff, variant, h->opt);
   const bool use_lane2 = !use_lane4 && newton_lane2_preferred(N + 1, nx, n_eff, variant, h->opt);
   const bool use_lane = !use_lane4 && !use_lane2 && newton_lane_preferred(N + 1, nx, n_eff, variant, h->opt);
@@ -933,6 +967,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
     a.lane_xs = a.lane_ts + (size_t)h->lane4_groups * vp2 * nx * 8;
     a.lane_tco = a.lane_xs + (size_t)h->lane4_groups * vp2 * nx * 8;
     a.lane_rec = a.lane_tco + (size_t)h->lane4_groups * cp2 * nx * 8;
+    a.lane_tcn = a.lane_rec + (size_t)h->lane4_groups * newton_lane4_rec_doubles(N + 1, nx);
   } else if (use_lane2) {
     const size_t per_group = (newton_lane2_rec_doubles(N + 1, nx) + newton_lane2_state_doubles(N + 1, nx)) * sizeof(double);
     if (!h->lane2_buf) {
@@ -950,6 +985,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
     a.lane_xs = a.lane_ts + (size_t)h->lane2_groups * vp2 * nx * 16;
     a.lane_tco = a.lane_xs + (size_t)h->lane2_groups * vp2 * nx * 16;
     a.lane_rec = a.lane_tco + (size_t)h->lane2_groups * cp2 * nx * 16;
+    a.lane_tcn = a.lane_rec + (size_t)h->lane2_groups * newton_lane2_rec_doubles(N + 1, nx);
   } else if (use_lane) {
     // one operating point per lane: transposed state + records of as many groups of 32 operating points as the batch capacity has,
     // capped at 48 GiB (the launcher walks a larger batch in chunks)
@@ -969,6 +1005,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
     a.lane_xs = a.lane_ts + (size_t)h->lane_groups * vp2 * nx * 32;
     a.lane_tco = a.lane_xs + (size_t)h->lane_groups * vp2 * nx * 32;
     a.lane_rec = a.lane_tco + (size_t)h->lane_groups * cp2 * nx * 32;
+    a.lane_tcn = a.lane_rec + (size_t)h->lane_groups * newton_lane_rec_doubles(N + 1, nx);
   } else if (newton_sweep_preferred(N + 1, nx, h->B, a.rt ? 2 : (a.mpb ? 1 : 0), h->opt)) {
     // one team (N+1 lanes) per operating point, 64/(N+1) per wave; the workspace holds the records of the resident waves: at
     // most four per SIMD, all of the batch capacity, and 32 GiB

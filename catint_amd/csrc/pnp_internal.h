@@ -201,6 +201,9 @@ struct NewtonArgs {
   double* lane_xs;                       // [groups][nx][(N+2)/2][32][2] Newton update
   double* lane_tco;                      // [groups][nx][(N+1)/2][32][2] previous time level
   double* lane_rec;                      // [groups][nx][((N+1)^2 + (N+1))/2][32][2]
+  double* lane_tcn;                      // [groups][nx][(N+1)/2][32][2] BDF2 inside a launch: the time level before the previous one
+  double* c_old2;                        // [B][N][ldx] its home between launches (null without BDF2)
+  int32_t bdf2, bdf_hist0;               // lane kernels: BDF2 steps inside the launch; c_old2 holds a history at its start
   int64_t lane_groups;                   // groups (of 32 operating points) the three buffers hold
   int64_t lane_group0;                   // first group of this launch (the batch is walked in chunks of lane_groups)
   const int32_t* lane_perm;              // [B] operating point of slot s (slot = group * points per group + lane), or null: slot s holds

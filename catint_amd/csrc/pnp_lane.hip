@@ -54,7 +54,8 @@ constexpr int LG = 32;      // operating points per wave (two lanes each)
 
 size_t newton_lane_rec_doubles(int nb, int nx) { return (size_t)nx * (size_t)(nb * nb + nb) * LG; }
 // ts + xs ((N+1) variables each, padded to pairs) + tco (N, padded)
-size_t newton_lane_state_doubles(int nb, int nx) { return (size_t)nx * (size_t)(2 * ((nb + 1) / 2 * 2) + nb / 2 * 2) * LG; }
+// (... + tcn, the BDF2 history, like tco)
+size_t newton_lane_state_doubles(int nb, int nx) { return (size_t)nx * (size_t)(2 * ((nb + 1) / 2 * 2) + 2 * (nb / 2 * 2)) * LG; }
 
 // ---- state transposition: c[b][k][ldx], phi[b][ldx]  <->  ts[group][i][pair][32][2] (variable N: potential); tco = c on the way in ----
 template <bool IN>
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
   const int t = threadIdx.x;
   double* ts = G.lane_ts + (size_t)g * (size_t)nx * VP * LGr * 2;
   double* tco = G.lane_tco + (size_t)g * (size_t)nx * CP * LGr * 2;
+  double* tcn = G.lane_tcn + (size_t)g * (size_t)nx * CP * LGr * 2;
   const int64_t b0 = (G.lane_group0 + g) * LGr;
   bool bad = false;
   for (int v = 0; v <= N; ++v) {
@@ -94,6 +96,26 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
         }
       }
       __syncthreads();
+      if (G.bdf2 && G.bdf_hist0 && v < N) {      // BDF2 inside the launch: the history c_n-1 comes in from its home between launches
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int op = rr * 4 + (t >> 6), ii = t & 63;
+          const int64_t slot = b0 + op;
+          double val = 0.0;
+          if (op < LGr && slot < G.B && i0 + ii < nx) {
+            const int64_t b = G.lane_perm ? G.lane_perm[slot] : slot;
+            val = G.c_old2[((size_t)b * N + v) * ldx + i0 + ii];
+          }
+          tile[op][ii] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int ii = rr * 8 + (t >> 5), op = t & 31;
+          if (i0 + ii < nx && op < LGr) tcn[(((size_t)(i0 + ii) * CP + (v >> 1)) * LGr + op) * 2 + (v & 1)] = tile[op][ii];
+        }
+        __syncthreads();
+      }
       if (G.ext_old && v < N) {      // the previous-level combination prepared by the caller (BDF2) instead of the state itself
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
@@ -137,6 +159,26 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
         }
       }
       __syncthreads();
+      if (G.bdf2 && v < N) {      // ... and the history goes home
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int ii = rr * 8 + (t >> 5), op = t & 31;
+          double val = 0.0;
+          if (i0 + ii < nx && op < LGr) val = tcn[(((size_t)(i0 + ii) * CP + (v >> 1)) * LGr + op) * 2 + (v & 1)];
+          tile[op][ii] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int op = rr * 4 + (t >> 6), ii = t & 63;
+          const int64_t slot = b0 + op;
+          if (op < LGr && slot < G.B && i0 + ii < nx) {
+            const int64_t b = G.lane_perm ? G.lane_perm[slot] : slot;
+            if (!(G.lane_mask && !G.lane_mask[b])) G.c_old2[((size_t)b * N + v) * ldx + i0 + ii] = tile[op][ii];
+          }
+        }
+        __syncthreads();
+      }
     }
   }
   if constexpr (!IN) {
@@ -185,6 +227,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   d2* ts = (d2*)G.lane_ts + (size_t)g * (size_t)nx * VP * LG + o;
   d2* xs = (d2*)G.lane_xs + (size_t)g * (size_t)nx * VP * LG + o;
   d2* tco = (d2*)G.lane_tco + (size_t)g * (size_t)nx * CP * LG + o;
+  d2* tcn = (d2*)G.lane_tcn + (size_t)g * (size_t)nx * CP * LG + o;      // BDF2: the time level before the previous one
   d2* rec = (d2*)G.lane_rec + (size_t)g * (size_t)nx * RP * LG + o;
   // Two copies of the state (G.lane_ts, G.lane_xs): the back-substitution of an iteration reads the current one and writes the updated
   // state into the other (see "backward" below); `cur` says which one is current for this lane's operating point.
@@ -194,6 +237,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   auto TN = [&](int i, int p) -> d2& { return tsn[((size_t)i * VP + p) * LG]; };      // the state being written
   auto XS = [&](int i, int p) -> d2& { return xs[((size_t)i * VP + p) * LG]; };       // (!FUSED: the Newton update; cur stays 0)
   auto CO = [&](int i, int p) -> d2& { return tco[((size_t)i * CP + p) * LG]; };
+  auto CN = [&](int i, int p) -> d2& { return tcn[((size_t)i * CP + p) * LG]; };
   auto REC = [&](int i, int p) -> d2& { return rec[((size_t)i * RP + p) * LG]; };
   const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
   if (!side) {
@@ -233,6 +277,11 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
     tsn = cur ? ts : xs;
     // first iteration of a timestep: the previous time level is the state itself -- unless the caller prepared it (BDF2: G.ext_old)
     const bool first = fresh && !G.ext_old;
+    // BDF2 inside a launch of several timesteps (G.bdf2, lane kernels): a step has a history -- the time level before the previous one,
+    // kept in CN -- if the launch started with one or it is not the operating point's first step; then the previous-level value is the
+    // combination (4 c_n - c_n-1) / 3 and 1/dt carries 3/2 (pnp_capi.hip: newton_timesteps; comsol_model.py:518-531, maxorder 2)
+    const bool hist = G.bdf2 && have && (G.bdf_hist0 || step > 0);
+    const double sgs = hist ? 1.5 : 1.0;
     if (fresh) {
       it = 0;
       upd_prev = INFINITY;
@@ -263,7 +312,9 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       for (int r = 0; r < NB; ++r) Tset(j, r, 0.0);
     }
     // inputs of the next row, requested one row ahead: the point ahead, the previous time level, the grid weights
-    d2 p_a[VP], p_co[CP];
+    d2 p_a[VP], p_co[CP], p_cn[CP];
+#pragma unroll
+    for (int p = 0; p < CP; ++p) p_cn[p] = (d2)(0.0);
     double p_vi, p_wea, p_web;
     auto request = [&](int s) {
       const int i = fwd_row(s);
@@ -272,6 +323,10 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       for (int p = 0; p < VP; ++p) p_a[p] = TS(ia, p);
 #pragma unroll
       for (int p = 0; p < CP; ++p) p_co[p] = CO(i, p);
+      if (first && hist) {      // (first iteration of a BDF2 step: the level before the previous one, read once per step)
+#pragma unroll
+        for (int p = 0; p < CP; ++p) p_cn[p] = CN(i, p);
+      }
       p_vi = G.gv[i];
       p_wea = G.gw[side ? i - 1 : i];
       p_web = G.gw[side ? i : (i > 0 ? i - 1 : 0)];
@@ -348,6 +403,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             v[0] = bc[2 * p];
             v[1] = 2 * p + 1 < N ? bc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
             CO(nx - 1, p) = v;
+            if (G.bdf2 && have) CN(nx - 1, p) = v;
           }
         }
       }
@@ -357,11 +413,12 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       const bool last = s == S - 1;     // the middle row: upward half only
       const bool act = last ? !side : (side ? s < n_dn : s < m);
       // this row's inputs have arrived during the previous row; the next row's are requested before this row's stores are issued
-      double ac[N], aphi, co[N];
+      double ac[N], aphi, co[N], cnv[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         ac[k] = p_a[k >> 1][k & 1];
         co[k] = p_co[k >> 1][k & 1];
+        cnv[k] = p_cn[k >> 1][k & 1];
       }
       aphi = p_a[N >> 1][N & 1];
       const double vi = p_vi, wea = p_wea, web_ = p_web;
@@ -410,19 +467,28 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         // ---- right-hand side and the diagonal block's ingredients ---------------------------------------------------------
         double rhs[NB], diag[N], Js[N];
         double rho = 0.0;
+        double cs_[N];      // the previous-level value of this step: the state itself (backward Euler) or the BDF2 combination
+#pragma unroll
+        for (int k = 0; k < N; ++k) cs_[k] = (first && hist) ? (4.0 * hc[k] - cnv[k]) / 3.0 : hc[k];
         if (first) {
 #pragma unroll
           for (int p = 0; p < CP; ++p) {
             d2 v;
-            v[0] = hc[2 * p];
-            v[1] = 2 * p + 1 < N ? hc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
+            v[0] = cs_[2 * p];
+            v[1] = 2 * p + 1 < N ? cs_[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
             CO(i, p) = v;
+            if (G.bdf2 && have) {      // (a finished point runs along with its wave: its history stays)
+              d2 w_;
+              w_[0] = hc[2 * p];
+              w_[1] = 2 * p + 1 < N ? hc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
+              CN(i, p) = w_;
+            }
           }
         }
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-          const double cok = first ? hc[k] : co[k];
-          const double sg = vi * P->sig[k];
+          const double cok = first ? cs_[k] : co[k];
+          const double sg = vi * P->sig[k] * sgs;
           rho = __builtin_fma(P->peq[k], hc[k], rho);
           double F = sg * (hc[k] - cok) + aJ[k] + eJ[k];
           if (wall) F -= G.flux[(size_t)b * N + k] * A.fl[k];

@@ -62,7 +62,7 @@ template <int NB> struct QuadShape {
 
 // per group of 8 operating points
 size_t newton_lane4_rec_doubles(int nb, int nx) { return (size_t)nx * 4 * (size_t)((((nb + 4) / 4) * nb + 1) / 2 * 2) * QG; }
-size_t newton_lane4_state_doubles(int nb, int nx) { return (size_t)nx * (size_t)(2 * ((nb + 1) / 2 * 2) + nb / 2 * 2) * QG; }
+size_t newton_lane4_state_doubles(int nb, int nx) { return (size_t)nx * (size_t)(2 * ((nb + 1) / 2 * 2) + 2 * (nb / 2 * 2)) * QG; }
 
 template <int NB, int MODE>
 __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
@@ -92,10 +92,12 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
   d2* ts = (d2*)G.lane_ts + (size_t)g * (size_t)nx * VP * QG + o;
   d2* xs = (d2*)G.lane_xs + (size_t)g * (size_t)nx * VP * QG + o;
   d2* tco = (d2*)G.lane_tco + (size_t)g * (size_t)nx * CP * QG + o;
+  d2* tcn = (d2*)G.lane_tcn + (size_t)g * (size_t)nx * CP * QG + o;      // BDF2: the time level before the previous one
   d2* rec = (d2*)G.lane_rec + (size_t)g * (size_t)nx * 4 * RP * QG + (size_t)q * RP * QG + o;      // this column lane's records
   auto TS = [&](int i, int p) -> d2& { return ts[((size_t)i * VP + p) * QG]; };
   auto XS = [&](int i, int p) -> d2& { return xs[((size_t)i * VP + p) * QG]; };
   auto CO = [&](int i, int p) -> d2& { return tco[((size_t)i * CP + p) * QG]; };
+  auto CN = [&](int i, int p) -> d2& { return tcn[((size_t)i * CP + p) * QG]; };
   auto REC = [&](int i, int p) -> d2& { return rec[((size_t)i * 4 * RP + p) * QG]; };
   const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
   if ((lane & 7) == 0) {
@@ -149,6 +151,11 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     const NewtonArgs& A = G;
     // first iteration of a timestep: the previous time level is the state itself -- unless the caller prepared it (BDF2: G.ext_old)
     const bool first = fresh && !G.ext_old;
+    // BDF2 inside a launch of several timesteps (G.bdf2, lane kernels): a step has a history -- the time level before the previous one,
+    // kept in CN -- if the launch started with one or it is not the operating point's first step; then the previous-level value is the
+    // combination (4 c_n - c_n-1) / 3 and 1/dt carries 3/2 (pnp_capi.hip: newton_timesteps; comsol_model.py:518-531, maxorder 2)
+    const bool hist = G.bdf2 && have && (G.bdf_hist0 || step > 0);
+    const double sgs = hist ? 1.5 : 1.0;
     if (fresh) {
       it = 0;
       upd_prev = INFINITY;
@@ -167,7 +174,9 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     for (int jj = 0; jj < CL; ++jj)
 #pragma unroll
       for (int r = 0; r < NB; ++r) Tl[jj][r] = 0.0;
-    d2 p_a[VP], p_co[CP];
+    d2 p_a[VP], p_co[CP], p_cn[CP];
+#pragma unroll
+    for (int p = 0; p < CP; ++p) p_cn[p] = (d2)(0.0);
     double p_vi, p_wea, p_web;
     auto request = [&](int s) {
 #ifdef L4_NO_REQUEST      // (diagnosis build: every row reads the first one again -- cache hits)
@@ -180,6 +189,10 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
       for (int p = 0; p < VP; ++p) p_a[p] = TS(ia, p);
 #pragma unroll
       for (int p = 0; p < CP; ++p) p_co[p] = CO(i, p);
+      if (first && hist) {      // (first iteration of a BDF2 step: the level before the previous one, read once per step)
+#pragma unroll
+        for (int p = 0; p < CP; ++p) p_cn[p] = CN(i, p);
+      }
       p_vi = G.gv[i];
       p_wea = G.gw[side ? i - 1 : i];
       p_web = G.gw[side ? i : (i > 0 ? i - 1 : 0)];
@@ -256,6 +269,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
               v[0] = bc[2 * p];
               v[1] = 2 * p + 1 < N ? bc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
               CO(nx - 1, p) = v;
+              if (G.bdf2 && have) CN(nx - 1, p) = v;
             }
           }
         }
@@ -265,11 +279,12 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     for (int s = 0; s < S; ++s) {
       const bool last = s == S - 1;
       const bool act = last ? !side : (side ? s < n_dn : s < m);
-      double ac[N], aphi, co[N];
+      double ac[N], aphi, co[N], cnv[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         ac[k] = p_a[k >> 1][k & 1];
         co[k] = p_co[k >> 1][k & 1];
+        cnv[k] = p_cn[k >> 1][k & 1];
       }
       aphi = p_a[N >> 1][N & 1];
       const double vi = p_vi, wea = p_wea, web = p_web;
@@ -340,19 +355,28 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
         // ---- right-hand side and the diagonal block's ingredients (every species, all column lanes) -----------------------------------
         double rhs[NB], diag[N], Js[N];
         double rho = 0.0;
+        double cs_[N];      // the previous-level value of this step: the state itself (backward Euler) or the BDF2 combination
+#pragma unroll
+        for (int k = 0; k < N; ++k) cs_[k] = (first && hist) ? (4.0 * hc[k] - cnv[k]) / 3.0 : hc[k];
         if (first && q == 0) {
 #pragma unroll
           for (int p = 0; p < CP; ++p) {
             d2 v;
-            v[0] = hc[2 * p];
-            v[1] = 2 * p + 1 < N ? hc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
+            v[0] = cs_[2 * p];
+            v[1] = 2 * p + 1 < N ? cs_[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
             CO(i, p) = v;
+            if (G.bdf2 && have) {      // (a finished point runs along with its wave: its history stays)
+              d2 w_;
+              w_[0] = hc[2 * p];
+              w_[1] = 2 * p + 1 < N ? hc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
+              CN(i, p) = w_;
+            }
           }
         }
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-          const double cok = first ? hc[k] : co[k];
-          const double sg = vi * P->sig[k];
+          const double cok = first ? cs_[k] : co[k];
+          const double sg = vi * P->sig[k] * sgs;
           rho = __builtin_fma(P->peq[k], hc[k], rho);
           double F = sg * (hc[k] - cok) + aJ[k] + eJ[k];
           if (wall) F -= G.flux[(size_t)b * N + k] * A.fl[k];

@@ -599,12 +599,14 @@ def test_predictor_matches_oracle_and_saves_iterations(N, nx, B, kernel, kw, mon
     assert got[2].sum() < plain[2].sum(), (got[2].sum(), plain[2].sum())
 
 
-def test_bdf2_steps_split_over_calls_and_second_order_in_time(monkeypatch):
+@pytest.mark.parametrize("kernel,N,B", [('', 3, 6), ('lane', 6, 70), ('lane2', 6, 37), ('lane4', 6, 21)])
+def test_bdf2_steps_split_over_calls_and_second_order_in_time(kernel, N, B, monkeypatch):
     """The BDF2 history (c_n-1) lives on the handle: pnp_step(2) + pnp_step(3) == pnp_step(5) to the bit, iteration counts of a call are
     the sums over its steps.  And the point of the option: halving dt cuts the error of a diffusion-dominated relaxation four-fold
-    (backward Euler: two-fold)."""
-    monkeypatch.setenv('CATINT_NEWTON_KERNEL', '')
-    N, nx, B = 3, 96, 6
+    (backward Euler: two-fold).  (The lane kernels take all steps of a call in ONE launch and keep the history in their own layout;
+    between calls it goes home to the handle -- the split must not show there either.)"""
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    nx = 96
     D, q, cb, dx, phiM = make_lanes(N, nx, B, 3)
     c0 = np.repeat(cb[:, :, None], nx, axis=2)
     pb = np.zeros((B, 4))
