@@ -302,12 +302,15 @@ def at_rounding_floor(upd, upd_prev, tol):
 
 
 def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver=solve_block_tridiagonal,
-                verbose=False, estimate=False):
+                verbose=False, estimate=False, jacobian_once=False):
     """Solve one backward-Euler step (or, with dt=inf, the stationary problem) by damped Newton.
     Damping (identical on the device): the whole update is scaled so that |d phi| <= dphi_max, a concentration
     never drops below 10 % of its previous iterate, and neither does the free volume fraction 1-phi0 (MPB).
     Converged when the scaled update max(|dc_k,i|/(c_k,i + c_bulk_k), |dphi| beta max|q|) < tol on a full step, or when the
     iteration sits on its rounding floor (see below).
+    jacobian_once=True: the Jacobian of the first iterate serves every iteration of the step (the chord iteration COMSOL is told
+    to run, comsol_model.py:526,530 jtech "once") -- a measuring option of the oracle only (tools/probe/jacobian_once_oracle.py: how many
+    iterations the chord needs on the bench workloads); the library factorises every iteration.
     Returns (c, phi, iterations, history of update norms); iterations = maxit+1 if not converged."""
     c = c.copy(); phi = phi.copy()
     N = p.N
@@ -315,7 +318,10 @@ def newton_step(p, c, phi, c_old, dt, tol=1e-10, maxit=50, dphi_max=0.05, solver
     hist = []
     upd_prev = np.inf
     for it in range(1, maxit + 1):
-        F, L, M, U = residual_and_jacobian(p, c, phi, c_old, dt)
+        if jacobian_once and it > 1:
+            F = residual(p, c, phi, c_old, dt)
+        else:
+            F, L, M, U = residual_and_jacobian(p, c, phi, c_old, dt)
         if not (np.all(np.isfinite(F)) and np.all(np.isfinite(M))):      # diverged: the device keeps iterating on NaNs and reports
             c = np.full_like(c, np.nan)                                   # maxit+1 iterations and the NaN status
             phi = np.full_like(phi, np.nan)

@@ -425,6 +425,27 @@ def test_bdf2_is_second_order_in_time():
     assert 1.7 < ratio[False] < 2.4 and 3.2 < ratio[True] < 5.0, ratio
 
 
+def test_jacobian_once_is_the_chord_iteration_same_fixed_point_more_iterations():
+    """newton_step(jacobian_once=True): the Jacobian of the first iterate serves the whole step (comsol_model.py:526,530 jtech "once").
+    Same equations, same stopping rule: the step ends on the same state to the tolerance, linearly instead of quadratically -- more
+    iterations, each update a roughly constant fraction of the one before (tools/probe/jacobian_once_oracle.py measures what that costs)."""
+    from catint_amd.units import unit_F, unit_R, unit_eps0
+    nx = 64
+    D, q, cb = np.array([1.957e-9, 1.185e-9]), np.array([unit_F, -unit_F]), np.array([10.0, 10.0])
+    beta, eps = 1.0 / (unit_R * 298.14), 78.36 * unit_eps0
+    dx = np.sqrt(eps / beta / (q ** 2 * cb).sum()) / 4.0
+    p = PH.PhysicalProblem(D=D, charges=q, beta=beta, eps=eps, dx=dx, nx=nx, c_bulk=cb, phiM=-0.08)
+    c0 = np.repeat(cb[:, None], nx, axis=1)
+    dt = 0.02 * (nx * dx) ** 2 / D.max()
+    c1, p1, it1, h1 = PH.newton_step(p, c0, np.zeros(nx), c0, dt, tol=1e-10)
+    c2, p2, it2, h2 = PH.newton_step(p, c0, np.zeros(nx), c0, dt, tol=1e-10, jacobian_once=True)
+    assert it1 <= 50 and it2 <= 50 and it2 > it1, (it1, it2)
+    assert np.abs(c2 - c1).max() <= 1e-8 * np.abs(c1).max() and np.abs(p2 - p1).max() <= 1e-9
+    assert h1[0] == h2[0]                                     # the first iteration is Newton's
+    tail = np.array(h2[-4:])
+    assert np.all(tail[1:] < tail[:-1]) and np.all(tail[1:] > 1e-4 * tail[:-1])      # linear: no update a millionth of the one before
+
+
 def test_convection_velocity_analytic_profile_and_flux_closure():
     """Constant velocity v along x (tp.system['flow rate'], comsol_model.py:901-903): flux -D c' + c v.  A neutral species with a closed
     wall relaxes to c(x) = c_L exp(v (x - L) / D); the exponentially fitted edge flux reproduces it to rounding on any grid, for both
