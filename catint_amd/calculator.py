@@ -559,82 +559,113 @@ class Calculator(object):
             cout, status, (v, g, l) = self.integrate_pnp_batch(c0, pb, vz, flux)
         self.status = status
         kf = getattr(self, 'kinetic_flux', None) if self.physical else None
-        for i in range(B):
-            self.fill_alldata(i, cout[-1, i].reshape(tp.nspecies, tp.nx), v[i], g[i], l[i], flux[i], int(status[i]),
-                              None if kf is None else kf[i])
+        self.fill_alldata_batch(cout[-1].reshape(B, tp.nspecies, tp.nx), v, g, l, flux, status, kf)
         return cout
 
     # ------------------------------------------------------------------------------------------
     def fill_alldata(self, i, cfin, v, g, l, flux, status, kinetic_flux=None):
-        """Descriptor point i: tp.alldata[i]['species'|'system'] in the field contract of the reference's reader
-        (comsol_reader.py:196-326) from the arrays a transport solve leaves behind -- cfin [N][nx], potential v,
-        gradient g and charge row l [nx], prescribed wall fluxes flux [N].  Host arithmetic only (tests/test_results_io.py walks
-        the reference's plotting accesses over its output without a GPU)."""
+        """Descriptor point i alone (fill_alldata_batch with one lane)."""
+        self.fill_alldata_batch(np.asarray(cfin)[None], np.asarray(v)[None], np.asarray(g)[None], np.asarray(l)[None],
+                                np.asarray(flux)[None], [status], None if kinetic_flux is None else np.asarray(kinetic_flux)[None], first=i)
+        return self.tp.alldata[i]
+
+    def fill_alldata_batch(self, cfin, v, g, l, flux, status, kinetic_flux=None, first=0):
+        """Descriptor points first ... first + B - 1: tp.alldata[i]['species'|'system'] in the field contract of the reference's reader
+        (comsol_reader.py:196-326) from the arrays a transport solve leaves behind -- cfin [B][N][nx], potential v,
+        gradient g and charge row l [B][nx], prescribed wall fluxes flux [B][N].  Host arithmetic only, one numpy pass per 64 lanes
+        (a sweep of 4096 voltages spent 0.5 s here point by point, three times its transport solves); the per-point entries are
+        rows of the batch arrays.  (tests/test_results_io.py walks the reference's plotting accesses over its output without a GPU.)"""
         tp = self.tp
         from .units import unit_NA
+        if len(cfin) > 64:          # (cache-sized pieces: the ~20 temporaries of 64 lanes x N x nx stay in L2)
+            for a in range(0, len(cfin), 64):
+                e = a + 64
+                self.fill_alldata_batch(cfin[a:e], v[a:e], g[a:e], l[a:e], flux[a:e], status[a:e],
+                                        None if kinetic_flux is None else kinetic_flux[a:e], first=first + a)
+            return
+        cfin = np.array(cfin, dtype=float)                      # (own copies: the dictionaries keep rows of these arrays)
+        v = np.array(v, dtype=float)
+        g = np.asarray(g, float)
+        l = np.asarray(l, float)
+        flux = np.asarray(flux, float)
+        B = cfin.shape[0]
         keys = list(tp.descriptors.keys())
-        lane = tp.alldata_names[i]
         names = list(tp.species.keys())
         radii = np.array([float(tp.species[sp].get('MPB_radius', 0.0)) for sp in names])
-        d = tp.alldata[i]
-        for k, sp in enumerate(names):
-            d['species'][sp] = {'concentration': cfin[k].copy(), 'surface_concentration': float(cfin[k, 0])}
-        d['system'] = {'potential': v.copy(), 'efield': -g, 'charge_density': -l * tp.eps,
-                       'surface_potential': float(v[0]), 'surface_efield': float(-g[0]),
-                       keys[0]: lane[0], keys[1]: lane[1], 'status': int(status)}
+        efield, rho = -g, -l * tp.eps
+        for b in range(B):
+            i = first + b
+            lane = tp.alldata_names[i]
+            d = tp.alldata[i]
+            for k, sp in enumerate(names):
+                d['species'][sp] = {'concentration': cfin[b, k], 'surface_concentration': float(cfin[b, k, 0])}
+            d['system'] = {'potential': v[b], 'efield': efield[b], 'charge_density': rho[b],
+                           'surface_potential': float(v[b, 0]), 'surface_efield': float(efield[b, 0]),
+                           keys[0]: lane[0], keys[1]: lane[1], 'status': int(status[b])}
         if not self.physical:
-            return d
+            return
         # derived fields of the COMSOL reader (comsol_reader.py:57-90, :196-230, :241-261)
-        gamma = 1.0 / (1.0 - (unit_NA * radii[:, None] ** 3 * cfin).sum(axis=0))
+        gamma = 1.0 / (1.0 - (unit_NA * radii[None, :, None] ** 3 * cfin).sum(axis=1))                 # [B][nx]
         ers = getattr(tp, 'electrode_reactions', None) or {}
+        jwall = flux + (np.asarray(kinetic_flux, float) if kinetic_flux is not None else 0.0)          # [B][N]
+        current = {}
         for k, sp in enumerate(names):
-            d['species'][sp]['activity_coefficient'] = gamma.copy()
-            d['species'][sp]['surface_activity_coefficient'] = float(gamma[0])
-            j = float(flux[k] + (kinetic_flux[k] if kinetic_flux is not None else 0.0))
-            d['species'][sp]['electrode_flux'] = j
             if sp in ers and 'nel' in ers[sp]:          # mA/cm^2, comsol_reader.py:241-246
                 nprod = len([a for a in ers[sp]['reaction'][1] if a == sp])
-                d['species'][sp]['electrode_current_density'] = j * ers[sp]['nel'] * unit_F / nprod / 10.
+                current[sp] = (k, ers[sp]['nel'], nprod)
         with np.errstate(divide='ignore', invalid='ignore'):
             if 'H+' in names:
-                ph = -np.log10(cfin[names.index('H+')] / 1000.)
+                ph = -np.log10(cfin[:, names.index('H+')] / 1000.)
             elif 'OH-' in names:
-                ph = 14 + np.log10(cfin[names.index('OH-')] / 1000.)
+                ph = 14 + np.log10(cfin[:, names.index('OH-')] / 1000.)
             else:
                 ph = None
-        if ph is not None:
-            d['system']['pH'] = ph - np.log10(gamma)
-            d['system']['surface_pH'] = float(ph[0] - np.log10(gamma[0]))
-        d['system']['activity_coefficient'] = gamma.copy()
+            pH = None if ph is None else ph - np.log10(gamma)
         # derived electrolyte quantities of the COMSOL model (comsol_model.py:1010-1040), on the cell edges
         x = np.asarray(tp.xmesh, float)
         h = np.diff(x)
         z = tp.charges / unit_F
-        cmid = 0.5 * (cfin[:, 1:] + cfin[:, :-1])
+        cmid = 0.5 * (cfin[:, :, 1:] + cfin[:, :, :-1])
         um = tp.D * tp.beta                                            # mobility D/(RT)
-        kappa = unit_F ** 2 * ((z ** 2 * um)[:, None] * cmid).sum(axis=0)              # rho_c, S/m
+        kappa = unit_F ** 2 * ((z ** 2 * um)[None, :, None] * cmid).sum(axis=1)        # rho_c, S/m
         w = -np.log(1.0 / gamma)                                                       # -ln(1-phi0)
-        u = (tp.charges * tp.beta)[:, None] * np.diff(v)[None, :] + np.diff(w)[None, :]
+        u = (tp.charges * tp.beta)[None, :, None] * np.diff(v, axis=1)[:, None, :] + np.diff(w, axis=1)[:, None, :]
         with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
             Bu = np.where(np.abs(u) < 1e-8, 1.0 - 0.5 * u, u / np.expm1(u))
-        jtot = -(tp.D[:, None] / h[None, :]) * ((Bu + u) * cfin[:, 1:] - Bu * cfin[:, :-1])   # Scharfetter-Gummel flux
-        jdif = -(tp.D[:, None] / h[None, :]) * np.diff(cfin, axis=1)
-        i_el = unit_F * (z[:, None] * jtot).sum(axis=0)                                # A/m^2
+        Dh = tp.D[None, :, None] / h[None, None, :]
+        jtot = -Dh * ((Bu + u) * cfin[:, :, 1:] - Bu * cfin[:, :, :-1])                # Scharfetter-Gummel flux
+        jdif = -Dh * np.diff(cfin, axis=2)
+        i_el = unit_F * (z[None, :, None] * jtot).sum(axis=1)                          # A/m^2
+        zero = np.zeros((B, 1))
         with np.errstate(divide='ignore', invalid='ignore'):
-            dphi_iR = np.concatenate([[0.0], np.cumsum(np.where(kappa > 0, -i_el / kappa, 0.0) * h)])
-            dphi_diff = np.concatenate([[0.0], np.cumsum(np.where(kappa > 0, unit_F * (z[:, None] * jdif).sum(axis=0) / kappa, 0.0) * h)])
-        d['system'].update({'conductivity': kappa, 'electrolyte_current_density': i_el, 'delta_phi_iR': dphi_iR,
-                            'delta_phi_diff': dphi_diff, 'delta_phi_iR_inf': float(dphi_iR[-1]),
-                            'delta_phi_diff_inf': float(dphi_diff[-1]), 'delta_phi_inf': float(v[-1] - v[0]),
-                            'delta_phi_inf_min_iR': float(v[-1] - v[0] - dphi_iR[-1])})
+            dphi_iR = np.concatenate([zero, np.cumsum(np.where(kappa > 0, -i_el / kappa, 0.0) * h[None, :], axis=1)], axis=1)
+            dphi_diff = np.concatenate([zero, np.cumsum(np.where(kappa > 0, unit_F * (z[None, :, None] * jdif).sum(axis=1) / kappa, 0.0)
+                                                         * h[None, :], axis=1)], axis=1)
         es = tp.system.get('Stern epsilon', None)
-        if isinstance(es, (int, float)) and es:
-            d['system']['Stern_efield'] = float(-g[0]) * tp.system['epsilon'] / es
-            d['system']['Stern_epsilon_func'] = es
-        elif es == 'Booth':           # field-dependent Stern permittivity, comsol_reader.py:102-119, :262-273
-            from .host import booth_stern_field
-            d['system']['Stern_efield'], d['system']['Stern_epsilon_func'] = booth_stern_field(-g[0], tp.system['epsilon'])
-        return d
+        for b in range(B):
+            d = tp.alldata[first + b]
+            for k, sp in enumerate(names):
+                ds = d['species'][sp]
+                ds['activity_coefficient'] = gamma[b].copy()
+                ds['surface_activity_coefficient'] = float(gamma[b, 0])
+                ds['electrode_flux'] = float(jwall[b, k])
+            for sp, (k, nel, nprod) in current.items():
+                d['species'][sp]['electrode_current_density'] = float(jwall[b, k]) * nel * unit_F / nprod / 10.
+            dsys = d['system']
+            if pH is not None:
+                dsys['pH'] = pH[b]
+                dsys['surface_pH'] = float(pH[b, 0])
+            dsys['activity_coefficient'] = gamma[b]
+            dsys.update({'conductivity': kappa[b], 'electrolyte_current_density': i_el[b], 'delta_phi_iR': dphi_iR[b],
+                         'delta_phi_diff': dphi_diff[b], 'delta_phi_iR_inf': float(dphi_iR[b, -1]),
+                         'delta_phi_diff_inf': float(dphi_diff[b, -1]), 'delta_phi_inf': float(v[b, -1] - v[b, 0]),
+                         'delta_phi_inf_min_iR': float(v[b, -1] - v[b, 0] - dphi_iR[b, -1])})
+            if isinstance(es, (int, float)) and es:
+                dsys['Stern_efield'] = float(efield[b, 0]) * tp.system['epsilon'] / es
+                dsys['Stern_epsilon_func'] = es
+            elif es == 'Booth':           # field-dependent Stern permittivity, comsol_reader.py:102-119, :262-273
+                from .host import booth_stern_field
+                dsys['Stern_efield'], dsys['Stern_epsilon_func'] = booth_stern_field(efield[b, 0], tp.system['epsilon'])
 
     # ------------------------------------------------------------------------------------------
     def _lane_inputs(self):

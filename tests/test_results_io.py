@@ -35,7 +35,7 @@ def test_nine_pickles_round_trip(tmp_path):
     assert len(tp2.alldata_step3) == 2
 
 
-def synthetic_sweep(lanes=3, nx=48, numeric_flux=False):
+def synthetic_sweep(lanes=3, nx=48, numeric_flux=False, batch=False):
     """The run.py system (reference input dictionaries) with `lanes` descriptor points whose alldata entries are filled by the SAME
     host code a GPU sweep uses (Calculator.fill_alldata) from smooth synthetic profiles -- no GPU needed."""
     import collections
@@ -53,6 +53,7 @@ def synthetic_sweep(lanes=3, nx=48, numeric_flux=False):
     calc = Calculator(transport=tp, calc='comsol')
     x = tp.xmesh / tp.xmesh[-1]
     cb = np.array([tp.species[sp]['bulk_concentration'] for sp in tp.species])
+    rows = []
     for i, phi in enumerate(phis):
         v = (phi - 0.16) * 0.3 * np.exp(-40.0 * x)
         c = cb[:, None] * np.exp(-(tp.charges * tp.beta)[:, None] * v[None, :] * 0.2) * (1.0 + 0.1 * (i + 1) * (1 - x)[None, :]) + 1e-6
@@ -61,8 +62,34 @@ def synthetic_sweep(lanes=3, nx=48, numeric_flux=False):
         kin = np.zeros(tp.nspecies)
         names = list(tp.species)
         kin[names.index('CO2')], kin[names.index('CO')], kin[names.index('OH-')] = -1e-5 * (i + 1), 1e-5 * (i + 1), 2e-5 * (i + 1)
-        calc.fill_alldata(i, c, v, g, l, tp.flux_bound[:, 0], 0, kin)
+        if batch:
+            rows.append((c, v, g, l, tp.flux_bound[:, 0], 0, kin))
+        else:
+            calc.fill_alldata(i, c, v, g, l, tp.flux_bound[:, 0], 0, kin)
+    if batch:          # the whole sweep in one call, as Calculator.run does
+        calc.fill_alldata_batch(*[np.array([r[j] for r in rows]) for j in range(7)])
     return tp
+
+
+def test_fill_alldata_batch_equals_point_by_point():
+    """Calculator.run fills tp.alldata for the whole sweep in one numpy pass (fill_alldata_batch); descriptor point by descriptor point
+    (fill_alldata, one lane) must give the same dictionaries: same keys, same types, same numbers to the bit."""
+    one, all_ = synthetic_sweep(lanes=4), synthetic_sweep(lanes=4, batch=True)
+
+    def same(a, b, path):
+        assert type(a) is type(b), (path, type(a), type(b))
+        if isinstance(a, dict):
+            assert list(a) == list(b), (path, list(a), list(b))
+            for k in a:
+                same(a[k], b[k], path + '/' + str(k))
+        elif isinstance(a, np.ndarray):
+            assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True), path
+        else:
+            assert a == b or (a != a and b != b), (path, a, b)
+    for i in range(4):
+        same(one.alldata[i], all_.alldata[i], 'alldata[%d]' % i)
+    all_.alldata[0]['system']['potential'][0] = 123.0               # rows of one batch array: a lane's entry is its own
+    assert all_.alldata[1]['system']['potential'][0] != 123.0
 
 
 def test_reference_reader_manifest(tmp_path):
