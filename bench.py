@@ -405,7 +405,7 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
     def lane_bytes(N_, nx_, fused=False):
         # per grid row and Newton iteration, in doubles: records (N+1)(N+2) written by the forward pass and read by the back-substitution;
         # state: forward reads c, phi, c_old (2N+1); then either the Newton update is written (N+1), read back with the state (2N+2) and
-        # the new state written (N+1) -- three passes, 6N+5 -- or (lane kernel from 24 576 points on: update fused into the
+        # the new state written (N+1) -- three passes, 6N+5 -- or (the lane kernel on timesteps: update fused into the
         # back-substitution, two state copies) the state is read once more and written once: 4N+3
         return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + (4 * N_ + 3 if fused else 6 * N_ + 5))
 
@@ -422,9 +422,9 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         s8.step(pmc_steps)
         ms2 = timed_steps(s8, pmc_steps, 0)        # the launch shape the counters were collected on (pmc_child)
         it2 = float(s8.newton_iterations().sum())
+        fused = s8.default_family() == 'lane+fused'          # (pnp_lane.hip: launch_lane_nb)
         s8.close()
         its = float(it8.sum())
-        fused = LB >= 24576 and LN >= 5          # (pnp_lane.hip: launch_lane_nb)
         alg = lane_bytes(LN, LX, fused)
         rec = {'workload': 'batch=%d, %d species size-modified, %d points, Stern wall, backward Euler: %s' % (LB, LN, LX, what),
                'timesteps_per_s': LB * steps / (ms8 * 1e-3), 'newton_iterations_per_s': its / (ms8 * 1e-3),
@@ -499,6 +499,22 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         out['config4_share'] = lane_record(8192, 8, 4096, 4448, 4, 'physical_lane_config4', "one GPU's share of configs[4] (65536 points over 8 GPUs)")
     except Exception as e:
         out['config4_share'] = {'error': str(e)}
+    try:      # the kernel-family thresholds checked against a measurement on THIS device (pnp_autotune: every family, 6 timed steps each)
+        sel = {}
+        for SB, SN, SX, seed in ((1024, 8, 512, 4445), (8192, 8, 512, 4444), (32768, 8, 512, 4446), BC_SHAPE + (4447,)):
+            sa, inpa = newton_solver(SB, SN, SX, seed, device, steric=True)
+            sa.set_batch(*inpa[1:])
+            del inpa
+            sa.step(1)
+            sa.synchronize()
+            lib_choice = sa.default_family()
+            fastest, fam_ms = sa.autotune(6)
+            sa.close()
+            sel['%dx%dx%d' % (SB, SN, SX)] = {'ms_per_timestep': fam_ms, 'fastest': fastest, 'library_choice': lib_choice,
+                                              'library_choice_over_fastest': fam_ms[lib_choice] / fam_ms[fastest]}
+        out['kernel_selection_measured'] = sel
+    except Exception as e:
+        out['kernel_selection_measured'] = {'error': str(e)}
     try:      # below the lane kernel's crossover: lane teams, two-sided sweep
         s8, inp = newton_solver(1024, 8, 512, 4445, device, steric=True)
         s8.set_batch(*inp[1:])
@@ -716,8 +732,8 @@ def main():
     if dist is not None and not args.no_extras:          # (world > 1, or CATINT_FORCE_DIST: the RCCL rehearsal of one rank)
         shares = {}
 
-        def lane_bytes_(N_, nx_, B_):      # (as lane_bytes of physical_mode: the lane kernel fuses the update from 24 576 points on)
-            return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + (4 * N_ + 3 if (B_ >= 24576 and N_ >= 5) else 6 * N_ + 5))
+        def lane_bytes_(N_, nx_, fused):      # (as lane_bytes of physical_mode: the lane kernel fuses the update into the back-substitution)
+            return 8.0 * nx_ * (2 * (N_ + 1) * (N_ + 2) + (4 * N_ + 3 if fused else 6 * N_ + 5))
 
         def compat_share(shape, seed, nsteps):
             SB, SN, SX = shape
@@ -746,6 +762,7 @@ def main():
             s_.synchronize()
             warm_clocks()
             t = timed_call(s_, lambda: s_.step(nsteps), lambda: [float(s_.newton_iterations().sum()), float((s_.get_status() == 0).sum())])
+            fused = s_.default_family() == 'lane+fused'
             s_.close()
             its = t['table'][:, 3]
             return {'workload': 'per GPU: batch=%d, %d species size-modified, %d points, Stern wall, backward Euler, coupled Newton'
@@ -753,7 +770,7 @@ def main():
                     'value': world * SB * nsteps / t['wall'], 'unit': 'timesteps/s', 'steps': nsteps,
                     'newton_iterations_per_s': float(its.sum()) / t['wall'],
                     'per_rank_timesteps_per_s': [SB * nsteps / w for w in t['per_rank_wall']], 'start_skew_us': t['start_skew_us'],
-                    'hbm_frac_algorithmic_slowest_rank': lane_bytes_(SN, SX, SB) * float(its.max()) / (t['ev_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'hbm_frac_algorithmic_slowest_rank': lane_bytes_(SN, SX, fused) * float(its.max()) / (t['ev_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     'lanes_ok': int(t['table'][:, 4].sum()), 'lanes_total': world * SB}
 
         div = max(1, int(os.environ.get('CATINT_BENCH_SHARE_DIV', '1')))      # tests: the same records on 1/div of the batch

@@ -33,7 +33,7 @@ SYMBOLS = [
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_integrate_dopri5', 'pnp_integrate_dop853', 'pnp_integrate_rkc', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_step_row_chunks', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
-    'pnp_set_potential', 'pnp_set_convection', 'pnp_set_option', 'pnp_get_lane_order', 'pnp_set_lanes', 'pnp_set_lane_mask', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
+    'pnp_set_potential', 'pnp_set_convection', 'pnp_set_option', 'pnp_get_lane_order', 'pnp_autotune', 'pnp_autotune_name', 'pnp_autotune_default', 'pnp_set_lanes', 'pnp_set_lane_mask', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
 ]
 
 
@@ -154,6 +154,12 @@ def load_library():
     lib.pnp_set_option.restype = C.c_int
     lib.pnp_get_lane_order.argtypes = [vp, ip]
     lib.pnp_get_lane_order.restype = C.c_int64
+    lib.pnp_autotune.argtypes = [vp, C.c_int32, dp, ip]
+    lib.pnp_autotune.restype = C.c_int
+    lib.pnp_autotune_name.argtypes = [C.c_int32]
+    lib.pnp_autotune_name.restype = C.c_char_p
+    lib.pnp_autotune_default.argtypes = [vp]
+    lib.pnp_autotune_default.restype = C.c_int32
     lib.pnp_solve_surface.argtypes = [vp, dp, C.c_int32, dp, dp, dp, ip]
     lib.pnp_solve_surface.restype = C.c_int
     lib.pnp_scf_cycle.argtypes = [vp, C.POINTER(PnpScfParams), dp, dp, C.POINTER(PnpScfState), ip]
@@ -292,6 +298,21 @@ class PnpSolver(object):
         if n > 0:
             self._lib.pnp_get_lane_order(self._h, _iptr(perm))
         return perm
+
+    def default_family(self):
+        """Name of the kernel family the library's thresholds choose for the current batch (pnp_autotune_default); None without one."""
+        i = int(self._lib.pnp_autotune_default(self._h))
+        return None if i < 0 else self._lib.pnp_autotune_name(i).decode()
+
+    def autotune(self, nsteps=2):
+        """Physical mode: pick the kernel family by measurement on this device and batch (pnp_autotune).  Returns (name of the chosen
+        family, {family: ms per timestep} of every family that supports the shape); the state and its history are left as they were."""
+        n = 8
+        ms = np.zeros(n)
+        chosen = np.zeros(1, np.int32)
+        self._check(self._lib.pnp_autotune(self._h, int(nsteps), _dptr(ms), _iptr(chosen)))
+        names = [self._lib.pnp_autotune_name(i).decode() for i in range(n)]
+        return names[int(chosen[0])], {names[i]: float(ms[i]) for i in range(n) if ms[i] >= 0.0}
 
     def set_convection(self, velocity):
         """Constant convection velocity (m/s) of the physical mode: tp.system['flow rate'] (comsol_model.py:901-903)."""

@@ -127,6 +127,7 @@ static bool option_assign(Options& o, const char* key_in, const char* value) {
     else if (v[0] == 't') o.newton_kernel = NK_TEAM;
     else if (v[0] == 's') o.newton_kernel = NK_SWEEP;
     else if (v[0] == 'b') o.newton_kernel = NK_BOTH;
+    else if (v[0] == 'w') o.newton_kernel = NK_WORKGROUP;
     else return false;
   } else if (key == "NEWTON_EXCHANGE") o.newton_exchange_global = (value[0] == 'g' || value[0] == 'G') ? 1 : 0;
   else if (key == "NEWTON_TEAM_THREADS") o.newton_team_threads = iv;
@@ -137,6 +138,7 @@ static bool option_assign(Options& o, const char* key_in, const char* value) {
   else if (key == "LANE_PIVOT_LIMIT") o.lane_pivot_limit = atof(value);
   else if (key == "LANE_ORDER") o.lane_order = iv;
   else if (key == "LANE_STAGGER") o.lane_stagger = iv;
+  else if (key == "LANE_FUSED") o.lane_fused = value[0] ? (iv != 0 ? 1 : 0) : -1;
   else if (key == "PNP_KERNEL") o.pnp_kernel = iv;
   else if (key == "PNP_WAVES_PER_GRID") o.pnp_waves_per_grid = iv;
   else if (key == "PNP_SPECIES_PER_WAVE") o.pnp_species_per_wave = iv;
@@ -149,7 +151,7 @@ static bool option_assign(Options& o, const char* key_in, const char* value) {
 }
 
 static const char* const kOptionKeys[] = {"NEWTON_KERNEL", "NEWTON_EXCHANGE", "NEWTON_TEAM_THREADS", "NEWTON_REGS", "NEWTON_BLOCKS",
-                                          "NEWTON_LANE_GROUPS", "NEWTON_SWEEP_BLOCKS", "LANE_PIVOT_LIMIT", "LANE_ORDER", "LANE_STAGGER", "PNP_KERNEL",
+                                          "NEWTON_LANE_GROUPS", "NEWTON_SWEEP_BLOCKS", "LANE_PIVOT_LIMIT", "LANE_ORDER", "LANE_STAGGER", "LANE_FUSED", "PNP_KERNEL",
                                           "PNP_WAVES_PER_GRID", "PNP_SPECIES_PER_WAVE", "PNP_STEP_STREAMS", "PNP_ALTERNATE_ROWS",
                                           "PNP_ST_WAVES_PER_CU", "PNP_NO_POST_UPLOAD_DISPATCH"};
 
@@ -913,6 +915,7 @@ static int run_newton(pnp_handle* h, int nsteps, bool stationary, double tol, in
   a.wall_bc = h->np.wall_bc;
   a.mpb = h->mpb ? 1 : 0;
   a.estimate = h->np.error_estimate ? 1 : 0;
+  a.stationary = stationary ? 1 : 0;
   a.RS = (nx + 15) / 16 * 16;
   a.B = h->B;
   a.work = h->work;
@@ -1379,6 +1382,158 @@ int pnp_set_lane_mask(pnp_handle* h, const int32_t* mask) {
   HIP_TRY(h, hipMemcpyAsync(h->user_mask, mask, (size_t)h->B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->newton_mask = h->user_mask;
+  return PNP_OK;
+}
+
+// ---- pnp_autotune: the kernel family of the physical mode chosen by measurement on THIS device and THIS batch --------------------
+// (the selection functions carry thresholds measured on the devices of one pool, and devices differ by ~10 %: DESIGN.md section 6a)
+static const struct {
+  const char* name;
+  int kernel, fused;
+} kTuneChoices[PNP_AUTOTUNE_CHOICES] = {{"lane4", NK_LANE4, -1},         {"lane2", NK_LANE2, -1}, {"lane", NK_LANE, 0},    {"lane+fused", NK_LANE, 1},
+                                        {"workgroup", NK_WORKGROUP, -1}, {"team", NK_TEAM, -1},   {"sweep", NK_SWEEP, -1}, {"both", NK_BOTH, -1}};
+
+const char* pnp_autotune_name(int32_t i) { return (i >= 0 && i < PNP_AUTOTUNE_CHOICES) ? kTuneChoices[i].name : nullptr; }
+
+static void free_dev(pnp_handle* h, double** p, size_t bytes) {
+  if (*p) {
+    (void)hipFree(*p);
+    h->dev_bytes -= (int64_t)bytes;
+  }
+  *p = nullptr;
+}
+
+int32_t pnp_autotune_default(const pnp_handle* h) {
+  if (!h || !h->newton || !h->have_batch) return -1;
+  Options o = h->opt;
+  o.newton_kernel = NK_AUTO;
+  o.lane_fused = -1;
+  const int nb = h->a.N + 1, nx = h->a.nx, variant = newton_variant(h);
+  const int64_t n_eff = newton_effective_batch(h);
+  if (newton_lane4_preferred(nb, nx, n_eff, variant, o)) return 0;
+  if (newton_lane2_preferred(nb, nx, n_eff, variant, o)) return 1;
+  if (newton_lane_preferred(nb, nx, n_eff, variant, o)) return 3;      // (timesteps: fused at every batch, pnp_lane.hip: launch_lane_nb)
+  return 4;
+}
+
+int pnp_autotune(pnp_handle* h, int32_t nsteps, double* ms_per_step, int32_t* chosen) {
+  if (!h) return PNP_EINVAL;
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_autotune: the handle was not created with PNP_METHOD_NEWTON");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_autotune: call pnp_set_batch first");
+  if (nsteps < 1 || nsteps > 64) return fail(h, PNP_EINVAL, "pnp_autotune: nsteps must be 1 ... 64");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx, nb = N + 1;
+  const int64_t B = h->B;
+  const int variant = newton_variant(h);
+  const size_t nc = (size_t)B * N * ldx, nv = (size_t)B * ldx;
+  // the trial steps run on the handle's own state: it is put back after every trial, with everything a step moves along
+  double *save_c = nullptr, *save_v = nullptr, *save_c2 = nullptr, *save_p2 = nullptr;
+  int32_t *save_st = nullptr, *save_it = nullptr;
+  struct Cleanup {
+    pnp_handle* h;
+    double **a, **b, **c, **d;
+    int32_t **e, **f;
+    ~Cleanup() {
+      for (double** p : {a, b, c, d})
+        if (*p) (void)hipFree(*p);
+      for (int32_t** p : {e, f})
+        if (*p) (void)hipFree(*p);
+    }
+  } cleanup{h, &save_c, &save_v, &save_c2, &save_p2, &save_st, &save_it};
+  HIP_TRY(h, hipMalloc((void**)&save_c, nc * sizeof(double)));
+  HIP_TRY(h, hipMalloc((void**)&save_v, nv * sizeof(double)));
+  HIP_TRY(h, hipMalloc((void**)&save_st, (size_t)B * sizeof(int32_t)));
+  HIP_TRY(h, hipMalloc((void**)&save_it, (size_t)B * sizeof(int32_t)));
+  if (h->c_old2) HIP_TRY(h, hipMalloc((void**)&save_c2, nc * sizeof(double)));
+  if (h->phi_old2) HIP_TRY(h, hipMalloc((void**)&save_p2, nv * sizeof(double)));
+  auto copy = [&](bool back) -> hipError_t {
+    struct {
+      void *live, *kept;
+      size_t bytes;
+    } items[6] = {{h->c, save_c, nc * sizeof(double)},        {h->v, save_v, nv * sizeof(double)},
+                  {h->c_old2, save_c2, nc * sizeof(double)},  {h->phi_old2, save_p2, nv * sizeof(double)},
+                  {h->status, save_st, (size_t)B * sizeof(int32_t)}, {h->iters, save_it, (size_t)B * sizeof(int32_t)}};
+    for (auto& it : items) {
+      if (!it.live || !it.kept) continue;
+      const hipError_t e = hipMemcpyAsync(back ? it.live : it.kept, back ? it.kept : it.live, it.bytes, hipMemcpyDeviceToDevice, h->stream);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  };
+  HIP_TRY(h, copy(false));
+  const Options opt0 = h->opt;
+  const int64_t steps0 = h->steps_done;
+  const bool hist0 = h->bdf_history, iters0 = h->iters_valid;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(h, hipEventCreate(&e0));
+  HIP_TRY(h, hipEventCreate(&e1));
+  double best = -1.0;
+  int best_i = -1, rc = PNP_OK;
+  int64_t best_ok = -1;
+  std::vector<int32_t> st((size_t)B);
+  for (int i = 0; i < PNP_AUTOTUNE_CHOICES && rc == PNP_OK; ++i) {
+    if (ms_per_step) ms_per_step[i] = -1.0;
+    const int k = kTuneChoices[i].kernel;
+    const bool applicable = k == NK_LANE4   ? newton_lane4_supported(nb, nx, variant)
+                            : k == NK_LANE2 ? newton_lane2_supported(nb, nx, variant)
+                            : k == NK_LANE  ? newton_lane_supported(nb, nx, variant)
+                            : k == NK_TEAM  ? (nb >= 3 && h->work != nullptr)
+                            : k == NK_SWEEP ? nb >= 3
+                            : k == NK_BOTH  ? (nb >= 6 && nx >= 8)
+                                            : true;
+    if (!applicable) continue;
+    h->opt = opt0;
+    h->opt.newton_kernel = k;
+    h->opt.lane_fused = kTuneChoices[i].fused;
+    float ms = 0.0f;
+    for (int pass = 0; pass < 2 && rc == PNP_OK; ++pass) {      // the first pass allocates the family's workspace and warms the caches
+      h->steps_done = steps0;
+      h->bdf_history = hist0;
+      h->iters_valid = iters0;
+      if (copy(true) != hipSuccess) rc = fail(h, PNP_EDEVICE, "pnp_autotune: restoring the state failed");
+      if (rc == PNP_OK && hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(h, PNP_EDEVICE, "pnp_autotune: hipEventRecord");
+      if (rc == PNP_OK) rc = newton_timesteps(h, pass == 0 ? 1 : nsteps);
+      if (rc == PNP_OK && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                           hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
+        rc = fail(h, PNP_EDEVICE, "pnp_autotune: timing a trial failed");
+    }
+    if (rc != PNP_OK) break;
+    if (hipMemcpy(st.data(), h->status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(h, PNP_EDEVICE, "pnp_autotune: reading the status failed");
+      break;
+    }
+    int64_t ok = 0;
+    for (int64_t b = 0; b < B; ++b) ok += st[(size_t)b] == PNP_STATUS_OK ? 1 : 0;
+    const double per_step = (double)ms / nsteps;
+    if (ms_per_step) ms_per_step[i] = per_step;
+    // the fastest family among those that solved the most operating points
+    if (ok > best_ok || (ok == best_ok && per_step < best)) {
+      best = per_step;
+      best_i = i;
+      best_ok = ok;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  h->opt = opt0;
+  h->steps_done = steps0;
+  h->bdf_history = hist0;
+  h->iters_valid = iters0;
+  if (copy(true) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, PNP_EDEVICE, "pnp_autotune: restoring the state failed");
+  if (rc != PNP_OK) return rc;
+  if (best_i < 0) return fail(h, PNP_ESTATE, "pnp_autotune: no kernel family applies");
+  h->opt.newton_kernel = kTuneChoices[best_i].kernel;
+  h->opt.lane_fused = kTuneChoices[best_i].fused;
+  // the workspaces of the families that lost go back to the device
+  const int nk = h->opt.newton_kernel;
+  if (nk != NK_LANE) free_dev(h, &h->lane_buf, (size_t)h->lane_groups * (newton_lane_rec_doubles(nb, nx) + newton_lane_state_doubles(nb, nx)) * sizeof(double));
+  if (nk != NK_LANE2)
+    free_dev(h, &h->lane2_buf, (size_t)h->lane2_groups * (newton_lane2_rec_doubles(nb, nx) + newton_lane2_state_doubles(nb, nx)) * sizeof(double));
+  if (nk != NK_LANE4)
+    free_dev(h, &h->lane4_buf, (size_t)h->lane4_groups * (newton_lane4_rec_doubles(nb, nx) + newton_lane4_state_doubles(nb, nx)) * sizeof(double));
+  if (nk == NK_LANE || nk == NK_LANE2 || nk == NK_LANE4 || nk == NK_TEAM)
+    free_dev(h, &h->sweep, (size_t)h->sweep_blocks * newton_sweep_doubles(nb, nx) * (size_t)(64 / nb) * sizeof(double));
+  if (chosen) *chosen = best_i;
   return PNP_OK;
 }
 

@@ -9,9 +9,11 @@ namespace pnp {
 
 // Debug / tuning options of a handle (C-ABI: pnp_set_option).  The CATINT_* environment variables of the same names are read ONCE,
 // in pnp_create, as the defaults of a new handle; nothing in the library reads the environment afterwards.
-enum NewtonKernelChoice { NK_AUTO = 0, NK_GENERIC, NK_TEAM, NK_SWEEP, NK_BOTH, NK_LANE, NK_LANE2, NK_LANE4 };
+// (NK_WORKGROUP: the library's own choice among the workgroup-per-point / team / sweep kernels, lane kernels excluded)
+enum NewtonKernelChoice { NK_AUTO = 0, NK_GENERIC, NK_TEAM, NK_SWEEP, NK_BOTH, NK_LANE, NK_LANE2, NK_LANE4, NK_WORKGROUP };
 struct Options {
-  int newton_kernel = NK_AUTO;       // NEWTON_KERNEL = generic | team | sweep | both | lane | lane2 (tests force a kernel family)
+  int newton_kernel = NK_AUTO;       // NEWTON_KERNEL = generic | team | sweep | both | lane | lane2 | lane4 | workgroup (tests, pnp_autotune)
+  int lane_fused = -1;               // LANE_FUSED = 0 | 1: the lane kernel with the update inside the back-substitution; -1: by the batch
   int newton_exchange_global = 0;    // NEWTON_EXCHANGE = global: the row-per-thread kernel's buffers in device memory (creation time)
   int newton_team_threads = 0;       // NEWTON_TEAM_THREADS = 256 | 512 | 1024
   int newton_regs = 0;               // NEWTON_REGS = 512: the 512-register build of the row-per-thread kernel (N = 5, 6)
@@ -156,7 +158,7 @@ hipError_t launch_surface(const DevArgs& a, double* csurf, hipStream_t stream);
 struct NewtonArgs {
   int32_t N, nx, ldx, nsteps;
   int32_t maxit, wall_bc, mpb, RS;       // RS: row stride of the element-major PCR buffers
-  int32_t estimate, pad_;                // accept on the quadratic error estimate (pnp_newton_params.error_estimate)
+  int32_t estimate, stationary;          // accept on the quadratic error estimate (pnp_newton_params.error_estimate); 1/dt = 0 (one solve)
   int64_t B;
   int64_t work_stride;                   // doubles per workgroup in `work`
   double tol, dphi_max;

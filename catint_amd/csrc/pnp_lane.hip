@@ -1095,7 +1095,11 @@ bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode, const Options& 
   // Round 4: below 10 240 points the lane-quad kernel (pnp_lane4.hip) is ahead of both; the pair keeps the window up to the lane
   // kernel's crossover (profiles/r04_lane4_probe.jsonl: B = 12 288 lane pair 9.96e5 / lane 9.55e5 / lane quad 7.78e5; 16 384 1.05e6 /
   // 1.10e6 / 0.87e6).
-  return B >= 1280 && B < 14336;
+  // End of the window, measured again with the fused lane kernel as the alternative (profiles/r04_family_rates.jsonl; lane pair /
+  // lane fused): N = 8, nx = 512: B = 14 336 1.17e6 / 1.05e6, 16 384 (1024 waves of 16 points: the last batch in one round) 1.25e6 /
+  // 1.19e6, 18 432 0.97e6 / 1.20e6; N = 8, nx = 1024: 16 384 5.6e5 / 5.4e5; N = 6, nx = 1024: 12 288 7.6e5 / 7.4e5, 14 336 7.8e5 / 8.1e5;
+  // N = 6, nx = 512: 12 288 1.62e6 / 1.58e6, 16 384 1.90e6 / 2.04e6.
+  return B >= 1280 && B <= (nb >= 9 ? 16384 : (nb == 8 ? 14335 : 13311));
 }
 
 template <int NB>
@@ -1110,11 +1114,14 @@ static hipError_t launch_lane_nb(const NewtonArgs& a0, hipStream_t stream) {
     const int64_t ng = groups - g0 < cap ? groups - g0 : cap;
     const dim3 tg((unsigned)ng, (unsigned)((a.nx + 63) / 64));
     hipLaunchKernelGGL((lane_transpose_kernel<true>), tg, dim3(256), 0, stream, a);
-    // FUSED (update inside the back-substitution, two state copies, no round trip of the Newton update: -8 % of the bytes) where the
-    // kernel is HBM-bound, i.e. from about three waves per CU on; below that the separate passes are faster (shorter dependent chains).
-    // One device, one call, libraries alternated (tools/probe/lane_rate.py; N = 8 steric, nx = 512, timesteps/s separate / fused):
-    // B = 32 768 1.645e6 / 1.727e6, 16 384 1.265e6 / 1.177e6, 8192 7.67e5 / 6.98e5; N = 6, nx = 1024, B = 32 768 1.031e6 / 1.130e6.
-    const bool fused = a.B >= 24576;
+    // FUSED: update inside the back-substitution, two state copies, no round trip of the Newton update (-8 % of the bytes; a damped
+    // iteration walks the back-substitution twice).  Timesteps: at every batch since the records move with non-temporal accesses
+    // (tools/probe/family_rates.py -> profiles/r04_family_rates.jsonl, one device, one call, 20-step launches, timesteps/s separate /
+    // fused: N = 8, nx = 512: B = 8192 6.24e5 / 6.95e5, 16 384 1.05e6 / 1.19e6, 24 576 1.32e6 / 1.53e6; N = 6, nx = 1024: 16 384
+    // 9.14e5 / 9.15e5, 24 576 1.06e6 / 1.16e6; N = 4, nx = 1024, B = 16 384 1.44e6 / 1.72e6; N = 2, nx = 4096, B = 8192 3.4e5 / 4.2e5;
+    // the round-3 measurement with cached record accesses had the separate passes ahead below 24 576 points).  Stationary solves
+    // (damped iterations at their start) keep the round-3 rule.
+    const bool fused = (a.opt && a.opt->lane_fused >= 0) ? a.opt->lane_fused != 0 : (a.stationary ? a.B >= 24576 : true);
     const int mode = (a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0);
     const dim3 gk((unsigned)ng), bk(64);
     if (fused) {

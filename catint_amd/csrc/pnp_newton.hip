@@ -2306,7 +2306,7 @@ static hipError_t launch_sweep2(const NewtonArgs& a, hipStream_t stream) {
 // Two teams per operating point instead of one: when the one-sided sweep would leave the SIMDs with fewer than ~3 waves.
 bool newton_sweep_two_sided(int nb, int nx, int64_t B, int mode, const Options& opt) {
   if (nb < 6 || nx < 8) return false;
-  if (opt.newton_kernel != NK_AUTO) return opt.newton_kernel == NK_BOTH;      // "both ends" (tests, probes)
+  if (opt.newton_kernel != NK_AUTO && opt.newton_kernel != NK_WORKGROUP) return opt.newton_kernel == NK_BOTH;      // "both ends" (tests, probes)
   // with homogeneous reactions (the 4096-lane CO2R sweep: stationary solves along a continuation, 3...30 iterations per lane) the
   // lane-team kernel stays ahead: 0.48 s against 0.52 s (one-sided sweep 0.83 s)
   if (mode >= 2) return false;
@@ -2321,7 +2321,8 @@ bool newton_sweep_two_sided(int nb, int nx, int64_t B, int mode, const Options& 
 
 // Large blocks and a batch that fills the chip with teams on its own (measured): the sweep kernel.
 bool newton_sweep_preferred(int nb, int nx, int64_t B, int mode, const Options& opt) {
-  if (opt.newton_kernel != NK_AUTO) return (opt.newton_kernel == NK_SWEEP && nb >= 3) || (opt.newton_kernel == NK_BOTH && nb >= 6 && nx >= 8);
+  if (opt.newton_kernel != NK_AUTO && opt.newton_kernel != NK_WORKGROUP)
+    return (opt.newton_kernel == NK_SWEEP && nb >= 3) || (opt.newton_kernel == NK_BOTH && nb >= 6 && nx >= 8);
   if (newton_sweep_two_sided(nb, nx, B, mode, opt)) return true;
   // at least one wave of teams per SIMD (1024 SIMDs): below that the chip is not full and, with uniform control flow, a wave
   // waits for its slowest lane -- the CO2R example (7 species, 4096 lanes, iteration counts 3...30) took 0.84 s instead of 0.51 s

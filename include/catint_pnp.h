@@ -93,8 +93,8 @@ const char* pnp_last_error(const pnp_handle* h); /* h may be NULL: last create()
 const char* pnp_version(void);
 
 /* Debug / tuning switch of one handle: which kernel family runs, workspace sizes, probes.  key = the name of the environment variable
- * without its CATINT_ prefix (NEWTON_KERNEL = auto | generic | team | sweep | both | lane | lane2 | lane4, NEWTON_TEAM_THREADS,
- * NEWTON_REGS, NEWTON_BLOCKS, NEWTON_LANE_GROUPS, NEWTON_SWEEP_BLOCKS, LANE_PIVOT_LIMIT, LANE_ORDER, PNP_KERNEL, PNP_WAVES_PER_GRID,
+ * without its CATINT_ prefix (NEWTON_KERNEL = auto | generic | team | sweep | both | lane | lane2 | lane4 | workgroup, LANE_FUSED,
+ * NEWTON_TEAM_THREADS, NEWTON_REGS, NEWTON_BLOCKS, NEWTON_LANE_GROUPS, NEWTON_SWEEP_BLOCKS, LANE_PIVOT_LIMIT, LANE_ORDER, PNP_KERNEL, PNP_WAVES_PER_GRID,
  * PNP_SPECIES_PER_WAVE, PNP_STEP_STREAMS, PNP_ALTERNATE_ROWS, PNP_ST_WAVES_PER_CU, PNP_NO_POST_UPLOAD_DISPATCH).  The environment is
  * read once, in pnp_create, as the defaults of the new handle; the library never reads it afterwards, so handles in one process
  * are configured independently.  PNP_EINVAL for an unknown key, PNP_ESTATE for an option that sizes a buffer already allocated.
@@ -318,6 +318,21 @@ int pnp_set_lane_mask(pnp_handle* h, const int32_t* mask /* [B] or NULL */);
  * number of slots filled (0: the last solve did not use an order -- another kernel family, fewer than 64 points, LANE_ORDER = 0);
  * perm[that many] (nullable). */
 int64_t pnp_get_lane_order(pnp_handle* h, int32_t* perm);
+
+/* Physical mode: choose the kernel family by MEASUREMENT on this device and this batch instead of by the library's thresholds (which
+ * were measured on the devices of one pool; devices differ by ~10 %).  Every family that supports the shape -- pnp_autotune_name(i),
+ * i < PNP_AUTOTUNE_CHOICES: lane4, lane2, lane, lane+fused, workgroup (the library's choice among the workgroup-per-point / team /
+ * sweep kernels), team, sweep, both -- takes one warm-up timestep and then `nsteps` timed ones from the handle's current state; the
+ * state, the BDF2 history, status and iteration counts are put back after every trial, so the call leaves the trajectory untouched.
+ * The fastest family among those that solved the most operating points becomes the handle's NEWTON_KERNEL / LANE_FUSED option (as
+ * pnp_set_option would set it: it stays until changed); the workspaces of the others are freed.  ms_per_step[PNP_AUTOTUNE_CHOICES]
+ * (nullable) receives the measured time per timestep of every family, -1 where it does not apply; *chosen (nullable) the index.
+ * Families agree to the Newton tolerance, not to the bit: tune once, before the steps whose results are compared.
+ * Replaces nothing in the reference (COMSOL picks its own linear solver, comsol_model.py:465-516). */
+#define PNP_AUTOTUNE_CHOICES 8
+const char* pnp_autotune_name(int32_t i);
+int32_t pnp_autotune_default(const pnp_handle* h);      /* index of the family the library's thresholds choose for the current batch; -1: no batch */
+int pnp_autotune(pnp_handle* h, int32_t nsteps, double* ms_per_step, int32_t* chosen);
 
 /* ---- read-back ------------------------------------------------------------------------------ */
 /* Any pointer may be NULL. c[B][N][nx]; v, grad_v, lapl_v [B][nx] are the Poisson solve of the

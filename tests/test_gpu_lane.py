@@ -321,6 +321,40 @@ def test_first_solve_after_an_upload_is_ordered_by_the_potential_difference_and_
         assert np.array_equal(s.lane_order(), by_potential)
 
 
+@pytest.mark.parametrize("N,nx,B,kw", [
+    (2, 64, 70, {}), (3, 97, 37, {}), (4, 80, 40, {}),
+    (6, 96, 70, {'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 6}),
+    (8, 65, 37, {'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 8}),
+    (8, 64, 35, {'time_order': 2, 'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 8}),
+])
+def test_update_fused_into_the_back_substitution_and_separate_passes_are_the_same_iteration(N, nx, B, kw):
+    """The lane kernel's two forms (option LANE_FUSED; timesteps run the fused one at every batch since round 4, stationary solves from
+    24 576 points on): the update applied inside the back-substitution with two state copies, or written out and applied by a third
+    pass.  Same arithmetic in the same order -- timesteps (first steps from the bulk state: damped iterations walk the back-substitution
+    twice) and a stationary solve give the same bits, iteration counts and status either way; and both match the oracle."""
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 23, phi_lo=-0.25, phi_hi=0.25)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    dt = 0.3 * (6 * dx) * (nx * dx) / D.max()
+    outs = []
+    for fused in ('0', '1'):
+        with _capi.PnpSolver(N, nx, dx, dt, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+            s.set_option('LANE_FUSED', fused)
+            s.set_newton(**kw)
+            s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+            s.step(3)
+            a = (s.get_state()[0], s.get_state()[1], s.newton_iterations(), s.get_status())
+            st = s.solve_stationary()
+            outs.append(a + (s.get_state()[0], s.get_state()[1], s.newton_iterations(), st))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert (outs[0][3] == 0).all() and (outs[0][7] == 0).all()
+    got, ref = run_both(N, nx, B=B, seed=23, dt=dt, nsteps=3, stationary=False, newton_kw=kw, phi_lo=-0.25, phi_hi=0.25)
+    assert_close(got, ref)
+    assert np.array_equal(got[0], outs[0][0])
+
+
 @pytest.mark.parametrize("kernel,N,nx", [('lane', 3, 96), ('lane', 8, 64), ('lane2', 6, 80), ('lane2', 8, 48), ('lane4', 5, 80), ('lane4', 8, 48)])
 def test_error_estimate_stopping_rule(kernel, N, nx, monkeypatch):
     """pnp_newton_params.error_estimate: accept an iterate whose quadratic error estimate upd^2 / upd_prev is below the tolerance (saves

@@ -225,6 +225,55 @@ def test_kernel_choice_for_large_batches_of_large_blocks(monkeypatch):
     assert np.array_equal(e[0], f[0]) and np.array_equal(e[2], f[2])
 
 
+@pytest.mark.parametrize("time_order", [1, 2])
+def test_autotune_measures_every_family_and_leaves_the_trajectory_untouched(time_order, monkeypatch):
+    """pnp_autotune: every kernel family that supports the shape is timed on the handle's own batch (one warm-up step + nsteps from the
+    current state), the fastest becomes the handle's option, and state, BDF2 history, status and iteration counts are put back after
+    every trial -- steps taken after the call continue the trajectory exactly as if the chosen family had been forced from the start."""
+    monkeypatch.delenv('CATINT_NEWTON_KERNEL', raising=False)
+    N, nx, B = 6, 96, 1536
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 11)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    kw = dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * N, time_order=time_order, tol=1e-10)
+
+    def solver(option=None):
+        s = _capi.PnpSolver(N, nx, dx, dt, BETA, EPS, D, q, method='Newton', batch_capacity=B)
+        s.set_newton(**kw)
+        for k, v in (option or {}).items():
+            s.set_option(k, v)
+        s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+        return s
+    with solver() as s:
+        s.step(2)
+        before = (s.get_state()[0].copy(), s.get_state()[1].copy(), s.newton_iterations().copy(), s.get_status().copy())
+        name, ms = s.autotune(2)
+        after = (s.get_state()[0], s.get_state()[1], s.newton_iterations(), s.get_status())
+        for a, b in zip(before, after):
+            assert np.array_equal(a, b)
+        assert set(ms) == {'lane4', 'lane2', 'lane', 'lane+fused', 'workgroup', 'team', 'sweep', 'both'} and name in ms
+        assert all(v > 0 for v in ms.values()) and ms[name] == min(ms.values())
+        held = s.device_bytes
+        s.step(3)
+        tuned = (s.get_state()[0], s.get_state()[1], s.newton_iterations())
+        assert (s.get_status() == 0).all()
+    forced = {'lane+fused': {'NEWTON_KERNEL': 'lane', 'LANE_FUSED': '1'}, 'lane': {'NEWTON_KERNEL': 'lane', 'LANE_FUSED': '0'}}.get(name, {'NEWTON_KERNEL': name})
+    with solver() as s:                       # the same trajectory with the family forced for its second part
+        s.step(2)
+        for k, v in forced.items():
+            s.set_option(k, v)
+        s.step(3)
+        ref = (s.get_state()[0], s.get_state()[1], s.newton_iterations())
+        assert held <= s.device_bytes + 16 * B        # the losers' workspaces went back to the device (a per-lane counter array may stay)
+    for a, b in zip(tuned, ref):
+        assert np.array_equal(a, b)
+    with _capi.PnpSolver(3, 64, 1e-10, 1e-9, BETA, EPS, D[:3], q[:3], batch_capacity=4) as s:       # compat handle: refused
+        with pytest.raises(_capi.PnpError):
+            s.autotune()
+
+
 @pytest.mark.parametrize("N,nx", [(3, 513), (2, 1030), (3, 1200)])
 def test_more_rows_than_threads(N, nx):
     got, ref = run_both(N, nx, B=3, seed=nx, points_per_debye=20.0)
