@@ -312,9 +312,10 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       for (int r = 0; r < NB; ++r) Tset(j, r, 0.0);
     }
     // inputs of the next row, requested one row ahead: the point ahead, the previous time level, the grid weights
-    d2 p_a[VP], p_co[CP], p_cn[CP];
-#pragma unroll
-    for (int p = 0; p < CP; ++p) p_cn[p] = (d2)(0.0);
+    d2 p_a[VP], p_co[CP];
+    // (first iteration of a BDF2 step with a history: the previous-level slot of the prefetch carries the level BEFORE the previous one
+    //  -- the previous level of such an iteration is formed from the state itself and not read; one pointer chosen per iteration)
+    const d2* tprev = (first && hist) ? tcn : tco;
     double p_vi, p_wea, p_web;
     auto request = [&](int s) {
       const int i = fwd_row(s);
@@ -322,11 +323,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
 #pragma unroll
       for (int p = 0; p < VP; ++p) p_a[p] = TS(ia, p);
 #pragma unroll
-      for (int p = 0; p < CP; ++p) p_co[p] = CO(i, p);
-      if (first && hist) {      // (first iteration of a BDF2 step: the level before the previous one, read once per step)
-#pragma unroll
-        for (int p = 0; p < CP; ++p) p_cn[p] = CN(i, p);
-      }
+      for (int p = 0; p < CP; ++p) p_co[p] = tprev[((size_t)i * CP + p) * LG];
       p_vi = G.gv[i];
       p_wea = G.gw[side ? i - 1 : i];
       p_web = G.gw[side ? i : (i > 0 ? i - 1 : 0)];
@@ -413,12 +410,11 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
       const bool last = s == S - 1;     // the middle row: upward half only
       const bool act = last ? !side : (side ? s < n_dn : s < m);
       // this row's inputs have arrived during the previous row; the next row's are requested before this row's stores are issued
-      double ac[N], aphi, co[N], cnv[N];
+      double ac[N], aphi, co[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         ac[k] = p_a[k >> 1][k & 1];
         co[k] = p_co[k >> 1][k & 1];
-        cnv[k] = p_cn[k >> 1][k & 1];
       }
       aphi = p_a[N >> 1][N & 1];
       const double vi = p_vi, wea = p_wea, web_ = p_web;
@@ -469,7 +465,11 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         double rho = 0.0;
         double cs_[N];      // the previous-level value of this step: the state itself (backward Euler) or the BDF2 combination
 #pragma unroll
-        for (int k = 0; k < N; ++k) cs_[k] = (first && hist) ? (4.0 * hc[k] - cnv[k]) / 3.0 : hc[k];
+        for (int k = 0; k < N; ++k) cs_[k] = hc[k];
+        if (first && hist) {      // (under its own branch: eight divisions that only the first iteration of a BDF2 step needs)
+#pragma unroll
+          for (int k = 0; k < N; ++k) cs_[k] = (4.0 * hc[k] - co[k]) / 3.0;
+        }
         if (first) {
 #pragma unroll
           for (int p = 0; p < CP; ++p) {

@@ -54,7 +54,9 @@ __device__ __forceinline__ double dpp_from_quad_lane(double v) {
 size_t newton_lane2_rec_doubles(int nb, int nx) { return (size_t)nx * 2 * (size_t)((((nb + 2) / 2) * nb + 1) / 2 * 2) * OG; }
 size_t newton_lane2_state_doubles(int nb, int nx) { return (size_t)nx * (size_t)(2 * ((nb + 1) / 2 * 2) + 2 * (nb / 2 * 2)) * OG; }
 
-template <int NB, int MODE>
+// (BDF: the BDF2 history inside the launch -- a template flag here: as a run-time flag it cost the backward-Euler instances 3-8 % in
+// registers moved around, tools/probe/ab_old_new.sh)
+template <int NB, int MODE, bool BDF>
 __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
   constexpr int N = NB - 1;
   constexpr int CL = (NB + 2) / 2;           // local columns of [Ah | r] (NB + 1 columns: unknown j < NB, right-hand side j = NB)
@@ -126,8 +128,8 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
     // BDF2 inside a launch of several timesteps (G.bdf2, lane kernels): a step has a history -- the time level before the previous one,
     // kept in CN -- if the launch started with one or it is not the operating point's first step; then the previous-level value is the
     // combination (4 c_n - c_n-1) / 3 and 1/dt carries 3/2 (pnp_capi.hip: newton_timesteps; comsol_model.py:518-531, maxorder 2)
-    const bool hist = G.bdf2 && have && (G.bdf_hist0 || step > 0);
-    const double sgs = hist ? 1.5 : 1.0;
+    const bool hist = BDF && have && (G.bdf_hist0 || step > 0);
+    const double sgs = (BDF && hist) ? 1.5 : 1.0;
     if (fresh) {
       it = 0;
       upd_prev = INFINITY;
@@ -146,9 +148,10 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
     for (int jj = 0; jj < CL; ++jj)
 #pragma unroll
       for (int r = 0; r < NB; ++r) Tl[jj][r] = 0.0;
-    d2 p_a[VP], p_co[CP], p_cn[CP];
-#pragma unroll
-    for (int p = 0; p < CP; ++p) p_cn[p] = (d2)(0.0);
+    d2 p_a[VP], p_co[CP];
+    // (first iteration of a BDF2 step with a history: the previous-level slot of the prefetch carries the level BEFORE the previous one
+    //  -- the previous level of such an iteration is formed from the state itself and not read; one pointer chosen per iteration)
+    const d2* tprev = (BDF && first && hist) ? tcn : tco;
     double p_vi, p_wea, p_web;
     auto request = [&](int s) {
       const int i = fwd_row(s);
@@ -156,11 +159,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
 #pragma unroll
       for (int p = 0; p < VP; ++p) p_a[p] = TS(ia, p);
 #pragma unroll
-      for (int p = 0; p < CP; ++p) p_co[p] = CO(i, p);
-      if (first && hist) {      // (first iteration of a BDF2 step: the level before the previous one, read once per step)
-#pragma unroll
-        for (int p = 0; p < CP; ++p) p_cn[p] = CN(i, p);
-      }
+      for (int p = 0; p < CP; ++p) p_co[p] = tprev[((size_t)i * CP + p) * OG];
       p_vi = G.gv[i];
       p_wea = G.gw[side ? i - 1 : i];
       p_web = G.gw[side ? i : (i > 0 ? i - 1 : 0)];
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
               v[0] = bc[2 * p];
               v[1] = 2 * p + 1 < N ? bc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
               CO(nx - 1, p) = v;
-              if (G.bdf2 && have) CN(nx - 1, p) = v;
+              if (BDF && have) CN(nx - 1, p) = v;
             }
           }
         }
@@ -247,12 +246,11 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
     for (int s = 0; s < S; ++s) {
       const bool last = s == S - 1;
       const bool act = last ? !side : (side ? s < n_dn : s < m);
-      double ac[N], aphi, co[N], cnv[N];
+      double ac[N], aphi, co[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         ac[k] = p_a[k >> 1][k & 1];
         co[k] = p_co[k >> 1][k & 1];
-        cnv[k] = p_cn[k >> 1][k & 1];
       }
       aphi = p_a[N >> 1][N & 1];
       const double vi = p_vi, wea = p_wea, web = p_web;
@@ -307,7 +305,11 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
         double rho = 0.0;
         double cs_[N];      // the previous-level value of this step: the state itself (backward Euler) or the BDF2 combination
 #pragma unroll
-        for (int k = 0; k < N; ++k) cs_[k] = (first && hist) ? (4.0 * hc[k] - cnv[k]) / 3.0 : hc[k];
+        for (int k = 0; k < N; ++k) cs_[k] = hc[k];
+        if (BDF && first && hist) {      // (under its own branch: eight divisions that only the first iteration of a BDF2 step needs)
+#pragma unroll
+          for (int k = 0; k < N; ++k) cs_[k] = (4.0 * hc[k] - co[k]) / 3.0;
+        }
         if (first && !h) {
 #pragma unroll
           for (int p = 0; p < CP; ++p) {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
             v[0] = cs_[2 * p];
             v[1] = 2 * p + 1 < N ? cs_[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
             CO(i, p) = v;
-            if (G.bdf2 && have) {      // (a finished point runs along with its wave: its history stays)
+            if (BDF && have) {      // (a finished point runs along with its wave: its history stays)
               d2 w_;
               w_[0] = hc[2 * p];
               w_[1] = 2 * p + 1 < N ? hc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
@@ -769,6 +771,12 @@ __global__ __launch_bounds__(64) void newton_lane2_kernel(const NewtonArgs G) {
   }
 }
 
+#define LAUNCH_BDF(MODE_)                                                                                              \
+  do {                                                                                                                 \
+    if (a.bdf2) hipLaunchKernelGGL((newton_lane2_kernel<NB, MODE_, true>), dim3((unsigned)ng), dim3(64), 0, stream, a);  \
+    else hipLaunchKernelGGL((newton_lane2_kernel<NB, MODE_, false>), dim3((unsigned)ng), dim3(64), 0, stream, a);       \
+  } while (0)
+
 template <int NB>
 static hipError_t launch_lane2_nb(const NewtonArgs& a0, hipStream_t stream) {
   const int64_t groups = (a0.B + OG - 1) / OG;
@@ -781,9 +789,9 @@ static hipError_t launch_lane2_nb(const NewtonArgs& a0, hipStream_t stream) {
     const int64_t ng = groups - g0 < cap ? groups - g0 : cap;
     hipError_t e = launch_lane_transpose(a, ng, true, stream);
     if (e != hipSuccess) return e;
-    if (a.rt || a.convect) hipLaunchKernelGGL((newton_lane2_kernel<NB, 2>), dim3((unsigned)ng), dim3(64), 0, stream, a);
-    else if (a.mpb) hipLaunchKernelGGL((newton_lane2_kernel<NB, 1>), dim3((unsigned)ng), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((newton_lane2_kernel<NB, 0>), dim3((unsigned)ng), dim3(64), 0, stream, a);
+    if (a.rt || a.convect) LAUNCH_BDF(2);
+    else if (a.mpb) LAUNCH_BDF(1);
+    else LAUNCH_BDF(0);
     e = launch_lane_transpose(a, ng, false, stream);
     if (e != hipSuccess) return e;
   }

@@ -64,7 +64,9 @@ template <int NB> struct QuadShape {
 size_t newton_lane4_rec_doubles(int nb, int nx) { return (size_t)nx * 4 * (size_t)((((nb + 4) / 4) * nb + 1) / 2 * 2) * QG; }
 size_t newton_lane4_state_doubles(int nb, int nx) { return (size_t)nx * (size_t)(2 * ((nb + 1) / 2 * 2) + 2 * (nb / 2 * 2)) * QG; }
 
-template <int NB, int MODE>
+// (BDF: the BDF2 history inside the launch -- a template flag here: as a run-time flag it cost the backward-Euler instances 3-8 % in
+// registers moved around, tools/probe/ab_old_new.sh)
+template <int NB, int MODE, bool BDF>
 __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
   constexpr int N = NB - 1;
   constexpr int CL = QuadShape<NB>::CL, CLD = QuadShape<NB>::CLD, RP = QuadShape<NB>::RP;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
   for (int z = (int)(g & 3) * G.lane_stagger; z > 0; --z) __builtin_amdgcn_s_sleep(127);
 #ifdef PNP_LANE_STAMPS
   double stamp_f = 0.0, stamp_b = 0.0, stamp_u = 0.0, stamp_n = 0.0;
+  double row_a = 0.0, row_d = 0.0, row_g = 0.0, row_s = 0.0, row_n = 0.0;      // forward row: assembly / D' and Ah columns / Gauss-Jordan / stores
 #endif
 
   for (;;) {
@@ -154,8 +157,8 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     // BDF2 inside a launch of several timesteps (G.bdf2, lane kernels): a step has a history -- the time level before the previous one,
     // kept in CN -- if the launch started with one or it is not the operating point's first step; then the previous-level value is the
     // combination (4 c_n - c_n-1) / 3 and 1/dt carries 3/2 (pnp_capi.hip: newton_timesteps; comsol_model.py:518-531, maxorder 2)
-    const bool hist = G.bdf2 && have && (G.bdf_hist0 || step > 0);
-    const double sgs = hist ? 1.5 : 1.0;
+    const bool hist = BDF && have && (G.bdf_hist0 || step > 0);
+    const double sgs = (BDF && hist) ? 1.5 : 1.0;
     if (fresh) {
       it = 0;
       upd_prev = INFINITY;
@@ -174,9 +177,10 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     for (int jj = 0; jj < CL; ++jj)
 #pragma unroll
       for (int r = 0; r < NB; ++r) Tl[jj][r] = 0.0;
-    d2 p_a[VP], p_co[CP], p_cn[CP];
-#pragma unroll
-    for (int p = 0; p < CP; ++p) p_cn[p] = (d2)(0.0);
+    d2 p_a[VP], p_co[CP];
+    // (first iteration of a BDF2 step with a history: the previous-level slot of the prefetch carries the level BEFORE the previous one
+    //  -- the previous level of such an iteration is formed from the state itself and not read; one pointer chosen per iteration)
+    const d2* tprev = (BDF && first && hist) ? tcn : tco;
     double p_vi, p_wea, p_web;
     auto request = [&](int s) {
 #ifdef L4_NO_REQUEST      // (diagnosis build: every row reads the first one again -- cache hits)
@@ -188,11 +192,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
 #pragma unroll
       for (int p = 0; p < VP; ++p) p_a[p] = TS(ia, p);
 #pragma unroll
-      for (int p = 0; p < CP; ++p) p_co[p] = CO(i, p);
-      if (first && hist) {      // (first iteration of a BDF2 step: the level before the previous one, read once per step)
-#pragma unroll
-        for (int p = 0; p < CP; ++p) p_cn[p] = CN(i, p);
-      }
+      for (int p = 0; p < CP; ++p) p_co[p] = tprev[((size_t)i * CP + p) * QG];
       p_vi = G.gv[i];
       p_wea = G.gw[side ? i - 1 : i];
       p_web = G.gw[side ? i : (i > 0 ? i - 1 : 0)];
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
               v[0] = bc[2 * p];
               v[1] = 2 * p + 1 < N ? bc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
               CO(nx - 1, p) = v;
-              if (G.bdf2 && have) CN(nx - 1, p) = v;
+              if (BDF && have) CN(nx - 1, p) = v;
             }
           }
         }
@@ -279,12 +279,11 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     for (int s = 0; s < S; ++s) {
       const bool last = s == S - 1;
       const bool act = last ? !side : (side ? s < n_dn : s < m);
-      double ac[N], aphi, co[N], cnv[N];
+      double ac[N], aphi, co[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         ac[k] = p_a[k >> 1][k & 1];
         co[k] = p_co[k >> 1][k & 1];
-        cnv[k] = p_cn[k >> 1][k & 1];
       }
       aphi = p_a[N >> 1][N & 1];
       const double vi = p_vi, wea = p_wea, web = p_web;
@@ -294,6 +293,9 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
         __builtin_amdgcn_wave_barrier();
       }
       if (act) {
+#ifdef PNP_LANE_STAMPS
+        const unsigned long long r0 = __builtin_readcyclecounter();
+#endif
         asm volatile("" : "+v"(poff));
         P = (const LaneParams*)((const char*)&sP + poff);
         const int i = fwd_row(s);
@@ -324,7 +326,15 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
             if constexpr (FULL) pe_ = P->pe[kq];
             const double u = sgn * __builtin_fma(qb_, dphi, dw) - (FULL ? pe_ * rwea : 0.0);
             const double cl = side ? ac_ : hc_, cr = side ? hc_ : ac_;
+#ifdef L4_CHEAP_EDGE      // (diagnosis build: the edge without its exponential)
+            LEdge e;
+            e.Bp = wea * (1.0 - 0.5 * u);
+            e.Bm = wea * (1.0 + 0.5 * u);
+            e.J = -(e.Bm * cr - e.Bp * cl);
+            e.Ju = -wea * 0.5 * (cr + cl);
+#else
             const LEdge e = lane_edge_flux(u, cl, cr, wea);
+#endif
             const double mJ = sgn * e.J, mBd = side ? e.Bm : e.Bp, mBn = side ? e.Bp : e.Bm, mJu = e.Ju;
             if (4 * kk + 0 < N) {
               aJ[k0] = quad_bcast<0>(mJ);
@@ -357,7 +367,11 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
         double rho = 0.0;
         double cs_[N];      // the previous-level value of this step: the state itself (backward Euler) or the BDF2 combination
 #pragma unroll
-        for (int k = 0; k < N; ++k) cs_[k] = (first && hist) ? (4.0 * hc[k] - cnv[k]) / 3.0 : hc[k];
+        for (int k = 0; k < N; ++k) cs_[k] = hc[k];
+        if (BDF && first && hist) {      // (under its own branch: eight divisions that only the first iteration of a BDF2 step needs)
+#pragma unroll
+          for (int k = 0; k < N; ++k) cs_[k] = (4.0 * hc[k] - co[k]) / 3.0;
+        }
         if (first && q == 0) {
 #pragma unroll
           for (int p = 0; p < CP; ++p) {
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
             v[0] = cs_[2 * p];
             v[1] = 2 * p + 1 < N ? cs_[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
             CO(i, p) = v;
-            if (G.bdf2 && have) {      // (a finished point runs along with its wave: its history stays)
+            if (BDF && have) {      // (a finished point runs along with its wave: its history stays)
               d2 w_;
               w_[0] = hc[2 * p];
               w_[1] = 2 * p + 1 < N ? hc[2 * p + 1 < N ? 2 * p + 1 : 0] : 0.0;
@@ -401,6 +415,17 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
           ahNN = wea;
         }
         const double pq = wall ? 0.0 : vi;
+#ifdef PNP_LANE_STAMPS
+        // (the stamps of a row must wait for the section's results: the counter read is scalar code the scheduler would float over the
+        //  vector work -- a sum of everything the section produced is handed to an empty asm first)
+        {
+          double z = rhs[N] + dNN;
+#pragma unroll
+          for (int k = 0; k < N; ++k) z += (rhs[k] + diag[k]) + (Js[k] + aBn[k]);
+          asm volatile("" ::"v"(z));
+        }
+        const unsigned long long r1 = __builtin_readcyclecounter();
+#endif
         // ---- this lane's columns of D' = D - Bk T and of [Ah | r - Bk t] ---------------------------------------------------------------
         double Dl[NB][CLD], Xl[NB][CL];           // [row][local column]
         // (Bk col)[k] = -eBn_k col[k] + eJu_k (qb_k col[N] + binv sum_q vol_q col[q]),  (Bk col)[N] = web col[N]
@@ -550,9 +575,26 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
           }
           Xl[N][jj] = isrhs ? Xl[N][jj] : ((isphi && !last) ? ahNN : 0.0);
         }
+#ifdef PNP_LANE_STAMPS
+        {
+          double z = 0.0;
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+#pragma unroll
+            for (int jj = 0; jj < CL; ++jj) z += Xl[r][jj] + (jj < CLD ? Dl[r][jj < CLD ? jj : 0] : 0.0);
+          }
+          asm volatile("" ::"v"(z));
+        }
+        const unsigned long long r2 = __builtin_readcyclecounter();
+#endif
         // ---- Gauss-Jordan over the distributed columns ------------------------------------------------------------------------------------------
+#ifdef L4_NO_GJ      // (diagnosis build, tools/probe/lane4_stamps.sh: what the row costs without its elimination; results are wrong)
+#pragma unroll
+        for (int k = 0; k < 0; ++k) {
+#else
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
+#endif
           double pc[NB];
 #pragma unroll
           for (int r = 0; r < NB; ++r) pc[r] = quad_bcast_sel(k & 3, Dl[r][k >> 2]);
@@ -577,6 +619,18 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
             for (int r = 0; r < NB; ++r) Xl[r][jj] = r == k ? t_ : __builtin_fma(-pc[r], t_, Xl[r][jj]);
           }
         }
+#ifdef PNP_LANE_STAMPS
+        {
+          double z = 0.0;
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+#pragma unroll
+            for (int jj = 0; jj < CL; ++jj) z += Xl[r][jj];
+          }
+          asm volatile("" ::"v"(z));
+        }
+        const unsigned long long r3 = __builtin_readcyclecounter();
+#endif
         // The next row's inputs (requested at the top of this row) are made to ARRIVE here, before this row's record stores are issued:
         // vector memory operations retire in order and the compiler's wait-count bookkeeping is conservative across the loop's back
         // edge -- left to itself it consumes these loads after the stores with s_waitcnt vmcnt(0), i.e. every row waits for its own
@@ -636,6 +690,16 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
           eBd[k] = aBn[k];
           eJu[k] = aJu[k];
         }
+#ifdef PNP_LANE_STAMPS
+        {
+          const unsigned long long r4 = __builtin_readcyclecounter();
+          row_a += (double)(r1 - r0);
+          row_d += (double)(r2 - r1);
+          row_g += (double)(r3 - r2);
+          row_s += (double)(r4 - r3);
+          row_n += 1.0;
+        }
+#endif
       }
     }
 #ifdef PNP_LANE_STAMPS
@@ -881,9 +945,21 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     G.iters[slot + 1] = (int32_t)(stamp_b / stamp_n);
     G.iters[slot + 2] = (int32_t)(stamp_u / stamp_n);
     G.iters[slot + 3] = (int32_t)stamp_n;
+    if (slot + 7 < G.B) {      // ... and the sections of a forward row, mean cycles per row
+      G.iters[slot + 4] = (int32_t)(row_a / row_n);
+      G.iters[slot + 5] = (int32_t)(row_d / row_n);
+      G.iters[slot + 6] = (int32_t)(row_g / row_n);
+      G.iters[slot + 7] = (int32_t)(row_s / row_n);
+    }
   }
 #endif
 }
+
+#define LAUNCH_BDF(MODE_)                                                                                              \
+  do {                                                                                                                 \
+    if (a.bdf2) hipLaunchKernelGGL((newton_lane4_kernel<NB, MODE_, true>), dim3((unsigned)ng), dim3(64), 0, stream, a);  \
+    else hipLaunchKernelGGL((newton_lane4_kernel<NB, MODE_, false>), dim3((unsigned)ng), dim3(64), 0, stream, a);       \
+  } while (0)
 
 template <int NB>
 static hipError_t launch_lane4_nb(const NewtonArgs& a0, hipStream_t stream) {
@@ -898,9 +974,9 @@ static hipError_t launch_lane4_nb(const NewtonArgs& a0, hipStream_t stream) {
     const int64_t ng = groups - g0 < cap ? groups - g0 : cap;
     hipError_t e = launch_lane_transpose(a, ng, true, stream);
     if (e != hipSuccess) return e;
-    if (a.rt || a.convect) hipLaunchKernelGGL((newton_lane4_kernel<NB, 2>), dim3((unsigned)ng), dim3(64), 0, stream, a);
-    else if (a.mpb) hipLaunchKernelGGL((newton_lane4_kernel<NB, 1>), dim3((unsigned)ng), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((newton_lane4_kernel<NB, 0>), dim3((unsigned)ng), dim3(64), 0, stream, a);
+    if (a.rt || a.convect) LAUNCH_BDF(2);
+    else if (a.mpb) LAUNCH_BDF(1);
+    else LAUNCH_BDF(0);
     e = launch_lane_transpose(a, ng, false, stream);
     if (e != hipSuccess) return e;
   }

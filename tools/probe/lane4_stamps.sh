@@ -26,4 +26,6 @@ f, b, u, n = it[:, 0].astype(float), it[:, 1].astype(float), it[:, 2].astype(flo
 tot = f + b + u
 print('N=%d nx=%d B=%d: %.3f ms per step; per wave and Newton iteration: forward %.0f cycles (%.0f per row), backward %.0f (%.0f), update %.0f (%.0f per row of a lane); shares %.2f / %.2f / %.2f; iterations per wave %.1f'
       % (N, nx, B, ms / 10, f.mean(), f.mean() / (nx / 2), b.mean(), b.mean() / (nx / 2), u.mean(), u.mean() / (nx / 8), (f / tot).mean(), (b / tot).mean(), (u / tot).mean(), n.mean()))
+print('forward row, mean cycles: assembly (edges, right-hand side) %.0f, columns of D\' and Ah %.0f, Gauss-Jordan %.0f, arrival + record stores + hand-over %.0f'
+      % (it[:, 4].mean(), it[:, 5].mean(), it[:, 6].mean(), it[:, 7].mean()))
 PY
