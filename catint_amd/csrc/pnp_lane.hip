@@ -1070,11 +1070,19 @@ bool newton_lane_preferred(int nb, int nx, int64_t B, int mode, const Options& o
   //            for the pair kernel (nx > 512): 0.9-1.0 x at 2048, 1.65 x at 4096, 2.9 x at 8192 against the lane teams
   //   N = 3:   0.6-0.75 x at 8192, 1.1-1.5 x at 32 768 against the pair kernel; grids too long for it (nx > 1024): 2.7 x at 8192
   //   N = 2:   only on grids too long for the pair kernel (1.95 x at B = 8192, nx = 4096)
+  // Round 4, small blocks again with the update fused into the back-substitution (+15-20 % for this kernel; tools/probe/family_rates.py
+  // --families lane+fused,workgroup -> profiles/r04_family_rates_small_blocks.jsonl: N = 2, 3, 4 x nx = 512, 1024, 2048 x seven batches,
+  // 10-step launches, timesteps/s fused lane kernel / the best workgroup-per-point kernel):
+  //   N = 4, pair kernel (nx = 512): 4096 1.15e6 / 1.49e6, 8192 2.01e6 / 1.52e6;  lane teams (nx >= 1024): 2048 2.99e5 / 2.64e5
+  //   N = 3, pair kernel: nx = 512: 12 288 3.10e6 / 3.50e6, 16 384 3.91e6 / 3.57e6; nx = 1024: 8192 1.24e6 / 1.45e6, 12 288 1.63e6 / 1.48e6;
+  //          lane teams (nx = 2048): 2048 1.78e5 / 1.86e5, 4096 3.40e5 / 1.97e5
+  //   N = 2, pair kernel: nx = 512: 24 576 6.35e6 / 6.76e6, 32 768 7.57e6 / 6.93e6; nx = 1024: 16 384 2.67e6 / 2.84e6, 24 576 3.23e6 / 2.89e6;
+  //          lane teams (nx = 2048): 2048 2.37e5 / 3.42e5, 4096 4.44e5 / 3.38e5
   if (nb >= 6) return B >= 1280;
   const bool pair = newton_pair_threads(nb, nx) > 0;
-  if (nb == 5) return pair ? B >= 8192 : B >= 3072;
-  if (nb == 4) return pair ? B >= 24576 : B >= 4096;
-  if (nb == 3) return !pair && B >= 4096;
+  if (nb == 5) return pair ? B >= 6144 : B >= 2048;
+  if (nb == 4) return pair ? B >= (nx > 768 ? 11264 : 15360) : B >= 3072;
+  if (nb == 3) return pair ? B >= (nx > 768 ? 20480 : 28672) : B >= 4096;
   return false;
 }
 
@@ -1119,9 +1127,11 @@ static hipError_t launch_lane_nb(const NewtonArgs& a0, hipStream_t stream) {
     // (tools/probe/family_rates.py -> profiles/r04_family_rates.jsonl, one device, one call, 20-step launches, timesteps/s separate /
     // fused: N = 8, nx = 512: B = 8192 6.24e5 / 6.95e5, 16 384 1.05e6 / 1.19e6, 24 576 1.32e6 / 1.53e6; N = 6, nx = 1024: 16 384
     // 9.14e5 / 9.15e5, 24 576 1.06e6 / 1.16e6; N = 4, nx = 1024, B = 16 384 1.44e6 / 1.72e6; N = 2, nx = 4096, B = 8192 3.4e5 / 4.2e5;
-    // the round-3 measurement with cached record accesses had the separate passes ahead below 24 576 points).  Stationary solves
-    // (damped iterations at their start) keep the round-3 rule.
-    const bool fused = (a.opt && a.opt->lane_fused >= 0) ? a.opt->lane_fused != 0 : (a.stationary ? a.B >= 24576 : true);
+    // the round-3 measurement with cached record accesses had the separate passes ahead below 24 576 points).  Stationary solves from
+    // the bulk state (damped iterations at their start): level, tools/probe/stationary_fused_ab.py -> profiles/r04_stationary_fused_ab.jsonl
+    // (separate / fused, ms per solve: 8 x 512 x 16 384 26.6 / 26.3, 32 768 40.0 / 39.6, 6 x 1024 x 16 384 35.7 / 32.9, 3 x 512 x 16 384
+    // 11.1 / 10.6) -- so the fused form is the one that runs; option LANE_FUSED = 0 keeps the separate passes selectable.
+    const bool fused = (a.opt && a.opt->lane_fused >= 0) ? a.opt->lane_fused != 0 : true;
     const int mode = (a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0);
     const dim3 gk((unsigned)ng), bk(64);
     if (fused) {

@@ -172,11 +172,14 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     double hc[N], hphi, hw = 0.0, hinv = 1.0;
     double bphi = 0.0, binv = 1.0;
     double eJ[N], eBd[N], eBn[N], eJu[N];                 // behind edge, every species, in all four column lanes
-    double Tl[CL][NB];                                    // this lane's columns of the behind record [T | t]
+    // this lane's columns of the behind record [T | t], [row][local column]: the SAME registers hold the augmented block [Ah | r] of the
+    // row being eliminated -- column jj of the new block depends on column jj of the record only, so it is built in place and what
+    // the Gauss-Jordan leaves there is the next row's record (no copy at the end of a row, 54 registers less to keep alive)
+    double Xl[NB][CL];
 #pragma unroll
     for (int jj = 0; jj < CL; ++jj)
 #pragma unroll
-      for (int r = 0; r < NB; ++r) Tl[jj][r] = 0.0;
+      for (int r = 0; r < NB; ++r) Xl[r][jj] = 0.0;
     d2 p_a[VP], p_co[CP];
     // (first iteration of a BDF2 step with a history: the previous-level slot of the prefetch carries the level BEFORE the previous one
     //  -- the previous level of such an iteration is formed from the state itself and not read; one pointer chosen per iteration)
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
         // t is column NB of [T | t]: it lives in column lane NB & 3, local index NB >> 2
         if (q == (NB & 3)) {
 #pragma unroll
-          for (int r = 0; r < NB; ++r) Tl[NB >> 2][r] = tb[r];
+          for (int r = 0; r < NB; ++r) Xl[r][NB >> 2] = tb[r];
         }
         if (q == 0) {
 #pragma unroll
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
         const unsigned long long r1 = __builtin_readcyclecounter();
 #endif
         // ---- this lane's columns of D' = D - Bk T and of [Ah | r - Bk t] ---------------------------------------------------------------
-        double Dl[NB][CLD], Xl[NB][CL];           // [row][local column]
+        double Dl[NB][CLD];           // [row][local column]
         // (Bk col)[k] = -eBn_k col[k] + eJu_k (qb_k col[N] + binv sum_q vol_q col[q]),  (Bk col)[N] = web col[N]
         auto minus_bk = [&](const double (&col)[NB], double (&v)[NB], const double (&bn)[N], const double (&ju)[N], double inv_, double wN) {
           double sj = 0.0;
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
           v[N] = isrhs ? rhs[N] : (isphi ? dNN : (j > NB ? 0.0 : pq * peqj));
           double col[NB];
 #pragma unroll
-          for (int r = 0; r < NB; ++r) col[r] = Tl[jj][r];
+          for (int r = 0; r < NB; ++r) col[r] = Xl[r][jj];
           minus_bk(col, v, eBn, eJu, binv, web);
           // D' has columns j < NB, the augmented block gets the right-hand side (j == NB) here and the Ah columns below
 #pragma unroll
@@ -653,7 +656,6 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
             const int e = jj * NB + r;
-            Tl[jj][r] = Xl[r][jj];
             if ((e & 1) == 0) {
               held = Xl[r][jj];
               if (e == CL * NB - 1) {
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
 #endif
             }
           }
-        // (middle row: x_m = the solved right-hand side now sits in its owner's t slot Tl[NB >> 2], where the hand-over below takes it;
+        // (middle row: x_m = the solved right-hand side now sits in its owner's t slot Xl[.][NB >> 2], where the hand-over below takes it;
         //  the zero Ah columns of that row leave zeros in the other slots)
         bphi = hphi;
         binv = hinv;
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(64) void newton_lane4_kernel(const NewtonArgs G) {
     double x[NB];
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      const double up = quad_bcast<(NB & 3)>(Tl[NB >> 2][r]);
+      const double up = quad_bcast<(NB & 3)>(Xl[r][NB >> 2]);
       const double from_up = other_side(up);            // (cross-lane: every lane takes part, the select comes afterwards)
       x[r] = side ? from_up : up;
     }

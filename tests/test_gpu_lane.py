@@ -328,8 +328,7 @@ def test_first_solve_after_an_upload_is_ordered_by_the_potential_difference_and_
     (8, 64, 35, {'time_order': 2, 'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 8}),
 ])
 def test_update_fused_into_the_back_substitution_and_separate_passes_are_the_same_iteration(N, nx, B, kw):
-    """The lane kernel's two forms (option LANE_FUSED; timesteps run the fused one at every batch since round 4, stationary solves from
-    24 576 points on): the update applied inside the back-substitution with two state copies, or written out and applied by a third
+    """The lane kernel's two forms (option LANE_FUSED; the fused one runs by default since round 4): the update applied inside the back-substitution with two state copies, or written out and applied by a third
     pass.  Same arithmetic in the same order -- timesteps (first steps from the bulk state: damped iterations walk the back-substitution
     twice) and a stationary solve give the same bits, iteration counts and status either way; and both match the oracle."""
     D, q, cb, dx, phiM = make_lanes(N, nx, B, 23, phi_lo=-0.25, phi_hi=0.25)

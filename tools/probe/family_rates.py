@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timesteps/s of the lane-kernel families on the bench's workload (one warm-up step, then STEPS steps in one call, best of 2), one device,
 one process -- the measurement behind newton_lane*_preferred and the lane kernel's fused flag.
-usage: python tools/probe/family_rates.py "N NX B STEPS" ..."""
+usage: python tools/probe/family_rates.py [--families lane+fused,workgroup] "N NX B STEPS" ..."""
 import json
 import os
 import sys
@@ -14,13 +14,20 @@ FAMILIES = (('lane4', {'NEWTON_KERNEL': 'lane4'}), ('lane2', {'NEWTON_KERNEL': '
 
 
 def main():
-    for spec in sys.argv[1:]:
+    argv = sys.argv[1:]
+    only = None
+    if argv and argv[0] == '--families':
+        only = set(argv[1].split(','))
+        argv = argv[2:]
+    for spec in argv:
         N, nx, B, steps = (int(v) for v in spec.split())
         row = {'N': N, 'nx': nx, 'B': B, 'steps': steps}
         for name, opts in FAMILIES:
+            if only is not None and name not in only:
+                continue
             if name == 'lane4' and N < 5:
                 continue
-            if name == 'workgroup' and B * nx * N > 8192 * 512 * 8:
+            if only is None and name == 'workgroup' and B * nx * N > 8192 * 512 * 8:
                 continue
             s, inp = bench.newton_solver(B, N, nx, 4446, 0, steric=N >= 5)
             for k, v in opts.items():
