@@ -225,6 +225,26 @@ def test_kernel_choice_for_large_batches_of_large_blocks(monkeypatch):
     assert np.array_equal(e[0], f[0]) and np.array_equal(e[2], f[2])
 
 
+@pytest.mark.parametrize("N,nx,B,family", [
+    (8, 16, 512, 'workgroup'), (8, 16, 1024, 'lane4'), (8, 16, 8192, 'lane4'), (8, 16, 10240, 'lane2'), (8, 16, 16384, 'lane2'),
+    (8, 16, 16385, 'lane+fused'), (6, 16, 13311, 'lane2'), (6, 16, 13312, 'lane+fused'), (7, 16, 14335, 'lane2'), (7, 16, 14336, 'lane+fused'),
+    (4, 16, 6143, 'workgroup'), (4, 16, 6144, 'lane+fused'), (3, 16, 15359, 'workgroup'), (3, 16, 15360, 'lane+fused'),
+    (2, 16, 28671, 'workgroup'), (2, 16, 28672, 'lane+fused'), (2, 2100, 4096, 'lane+fused'), (2, 2100, 4095, 'workgroup'),
+])
+def test_default_family_follows_the_measured_thresholds(N, nx, B, family, monkeypatch):
+    """pnp_autotune_default reports the kernel family the library's thresholds choose for a batch -- the table of
+    profiles/r04_family_rates*.jsonl as the selection functions state it (pnp_lane.hip, pnp_lane4.hip): lane quad from 896 to 10 239
+    points, lane pair up to 16 384 at N = 8 (14 335 at N = 7, 13 311 below), then the fused lane kernel; small blocks go to the lane
+    kernel where it overtakes the pair kernel / the lane teams."""
+    monkeypatch.delenv('CATINT_NEWTON_KERNEL', raising=False)
+    D, q, cb, dx, phiM = make_lanes(N, nx, 2, 5)
+    with _capi.PnpSolver(N, nx, dx, 1e-9, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+        assert s.default_family() is None                      # no batch yet
+        s.set_newton(**({'mpb_radius': [3.5e-10] * N} if N >= 5 else {}))
+        s.set_batch(np.repeat(np.repeat(cb[:1], B, axis=0)[:, :, None], nx, axis=2), np.zeros((B, 4)), np.zeros(B), np.zeros((B, N)))
+        assert s.default_family() == family
+
+
 @pytest.mark.parametrize("time_order", [1, 2])
 def test_autotune_measures_every_family_and_leaves_the_trajectory_untouched(time_order, monkeypatch):
     """pnp_autotune: every kernel family that supports the shape is timed on the handle's own batch (one warm-up step + nsteps from the

@@ -3,7 +3,8 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04prof; mkdir -p $O; export TMPDIR=/tmp
 if [ "$1" = part1 ]; then
   cd $R
-  python bench.py --steps 20 --warmup 5 > $O/r04_bench_line_steps20.json 2> $O/steps20.err; echo "steps20 rc $?"
+  python bench.py --steps 20 --warmup 5 > $O/r04_bench_line_steps20$RUN.json 2> $O/steps20.err; echo "steps20 rc $?"
+  [ -n "$RUN" ] && exit 0      # (RUN=_run2: only the driver's command again -- another box of the pool)
   python bench.py > $O/r04_bench_line_default.json 2> $O/default.err; echo "default rc $?"
   CATINT_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-pmc --no-cpu-baseline > $O/r04_bench_line_gpus2_gloo_rehearsal.json 2> $O/gpus2.err; echo "gpus2 rc $?"
   cd /tmp
