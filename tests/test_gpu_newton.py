@@ -704,6 +704,48 @@ def test_bdf2_steps_split_over_calls_and_second_order_in_time(kernel, N, B, monk
     assert 1.6 < err[1] < 2.6 and 3.0 < err[2] < 5.5, err
 
 
+@pytest.mark.parametrize("kernel,B", [('lane', 133), ('lane2', 70), ('lane4', 37)])
+def test_bdf2_history_inside_the_lane_kernels_with_several_chunks_and_a_mask(kernel, B, monkeypatch):
+    """The lane kernels keep the BDF2 history in their transposed workspace and bring it home between launches.  With a workspace of
+    ONE group (the launcher walks the batch in chunks, every chunk transposes its own history in and out) and split calls the
+    trajectory is the one-call, whole-workspace trajectory to the bit; and operating points masked out of a call keep state AND
+    history, so that they continue from where they were."""
+    N, nx = 6, 64
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 17)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    kw = dict(time_order=2, mpb_radius=[3.5e-10] * N, wall_bc='stern', stern_capacitance=0.25)
+
+    def run(groups, calls, mask_call=None):
+        monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+        if groups:
+            monkeypatch.setenv('CATINT_NEWTON_LANE_GROUPS', str(groups))
+        else:
+            monkeypatch.delenv('CATINT_NEWTON_LANE_GROUPS', raising=False)
+        with _capi.PnpSolver(N, nx, dx, dt, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+            s.set_newton(**kw)
+            s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+            for i, n in enumerate(calls):
+                if mask_call is not None and i == mask_call[0]:
+                    s.set_lane_mask(mask_call[1])
+                s.step(n)
+                if mask_call is not None and i == mask_call[0]:
+                    s.set_lane_mask(None)
+            assert (s.get_status() == 0).all()
+            return s.get_state()[0], s.get_state()[1]
+    whole = run(0, [5])
+    chunks = run(1, [2, 1, 2])
+    assert np.array_equal(whole[0], chunks[0]) and np.array_equal(whole[1], chunks[1])
+    # the odd points sit out the middle call: they end on the 4-step trajectory, the even ones on the 5-step trajectory
+    mask = (np.arange(B) % 2 == 0).astype(np.int32)
+    mixed = run(1, [2, 1, 2], mask_call=(1, mask))
+    four = run(0, [4])
+    even, odd = mask == 1, mask == 0
+    assert np.array_equal(mixed[0][even], whole[0][even]) and np.array_equal(mixed[0][odd], four[0][odd])
+
+
 # ---- constant convection velocity (tp.system['flow rate'], comsol_model.py:901-903) ------------------------------------------------------
 @pytest.mark.parametrize("N,nx,B,kernel,kw,graded", [
     (3, 128, 5, None, {}, False),                                                                       # pair kernel
