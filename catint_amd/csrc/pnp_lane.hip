@@ -201,7 +201,21 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   // The record a row hands to the next one (T, t) and the LU factors of D' do not both fit the register file next to everything
   // else once the blocks are 8 x 8 or 9 x 9: the first TL columns of T then live in LDS (written as they are solved, read back
   // column by column when the next row forms D'), the rest and t stay in registers.  4 waves per CU: at most 40 KiB each.
-  constexpr int TL = NB >= 9 ? 8 : (NB >= 8 ? 5 : 0);
+  // How many: measured at the end of round 4 (tools/probe/lane_tl_variants.sh + ab_libs.sh: the variants alternated process by process
+  // on one device, timesteps/s).  9 x 9 blocks, 32 768 points, 8 / 7 / 6 / 5 / 4 columns in LDS: 1.75e6 / 1.77e6 / 1.66e6 / 1.70e6 /
+  // 1.59e6 on one box, 1.56e6 / 1.70e6 (8 / 7) on another; 16 384 points 1.14e6 / 1.29e6 (8 / 7): seven -- the eighth column's LDS
+  // traffic costs more than the 64 bytes of scratch it saves.  7 x 7 blocks (no scratch to speak of): 0 / 2 / 4 / 6 columns level at
+  // 32 768 points (1.20e6), 1.03e6 / 1.02e6 / 0.94e6 / 0.92e6 at 16 384: none.
+#ifndef PNP_LANE_TL9      // (A/B builds: tools/probe/lane_tl_variants.sh)
+#define PNP_LANE_TL9 7
+#endif
+#ifndef PNP_LANE_TL8
+#define PNP_LANE_TL8 5
+#endif
+#ifndef PNP_LANE_TL7
+#define PNP_LANE_TL7 0
+#endif
+  constexpr int TL = NB >= 9 ? PNP_LANE_TL9 : (NB >= 8 ? PNP_LANE_TL8 : (NB >= 7 ? PNP_LANE_TL7 : 0));
   constexpr int TR = NB - TL;                // columns of T in registers
   __shared__ double s_T[TL > 0 ? TL * NB : 1][64];
   // per-species constants: with all five arrays read from the kernel arguments the scalar registers run out and are spilled to
