@@ -1121,7 +1121,9 @@ bool newton_lane2_preferred(int nb, int nx, int64_t B, int mode, const Options& 
   // lane fused): N = 8, nx = 512: B = 14 336 1.17e6 / 1.05e6, 16 384 (1024 waves of 16 points: the last batch in one round) 1.25e6 /
   // 1.19e6, 18 432 0.97e6 / 1.20e6; N = 8, nx = 1024: 16 384 5.6e5 / 5.4e5; N = 6, nx = 1024: 12 288 7.6e5 / 7.4e5, 14 336 7.8e5 / 8.1e5;
   // N = 6, nx = 512: 12 288 1.62e6 / 1.58e6, 16 384 1.90e6 / 2.04e6.
-  return B >= 1280 && B <= (nb >= 9 ? 16384 : (nb == 8 ? 14335 : 13311));
+  // N = 7, nx = 512 (profiles/r04_family_rates_n5_n7.jsonl): 12 288 1.39e6 / 1.28e6, 14 336 1.44e6 / 1.47e6;  N = 5: 10 240 1.79e6 / 1.86e6,
+  // 12 288 2.12e6 / 2.26e6 -- no window above the lane quad's.
+  return B >= 1280 && B <= (nb >= 9 ? 16384 : (nb >= 7 ? 13311 : 10239));
 }
 
 template <int NB>

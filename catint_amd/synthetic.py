@@ -18,7 +18,9 @@ SPECIES_SETS = {
     2: ['K+', 'HCO3-'],
     3: ['K+', 'Cl-', 'HCO3-'],
     4: ['K+', 'Na+', 'Cl-', 'HCO3-'],
+    5: ['K+', 'Na+', 'Cl-', 'HCO3-', 'OH-'],                       # (5, 7: not in SURVEY section 8d's list -- probes of the kernel thresholds)
     6: ['K+', 'Na+', 'Cl-', 'HCO3-', 'CO32-', 'OH-'],
+    7: ['K+', 'Na+', 'Cl-', 'HCO3-', 'CO32-', 'OH-', 'Cs+'],
     8: ['K+', 'Na+', 'Cl-', 'HCO3-', 'CO32-', 'OH-', 'Cs+', 'ClO4-'],
 }
 

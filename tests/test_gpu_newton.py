@@ -227,14 +227,14 @@ def test_kernel_choice_for_large_batches_of_large_blocks(monkeypatch):
 
 @pytest.mark.parametrize("N,nx,B,family", [
     (8, 16, 512, 'workgroup'), (8, 16, 1024, 'lane4'), (8, 16, 8192, 'lane4'), (8, 16, 10240, 'lane2'), (8, 16, 16384, 'lane2'),
-    (8, 16, 16385, 'lane+fused'), (6, 16, 13311, 'lane2'), (6, 16, 13312, 'lane+fused'), (7, 16, 14335, 'lane2'), (7, 16, 14336, 'lane+fused'),
+    (8, 16, 16385, 'lane+fused'), (6, 16, 13311, 'lane2'), (6, 16, 13312, 'lane+fused'), (7, 16, 13311, 'lane2'), (7, 16, 13312, 'lane+fused'), (5, 16, 10239, 'lane4'), (5, 16, 10240, 'lane+fused'),
     (4, 16, 6143, 'workgroup'), (4, 16, 6144, 'lane+fused'), (3, 16, 15359, 'workgroup'), (3, 16, 15360, 'lane+fused'),
     (2, 16, 28671, 'workgroup'), (2, 16, 28672, 'lane+fused'), (2, 2100, 4096, 'lane+fused'), (2, 2100, 4095, 'workgroup'),
 ])
 def test_default_family_follows_the_measured_thresholds(N, nx, B, family, monkeypatch):
     """pnp_autotune_default reports the kernel family the library's thresholds choose for a batch -- the table of
     profiles/r04_family_rates*.jsonl as the selection functions state it (pnp_lane.hip, pnp_lane4.hip): lane quad from 896 to 10 239
-    points, lane pair up to 16 384 at N = 8 (14 335 at N = 7, 13 311 below), then the fused lane kernel; small blocks go to the lane
+    points, lane pair up to 16 384 at N = 8 (13 311 at N = 6, 7; none at N = 5), then the fused lane kernel; small blocks go to the lane
     kernel where it overtakes the pair kernel / the lane teams."""
     monkeypatch.delenv('CATINT_NEWTON_KERNEL', raising=False)
     D, q, cb, dx, phiM = make_lanes(N, nx, 2, 5)
