@@ -31,7 +31,7 @@ class FakeSolver(object):
         self.law = (alpha, saturation)
         self.calls.append(('kinetics', list(species), np.array(nu, float).copy(), np.array(k, float).copy()))
 
-    def solve_stationary(self):
+    def solve_stationary(self, tol=0.0, maxit=0):
         n = sum(1 for c in self.calls if c[0] == 'solve')
         self.calls.append(('solve',))
         if self.fail_direct and n == 0:
@@ -210,7 +210,7 @@ class LadderSolver(FakeSolver):
     def get_state(self):
         return self.c.copy(), self.phi.copy(), None, None
 
-    def solve_stationary(self):
+    def solve_stationary(self, tol=0.0, maxit=0):
         self.calls.append(('solve',))
         st = np.zeros(self.B, np.int32)
         if self.mask is not None:            # confirming solve of patched lanes: their state stays, the verdict is the handle's
