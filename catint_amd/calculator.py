@@ -341,12 +341,15 @@ class Calculator(object):
                 out[:, names.index(sp)] += v * K * g
         return out
 
-    def solve_physical(self, solver, c0, phiM, flux, nramp=8, warm=False, retry=True):
+    def solve_physical(self, solver, c0, phiM, flux, nramp=4, warm=False, retry=True):
         """One transport solve of every lane (run_single_step, calculator.py:408-535).
         Stationary mode: Newton from the current state (warm) or from the bulk state.  If lanes do not converge from the
         bulk state -- or the potentials are far from phiPZC, or surface kinetics are coupled in, where that is the rule --
         every lane walks a continuation path instead: the wall potential goes from phiPZC (uncharged interface) to its phiM
-        in stages of at most tp.newton['dphi_stage'] (0.2 V; 0.1 ... 0.5 V give the same answer on the CO2R example), the prescribed fluxes grow proportionally and the surface
+        in stages of at most tp.newton['dphi_stage'] (0.4 V since round 4, at least nramp = 4 stages; round 3: 0.2 V and 8.  The Newton iteration limits its own
+        potential step, so wide stages cost iterations, not convergence: on the CO2R example 0.2 / 0.3 / 0.4 / 0.5 / 1.0 V = 11 / 8 / 6 / 5 / 3 stages take
+        0.126 / 0.095 / 0.081 / 0.068 / 0.051 s, all 4096 lanes converge to the same answer (1e-9; tools/probe/co2r_stage_width.py ->
+        profiles/r04_co2r_stage_width.jsonl); lanes that fail walk the path again with 2, 4, 8 x the stages, see below), the prescribed fluxes grow proportionally and the surface
         rate constants are evaluated at the stage potential, each stage warm-started from the previous one (the reference's
         parametric sweeps: flux_factor / PZC / CS ramps, transport.py:877-893, comsol_model.py:1147-1167).
         Time-dependent mode: tp.nt-1 backward-Euler steps.  retry=False: no rerun ladder for lanes that fail (the first solve of an
@@ -368,6 +371,8 @@ class Calculator(object):
             solver.step(self.tp.nt - 1)
             return solver.get_status()
         nk = getattr(self.tp, 'newton', {})
+        if nramp > 1 and 'min_stages' in nk:      # (tp.newton['min_stages']: the least number of stages of a continuation path)
+            nramp = int(nk['min_stages'])
         stern = self.tp.system.get('wall potential', 'stern') == 'stern' and float(self.tp.system.get('Stern capacitance', 0.0)) > 0
         start = float(self.tp.system.get('phiPZC', 0.0)) if stern else 0.0
         span = float(np.abs(phiM - start).max())
@@ -378,7 +383,7 @@ class Calculator(object):
             st = solver.solve_stationary()
             if not (st != 0).any() or nramp <= 1:
                 return st
-        nst = max(int(nramp), int(np.ceil(span / nk.get('dphi_stage', 0.2))))
+        nst = max(int(nramp), int(np.ceil(span / nk.get('dphi_stage', 0.4))))
         self.continuation_stages = nst
         st = self._continuation(solver, c0, pb, vz, flux, phiM, start, nst)
         # Lanes that still fail: the reference reruns COMSOL up to 25 times with a load / non-linearity ramp half as coarse each time

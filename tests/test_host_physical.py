@@ -74,7 +74,7 @@ def test_failed_direct_solve_restarts_on_the_continuation_path():
     flux = np.array([[0.0, 0.0, -1e-4]] * 3)
     calc.solve_physical(s, np.zeros((3, 3 * tp.nx)), phis, flux)
     stages = calc.continuation_stages
-    assert stages == 8                                  # nramp: span 0.34 V / 0.1 V = 4 stages < 8
+    assert stages == 4                                  # nramp: span 0.34 V / 0.4 V = 1 stage < 4 (round 3: 8 stages of at most 0.2 V)
     batches = [c for c in s.calls if c[0] == 'set_batch']
     assert len(batches) == 2                            # direct attempt, then the restart from the bulk state
     assert np.allclose(batches[1][1], 0.16 + (phis - 0.16) / stages) and np.allclose(batches[1][2], flux / stages)
@@ -83,7 +83,7 @@ def test_failed_direct_solve_restarts_on_the_continuation_path():
     assert np.allclose([c for c in s.calls if c[0] == 'set_flux'][-1][1], flux)
 
 
-def test_far_potentials_and_kinetics_walk_from_phi_pzc_in_200mV_stages():
+def test_far_potentials_and_kinetics_walk_from_phi_pzc_in_400mV_stages():
     phis = np.linspace(-0.5, -2.0, 4)
     tp = make_tp(phis)
     calc = Calculator(transport=tp, calc='comsol')
@@ -91,7 +91,13 @@ def test_far_potentials_and_kinetics_walk_from_phi_pzc_in_200mV_stages():
     calc.set_surface_kinetics([{'species': 'CO2', 'rate': rate, 'stoichiometry': {'CO2': -1.0, 'HCO3-': 0.5}}])
     s = FakeSolver()
     calc.solve_physical(s, np.zeros((4, 3 * tp.nx)), phis, np.zeros((4, 3)))
+    assert calc.continuation_stages == int(np.ceil(2.16 / 0.4))
+    tp.newton = {'dphi_stage': 0.2}                     # (the width is an input: tp.newton['dphi_stage'])
+    s2 = FakeSolver()
+    calc.solve_physical(s2, np.zeros((4, 3 * tp.nx)), phis, np.zeros((4, 3)))
     assert calc.continuation_stages == int(np.ceil(2.16 / 0.2))
+    tp.newton = {}
+    calc.solve_physical(FakeSolver(), np.zeros((4, 3 * tp.nx)), phis, np.zeros((4, 3)))
     assert [c[0] for c in s.calls].count('solve') == calc.continuation_stages
     kin = [c for c in s.calls if c[0] == 'kinetics']
     assert len(kin) == calc.continuation_stages and kin[0][1] == [2]
@@ -230,7 +236,7 @@ def test_failed_lanes_walk_finer_ramps_and_are_patched_back(monkeypatch):
     state in the main handle (pnp_set_lanes: nothing else moves) and is confirmed by a solve of the main handle restricted to them."""
     phis = np.linspace(-0.5, -2.0, 4)
     tp = make_tp(phis)
-    tp.newton = {'retry_rungs': 3, 'retry_mesh_rungs': 0}
+    tp.newton = {'retry_rungs': 3, 'retry_mesh_rungs': 0, 'dphi_stage': 0.2}      # (11 stages, as the ladder's numbers below assume)
     calc = Calculator(transport=tp, calc='comsol')
     main = LadderSolver(4, tp.nx, 3, stuck=[1, 3])
     subs = []
@@ -261,7 +267,7 @@ def test_mesh_rung_and_the_main_handles_verdict(monkeypatch):
     phis = np.linspace(-0.5, -2.0, 3)
     tp = make_tp(phis)
     tp.set_graded_mesh(tp.xmesh[1] / 50.0)
-    tp.newton = {'retry_rungs': 1, 'retry_mesh_rungs': 2}
+    tp.newton = {'retry_rungs': 1, 'retry_mesh_rungs': 2, 'dphi_stage': 0.2}
     calc = Calculator(transport=tp, calc='comsol')
     main = LadderSolver(3, tp.nx, 3, stuck=[0, 2], confirm_fails=[2])
     grids = []
