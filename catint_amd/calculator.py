@@ -11,6 +11,7 @@ The reference runs one descriptor point at a time; here every descriptor point i
 GPU batch (`integrate_pnp_batch`, `run`).
 """
 import copy
+import os
 
 import numpy as np
 
@@ -582,47 +583,44 @@ class Calculator(object):
     def fill_alldata_batch(self, cfin, v, g, l, flux, status, kinetic_flux=None, first=0):
         """Descriptor points first ... first + B - 1: tp.alldata[i]['species'|'system'] in the field contract of the reference's reader
         (comsol_reader.py:196-326) from the arrays a transport solve leaves behind -- cfin [B][N][nx], potential v,
-        gradient g and charge row l [B][nx], prescribed wall fluxes flux [B][N].  Host arithmetic only, one numpy pass per 64 lanes
-        (a sweep of 4096 voltages spent 0.5 s here point by point, three times its transport solves); the per-point entries are
-        rows of the batch arrays.  (tests/test_results_io.py walks the reference's plotting accesses over its output without a GPU.)"""
+        gradient g and charge row l [B][nx], prescribed wall fluxes flux [B][N].  Host arithmetic only: the derived arrays are computed
+        64 lanes at a time (cache-sized pieces: the ~20 temporaries of 64 lanes x N x nx stay in L2; pure numpy, so the pieces of a large
+        sweep run on a pool of threads), then the dictionaries are filled; the per-point entries are rows of the pieces' arrays.  (A sweep
+        of 4096 voltages spent 0.5 s here point by point, three times its transport solves.  tests/test_results_io.py walks the
+        reference's plotting accesses over the output without a GPU.)"""
+        B = len(cfin)
+        pieces = [(a, min(a + 64, B)) for a in range(0, B, 64)]
+
+        def derive(ab):
+            a, e = ab
+            return self._alldata_arrays(cfin[a:e], v[a:e], g[a:e], l[a:e], flux[a:e], None if kinetic_flux is None else kinetic_flux[a:e])
+        if len(pieces) > 2:
+            import concurrent.futures
+            with concurrent.futures.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1, len(pieces))) as pool:
+                derived = list(pool.map(derive, pieces))
+        else:
+            derived = [derive(ab) for ab in pieces]
+        for (a, e), arrays in zip(pieces, derived):
+            self._alldata_fill(first + a, arrays, status[a:e])
+
+    def _alldata_arrays(self, cfin, v, g, l, flux, kinetic_flux):
+        """The arrays behind the dictionaries of a piece of the sweep (no shared state: runs on any thread)."""
         tp = self.tp
         from .units import unit_NA
-        if len(cfin) > 64:          # (cache-sized pieces: the ~20 temporaries of 64 lanes x N x nx stay in L2)
-            for a in range(0, len(cfin), 64):
-                e = a + 64
-                self.fill_alldata_batch(cfin[a:e], v[a:e], g[a:e], l[a:e], flux[a:e], status[a:e],
-                                        None if kinetic_flux is None else kinetic_flux[a:e], first=first + a)
-            return
         cfin = np.array(cfin, dtype=float)                      # (own copies: the dictionaries keep rows of these arrays)
         v = np.array(v, dtype=float)
         g = np.asarray(g, float)
         l = np.asarray(l, float)
         flux = np.asarray(flux, float)
         B = cfin.shape[0]
-        keys = list(tp.descriptors.keys())
+        out = {'cfin': cfin, 'v': v, 'efield': -g, 'rho': -l * tp.eps}
+        if not self.physical:
+            return out
         names = list(tp.species.keys())
         radii = np.array([float(tp.species[sp].get('MPB_radius', 0.0)) for sp in names])
-        efield, rho = -g, -l * tp.eps
-        for b in range(B):
-            i = first + b
-            lane = tp.alldata_names[i]
-            d = tp.alldata[i]
-            for k, sp in enumerate(names):
-                d['species'][sp] = {'concentration': cfin[b, k], 'surface_concentration': float(cfin[b, k, 0])}
-            d['system'] = {'potential': v[b], 'efield': efield[b], 'charge_density': rho[b],
-                           'surface_potential': float(v[b, 0]), 'surface_efield': float(efield[b, 0]),
-                           keys[0]: lane[0], keys[1]: lane[1], 'status': int(status[b])}
-        if not self.physical:
-            return
         # derived fields of the COMSOL reader (comsol_reader.py:57-90, :196-230, :241-261)
         gamma = 1.0 / (1.0 - (unit_NA * radii[None, :, None] ** 3 * cfin).sum(axis=1))                 # [B][nx]
-        ers = getattr(tp, 'electrode_reactions', None) or {}
         jwall = flux + (np.asarray(kinetic_flux, float) if kinetic_flux is not None else 0.0)          # [B][N]
-        current = {}
-        for k, sp in enumerate(names):
-            if sp in ers and 'nel' in ers[sp]:          # mA/cm^2, comsol_reader.py:241-246
-                nprod = len([a for a in ers[sp]['reaction'][1] if a == sp])
-                current[sp] = (k, ers[sp]['nel'], nprod)
         with np.errstate(divide='ignore', invalid='ignore'):
             if 'H+' in names:
                 ph = -np.log10(cfin[:, names.index('H+')] / 1000.)
@@ -638,19 +636,47 @@ class Calculator(object):
         cmid = 0.5 * (cfin[:, :, 1:] + cfin[:, :, :-1])
         um = tp.D * tp.beta                                            # mobility D/(RT)
         kappa = unit_F ** 2 * ((z ** 2 * um)[None, :, None] * cmid).sum(axis=1)        # rho_c, S/m
-        w = -np.log(1.0 / gamma)                                                       # -ln(1-phi0)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            w = -np.log(1.0 / gamma)                                                   # -ln(1-phi0)
         u = (tp.charges * tp.beta)[None, :, None] * np.diff(v, axis=1)[:, None, :] + np.diff(w, axis=1)[:, None, :]
         with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
             Bu = np.where(np.abs(u) < 1e-8, 1.0 - 0.5 * u, u / np.expm1(u))
-        Dh = tp.D[None, :, None] / h[None, None, :]
-        jtot = -Dh * ((Bu + u) * cfin[:, :, 1:] - Bu * cfin[:, :, :-1])                # Scharfetter-Gummel flux
-        jdif = -Dh * np.diff(cfin, axis=2)
-        i_el = unit_F * (z[None, :, None] * jtot).sum(axis=1)                          # A/m^2
-        zero = np.zeros((B, 1))
-        with np.errstate(divide='ignore', invalid='ignore'):
+            Dh = tp.D[None, :, None] / h[None, None, :]
+            jtot = -Dh * ((Bu + u) * cfin[:, :, 1:] - Bu * cfin[:, :, :-1])            # Scharfetter-Gummel flux
+            jdif = -Dh * np.diff(cfin, axis=2)
+            i_el = unit_F * (z[None, :, None] * jtot).sum(axis=1)                      # A/m^2
+            zero = np.zeros((B, 1))
             dphi_iR = np.concatenate([zero, np.cumsum(np.where(kappa > 0, -i_el / kappa, 0.0) * h[None, :], axis=1)], axis=1)
             dphi_diff = np.concatenate([zero, np.cumsum(np.where(kappa > 0, unit_F * (z[None, :, None] * jdif).sum(axis=1) / kappa, 0.0)
                                                          * h[None, :], axis=1)], axis=1)
+        out.update(gamma=gamma, jwall=jwall, pH=pH, kappa=kappa, i_el=i_el, dphi_iR=dphi_iR, dphi_diff=dphi_diff)
+        return out
+
+    def _alldata_fill(self, first, A, status):
+        """tp.alldata[first ...] from the arrays of _alldata_arrays (the entries are rows of those arrays)."""
+        tp = self.tp
+        cfin, v, efield, rho = A['cfin'], A['v'], A['efield'], A['rho']
+        B = cfin.shape[0]
+        keys = list(tp.descriptors.keys())
+        names = list(tp.species.keys())
+        for b in range(B):
+            i = first + b
+            lane = tp.alldata_names[i]
+            d = tp.alldata[i]
+            for k, sp in enumerate(names):
+                d['species'][sp] = {'concentration': cfin[b, k], 'surface_concentration': float(cfin[b, k, 0])}
+            d['system'] = {'potential': v[b], 'efield': efield[b], 'charge_density': rho[b],
+                           'surface_potential': float(v[b, 0]), 'surface_efield': float(efield[b, 0]),
+                           keys[0]: lane[0], keys[1]: lane[1], 'status': int(status[b])}
+        if not self.physical:
+            return
+        gamma, jwall, pH, kappa, i_el, dphi_iR, dphi_diff = (A[k] for k in ('gamma', 'jwall', 'pH', 'kappa', 'i_el', 'dphi_iR', 'dphi_diff'))
+        ers = getattr(tp, 'electrode_reactions', None) or {}
+        current = {}
+        for k, sp in enumerate(names):
+            if sp in ers and 'nel' in ers[sp]:          # mA/cm^2, comsol_reader.py:241-246
+                nprod = len([a for a in ers[sp]['reaction'][1] if a == sp])
+                current[sp] = (k, ers[sp]['nel'], nprod)
         es = tp.system.get('Stern epsilon', None)
         for b in range(B):
             d = tp.alldata[first + b]
