@@ -215,7 +215,8 @@ typedef struct pnp_newton_params {
   double dphi_max;           /* potential limiting per iteration (V); <= 0 disables */
   int32_t time_order;        /* pnp_step: 0 or 1 backward Euler (default); 2 = BDF2, the time stepping the reference asks COMSOL for
                               *    (comsol_model.py:518-531: tds time solver, "maxorder" 2): (3 c_n+1 - 4 c_n + c_n-1) / (2 dt), the first
-                              *    step of a trajectory (after pnp_set_batch) backward Euler.  One launch per timestep in this mode. */
+                              *    step of a trajectory (after pnp_set_batch) backward Euler.  The lane kernels keep the history themselves (all timesteps of a
+                              *    call in one launch); the workgroup-per-point kernels take one launch per timestep in this mode. */
   int32_t predictor;         /* pnp_step: 0 every timestep's Newton iteration starts from the previous state (default); 1 from the linear
                               *    extrapolation 2 u_n - u_n-1 of the two previous time levels (concentrations and potential), as a BDF
                               *    time stepper starts its corrector -- same equations and stopping rule, fewer iterations per step.
