@@ -414,6 +414,9 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         s8.set_batch(*inp[1:])
         s8.step(1)
         s8.synchronize()
+        # where the multi-GB workspace of a lane kernel lies decides which of a few discrete rates an HBM-bound launch runs at (DESIGN.md
+        # section 7b): four placements are tried on two timesteps each, the fastest stays (pnp_tune_placement; the state is put back)
+        placement = s8.tune_placement(2, 4)
         warm()
         ms8 = timed_steps(s8, steps, 0)
         it8 = s8.newton_iterations()
@@ -428,7 +431,8 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         alg = lane_bytes(LN, LX, fused)
         rec = {'workload': 'batch=%d, %d species size-modified, %d points, Stern wall, backward Euler: %s' % (LB, LN, LX, what),
                'timesteps_per_s': LB * steps / (ms8 * 1e-3), 'newton_iterations_per_s': its / (ms8 * 1e-3),
-               'mean_newton_iterations_per_step': its / (LB * steps), 'ms_per_step': ms8 / steps, 'lanes_ok': ok8}
+               'mean_newton_iterations_per_step': its / (LB * steps), 'ms_per_step': ms8 / steps, 'lanes_ok': ok8,
+               'workspace_placement_trials_ms_per_step': [round(v, 3) for v in placement]}
         roof = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'algorithmic_bytes_per_lane_iteration': alg,
                 'achieved': alg * its / (ms8 * 1e-3) / 1e9, 'traffic': None,
                 'achieved_is': 'algorithmic bytes per Newton iteration and operating point (state + block-Thomas records, written by the '
@@ -480,6 +484,7 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
             se.set_batch(*inpe[1:])
             se.step(1)
             se.synchronize()
+            se.tune_placement(2, 4)
             warm()
             mse = timed_steps(se, 20, 0)
             ite = se.newton_iterations()
@@ -760,6 +765,7 @@ def main():
             del inp
             s_.step(1)
             s_.synchronize()
+            s_.tune_placement(2, 4)          # (the workspace where it runs fastest: see lane_record)
             warm_clocks()
             t = timed_call(s_, lambda: s_.step(nsteps), lambda: [float(s_.newton_iterations().sum()), float((s_.get_status() == 0).sum())])
             fused = s_.default_family() == 'lane+fused'

@@ -33,7 +33,7 @@ SYMBOLS = [
     'pnp_set_batch', 'pnp_set_flux', 'pnp_set_pb', 'pnp_step', 'pnp_integrate', 'pnp_mol_rhs', 'pnp_integrate_dopri5', 'pnp_integrate_dop853', 'pnp_integrate_rkc', 'pnp_get_state',
     'pnp_get_surface', 'pnp_get_status', 'pnp_synchronize', 'pnp_timer_start', 'pnp_timer_stop',
     'pnp_device_bytes', 'pnp_row_pitch', 'pnp_step_row_chunks', 'pnp_set_newton', 'pnp_solve_stationary', 'pnp_get_newton_iterations',
-    'pnp_set_potential', 'pnp_set_convection', 'pnp_set_option', 'pnp_get_lane_order', 'pnp_autotune', 'pnp_autotune_name', 'pnp_autotune_default', 'pnp_set_lanes', 'pnp_set_lane_mask', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
+    'pnp_set_potential', 'pnp_set_convection', 'pnp_set_option', 'pnp_get_lane_order', 'pnp_autotune', 'pnp_autotune_name', 'pnp_autotune_default', 'pnp_tune_placement', 'pnp_set_lanes', 'pnp_set_lane_mask', 'pnp_set_wall_kinetics', 'pnp_set_wall_rate_law', 'pnp_set_grid', 'pnp_solve_surface', 'pnp_scf_cycle',
 ]
 
 
@@ -160,6 +160,8 @@ def load_library():
     lib.pnp_autotune_name.restype = C.c_char_p
     lib.pnp_autotune_default.argtypes = [vp]
     lib.pnp_autotune_default.restype = C.c_int32
+    lib.pnp_tune_placement.argtypes = [vp, C.c_int32, C.c_int32, dp]
+    lib.pnp_tune_placement.restype = C.c_int
     lib.pnp_solve_surface.argtypes = [vp, dp, C.c_int32, dp, dp, dp, ip]
     lib.pnp_solve_surface.restype = C.c_int
     lib.pnp_scf_cycle.argtypes = [vp, C.POINTER(PnpScfParams), dp, dp, C.POINTER(PnpScfState), ip]
@@ -303,6 +305,13 @@ class PnpSolver(object):
         """Name of the kernel family the library's thresholds choose for the current batch (pnp_autotune_default); None without one."""
         i = int(self._lib.pnp_autotune_default(self._h))
         return None if i < 0 else self._lib.pnp_autotune_name(i).decode()
+
+    def tune_placement(self, nsteps=2, trials=4):
+        """Lane kernels: allocate the workspace up to `trials` times, keep the placement on which `nsteps` timesteps run fastest
+        (pnp_tune_placement); the state is left as it was.  Returns the time per timestep (ms) of the trials that were made."""
+        ms = np.full(int(trials), -1.0)
+        self._check(self._lib.pnp_tune_placement(self._h, int(nsteps), int(trials), _dptr(ms)))
+        return [float(v) for v in ms if v >= 0.0]
 
     def autotune(self, nsteps=2):
         """Physical mode: pick the kernel family by measurement on this device and batch (pnp_autotune).  Returns (name of the chosen

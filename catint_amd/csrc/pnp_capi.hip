@@ -1537,6 +1537,113 @@ int pnp_autotune(pnp_handle* h, int32_t nsteps, double* ms_per_step, int32_t* ch
   return PNP_OK;
 }
 
+// ---- pnp_tune_placement: the lane kernels' workspace put where it runs fastest ----------------------------------------------------------
+// The rate of an HBM-bound lane-kernel launch depends on WHERE its workspace lies in device memory: on some devices one of three
+// discrete values (1.52 / 1.66 / 1.83e6 timesteps/s at 32 768 x 8 x 512), fixed for the lifetime of the allocation, equal between
+// repetitions to 0.3 %, different between allocations of one process (tools/probe/lane_modes2.py, profiles/r04_lane_modes.jsonl;
+// address translation, instruction cache, start phases and the layout of the streams ruled out: profiles/r04_measured_not_taken.txt #11).
+// So: allocate the workspace up to `trials` times (the earlier ones stay allocated meanwhile, so that each lands elsewhere), time
+// `nsteps` timesteps on each from the same state, keep the fastest, free the others.
+int pnp_tune_placement(pnp_handle* h, int32_t nsteps, int32_t trials, double* ms_per_step) {
+  if (!h) return PNP_EINVAL;
+  if (!h->newton) return fail(h, PNP_EINVAL, "pnp_tune_placement: the handle was not created with PNP_METHOD_NEWTON");
+  if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_tune_placement: call pnp_set_batch first");
+  if (nsteps < 1 || nsteps > 64 || trials < 1 || trials > 16) return fail(h, PNP_EINVAL, "pnp_tune_placement: nsteps 1 ... 64, trials 1 ... 16");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  for (int i = 0; i < trials && ms_per_step; ++i) ms_per_step[i] = -1.0;
+  const int N = h->a.N, nx = h->a.nx, ldx = h->a.ldx, nb = N + 1, variant = newton_variant(h);
+  const int64_t B = h->B, n_eff = newton_effective_batch(h);
+  double** bufp = nullptr;
+  int64_t* groupsp = nullptr;
+  size_t per_group = 0;
+  if (newton_lane4_preferred(nb, nx, n_eff, variant, h->opt)) {
+    bufp = &h->lane4_buf, groupsp = &h->lane4_groups, per_group = newton_lane4_rec_doubles(nb, nx) + newton_lane4_state_doubles(nb, nx);
+  } else if (newton_lane2_preferred(nb, nx, n_eff, variant, h->opt)) {
+    bufp = &h->lane2_buf, groupsp = &h->lane2_groups, per_group = newton_lane2_rec_doubles(nb, nx) + newton_lane2_state_doubles(nb, nx);
+  } else if (newton_lane_preferred(nb, nx, n_eff, variant, h->opt)) {
+    bufp = &h->lane_buf, groupsp = &h->lane_groups, per_group = newton_lane_rec_doubles(nb, nx) + newton_lane_state_doubles(nb, nx);
+  }
+  if (!bufp) return PNP_OK;      // (no lane kernel for this batch: nothing to place)
+  const size_t nc = (size_t)B * N * ldx, nv = (size_t)B * ldx;
+  struct Saved {
+    void *live, *kept;
+    size_t bytes;
+  } items[6] = {{h->c, nullptr, nc * sizeof(double)},        {h->v, nullptr, nv * sizeof(double)},
+                {h->c_old2, nullptr, nc * sizeof(double)},  {h->phi_old2, nullptr, nv * sizeof(double)},
+                {h->status, nullptr, (size_t)B * sizeof(int32_t)}, {h->iters, nullptr, (size_t)B * sizeof(int32_t)}};
+  std::vector<double*> held;      // the workspaces of the trials so far
+  auto release = [&]() {      // the snapshot, and every workspace but the one the handle keeps
+    for (auto& it : items)
+      if (it.kept) (void)hipFree(it.kept);
+    for (double* p : held)
+      if (p && p != *bufp) {
+        (void)hipFree(p);
+        h->dev_bytes -= (int64_t)((size_t)*groupsp * per_group * sizeof(double));
+      }
+    held.clear();
+  };
+  for (auto& it : items)
+    if (it.live && hipMalloc(&it.kept, it.bytes) != hipSuccess) {
+      it.kept = nullptr;
+      release();
+      return fail(h, PNP_ENOMEM, "pnp_tune_placement: no memory for the state snapshot");
+    }
+  auto copy = [&](bool back) -> bool {
+    for (auto& it : items)
+      if (it.live && it.kept &&
+          hipMemcpyAsync(back ? it.live : it.kept, back ? it.kept : it.live, it.bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+        return false;
+    return true;
+  };
+  const int64_t steps0 = h->steps_done;
+  const bool hist0 = h->bdf_history, iters0 = h->iters_valid;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = PNP_OK, best_i = -1;
+  double best = 0.0;
+  double* best_buf = *bufp;
+  if (!copy(false) || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(h, PNP_EDEVICE, "pnp_tune_placement: set-up failed");
+  for (int i = 0; i < trials && rc == PNP_OK; ++i) {
+    if (i > 0) *bufp = nullptr;      // the next placement: run_newton allocates on first use, while the earlier workspaces are still there
+    float ms = 0.0f;
+    for (int pass = 0; pass < 2 && rc == PNP_OK; ++pass) {      // (the first pass allocates and warms)
+      h->steps_done = steps0;
+      h->bdf_history = hist0;
+      h->iters_valid = iters0;
+      if (!copy(true)) rc = fail(h, PNP_EDEVICE, "pnp_tune_placement: restoring the state failed");
+      if (rc == PNP_OK && hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(h, PNP_EDEVICE, "pnp_tune_placement: hipEventRecord");
+      if (rc == PNP_OK) rc = newton_timesteps(h, pass == 0 ? 1 : nsteps);
+      if (rc == PNP_OK && (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                           hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
+        rc = fail(h, PNP_EDEVICE, "pnp_tune_placement: timing a trial failed");
+    }
+    if (rc == PNP_ENOMEM && i > 0) {      // no room for another placement: what was measured so far decides
+      rc = PNP_OK;
+      if (*bufp) held.push_back(*bufp);
+      break;
+    }
+    if (rc != PNP_OK) break;
+    held.push_back(*bufp);
+    const double per_step = (double)ms / nsteps;
+    if (ms_per_step) ms_per_step[i] = per_step;
+    if (best_i < 0 || per_step < best) {
+      best = per_step;
+      best_i = i;
+      best_buf = *bufp;
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (*bufp && std::find(held.begin(), held.end(), *bufp) == held.end()) held.push_back(*bufp);      // (a trial that failed after allocating)
+  *bufp = best_buf;
+  h->steps_done = steps0;
+  h->bdf_history = hist0;
+  h->iters_valid = iters0;
+  const bool restored = copy(true) && hipStreamSynchronize(h->stream) == hipSuccess;
+  release();
+  if (!restored) return fail(h, PNP_EDEVICE, "pnp_tune_placement: restoring the state failed");
+  return rc;
+}
+
 int pnp_step(pnp_handle* h, int32_t nsteps, int32_t steps_per_launch) {
   if (!h) return PNP_EINVAL;
   if (!h->have_batch) return fail(h, PNP_ESTATE, "pnp_step: call pnp_set_batch first");

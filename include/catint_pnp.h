@@ -330,6 +330,15 @@ int64_t pnp_get_lane_order(pnp_handle* h, int32_t* perm);
  * (nullable) receives the measured time per timestep of every family, -1 where it does not apply; *chosen (nullable) the index.
  * Families agree to the Newton tolerance, not to the bit: tune once, before the steps whose results are compared.
  * Replaces nothing in the reference (COMSOL picks its own linear solver, comsol_model.py:465-516). */
+/* Physical mode, lane kernels (large batches): put the workspace where it runs fastest.  On some devices the rate of an HBM-bound launch
+ * takes one of a few discrete values that is decided by where its multi-GB workspace lies in device memory -- fixed for the lifetime
+ * of the allocation, different between allocations (1.52 / 1.66 / 1.83e6 timesteps/s at 32 768 x 8 x 512).  The workspace is allocated up
+ * to `trials` times (the earlier ones stay allocated meanwhile, so that each lands elsewhere; a trial that does not fit ends the
+ * search), `nsteps` timesteps are timed on each from the handle's current state -- which is put back afterwards, history, status and
+ * iteration counts included -- the fastest is kept and the others are freed.  ms_per_step[trials] (nullable): time per timestep of
+ * every trial, -1 where none was made.  A batch no lane kernel takes: nothing happens.  No reference counterpart. */
+int pnp_tune_placement(pnp_handle* h, int32_t nsteps, int32_t trials, double* ms_per_step);
+
 #define PNP_AUTOTUNE_CHOICES 8
 const char* pnp_autotune_name(int32_t i);
 int32_t pnp_autotune_default(const pnp_handle* h);      /* index of the family the library's thresholds choose for the current batch; -1: no batch */

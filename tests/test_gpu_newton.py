@@ -225,6 +225,40 @@ def test_kernel_choice_for_large_batches_of_large_blocks(monkeypatch):
     assert np.array_equal(e[0], f[0]) and np.array_equal(e[2], f[2])
 
 
+@pytest.mark.parametrize("kernel,B", [('lane4', 1536), ('lane', 2100), ('', 40)])
+def test_tune_placement_keeps_the_trajectory_and_the_memory(kernel, B, monkeypatch):
+    """pnp_tune_placement: the lane kernels' workspace is allocated several times, a few timesteps are timed on each placement from the
+    handle's state, the fastest placement stays and the others are freed.  Where the workspace lies changes no number: state, history,
+    status and iteration counts are as before the call, the steps after it continue the trajectory to the bit, and the handle holds as
+    much device memory as before.  A batch that no lane kernel takes is left alone."""
+    monkeypatch.setenv('CATINT_NEWTON_KERNEL', kernel)
+    N, nx = 6, 64
+    D, q, cb, dx, phiM = make_lanes(N, nx, B, 13)
+    c0 = np.repeat(cb[:, :, None], nx, axis=2)
+    pb = np.zeros((B, 4))
+    pb[:, 0] = phiM
+    dt = 0.2 * (6 * dx) * (nx * dx) / D.max()
+    kw = dict(wall_bc='stern', stern_capacitance=0.25, mpb_radius=[3.5e-10] * N, time_order=2)
+
+    def run(tune):
+        with _capi.PnpSolver(N, nx, dx, dt, BETA, EPS, D, q, method='Newton', batch_capacity=B) as s:
+            s.set_newton(**kw)
+            s.set_batch(c0, pb, np.zeros(B), np.zeros((B, N)))
+            s.step(2)
+            if tune:
+                before = (s.get_state()[0].copy(), s.get_state()[1].copy(), s.newton_iterations().copy(), s.device_bytes)
+                ms = s.tune_placement(2, 3)
+                assert len(ms) == (3 if kernel else 0) and all(v > 0 for v in ms)
+                assert np.array_equal(before[0], s.get_state()[0]) and np.array_equal(before[1], s.get_state()[1])
+                assert np.array_equal(before[2], s.newton_iterations()) and s.device_bytes <= before[3] + 16 * B
+            s.step(3)
+            assert (s.get_status() == 0).all()
+            return s.get_state()[0], s.get_state()[1], s.newton_iterations()
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("N,nx,B,family", [
     (8, 16, 512, 'workgroup'), (8, 16, 1024, 'lane4'), (8, 16, 8192, 'lane4'), (8, 16, 10240, 'lane2'), (8, 16, 16384, 'lane2'),
     (8, 16, 16385, 'lane+fused'), (6, 16, 13311, 'lane2'), (6, 16, 13312, 'lane+fused'), (7, 16, 13311, 'lane2'), (7, 16, 13312, 'lane+fused'), (5, 16, 10239, 'lane4'), (5, 16, 10240, 'lane+fused'),
