@@ -1603,7 +1603,14 @@ int pnp_tune_placement(pnp_handle* h, int32_t nsteps, int32_t trials, double* ms
   double* best_buf = *bufp;
   if (!copy(false) || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(h, PNP_EDEVICE, "pnp_tune_placement: set-up failed");
   for (int i = 0; i < trials && rc == PNP_OK; ++i) {
-    if (i > 0) *bufp = nullptr;      // the next placement: run_newton allocates on first use, while the earlier workspaces are still there
+    if (i > 0) {
+      // the next placement: run_newton allocates on first use, while the earlier workspaces are still there -- if the device has room for
+      // it twice over (other handles and other processes on the device allocate too), else what was measured so far decides
+      size_t free_b = 0, total_b = 0;
+      const size_t W = (size_t)*groupsp * per_group * sizeof(double);
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * W + ((size_t)4 << 30)) break;
+      *bufp = nullptr;
+    }
     float ms = 0.0f;
     for (int pass = 0; pass < 2 && rc == PNP_OK; ++pass) {      // (the first pass allocates and warms)
       h->steps_done = steps0;
