@@ -18,6 +18,10 @@ def main():
         N, nx, B, steps = (int(v) for v in spec.split())
         s, inp = bench.newton_solver(B, N, nx, 4446, 0, steric=True)
         rates = []
+        if os.environ.get('LANE_RATE_TUNE'):          # (the workspace placed first: pnp_tune_placement)
+            s.set_batch(*inp[1:])
+            s.step(1)
+            s.tune_placement(2, 4)
         for _ in range(3):
             s.set_batch(*inp[1:])
             s.step(1)
