@@ -415,8 +415,8 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
         s8.step(1)
         s8.synchronize()
         # where the multi-GB workspace of a lane kernel lies decides which of a few discrete rates an HBM-bound launch runs at (DESIGN.md
-        # section 7b): four placements are tried on two timesteps each, the fastest stays (pnp_tune_placement; the state is put back)
-        placement = s8.tune_placement(2, 4)
+        # section 7b): up to six placements are tried on two timesteps each, the fastest stays (pnp_tune_placement; the state is put back)
+        placement = s8.tune_placement(2, 6)
         warm()
         ms8 = timed_steps(s8, steps, 0)
         it8 = s8.newton_iterations()
@@ -484,7 +484,7 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
             se.set_batch(*inpe[1:])
             se.step(1)
             se.synchronize()
-            se.tune_placement(2, 4)
+            se.tune_placement(2, 6)
             warm()
             mse = timed_steps(se, 20, 0)
             ite = se.newton_iterations()
@@ -765,7 +765,7 @@ def main():
             del inp
             s_.step(1)
             s_.synchronize()
-            s_.tune_placement(2, 4)          # (the workspace where it runs fastest: see lane_record)
+            s_.tune_placement(2, 6)          # (the workspace where it runs fastest: see lane_record)
             warm_clocks()
             t = timed_call(s_, lambda: s_.step(nsteps), lambda: [float(s_.newton_iterations().sum()), float((s_.get_status() == 0).sum())])
             fused = s_.default_family() == 'lane+fused'

@@ -370,10 +370,10 @@ class Calculator(object):
             solver.set_batch(c0, pb, vz, flux)
             self._apply_surface_kinetics(solver, phiM)
             nk_ = getattr(self.tp, 'newton', {})
-            # (a long run of a large batch: the lane kernels' workspace goes where it runs fastest first -- pnp_tune_placement, four
+            # (a long run of a large batch: the lane kernels' workspace goes where it runs fastest first -- pnp_tune_placement, up to six
             # placements on two timesteps each, the state is put back; tp.newton['tune_placement'] forces it on or off)
             if nk_.get('tune_placement', B >= 16384 and self.tp.nt - 1 >= 40) and hasattr(solver, 'tune_placement'):
-                solver.tune_placement(2, 4)
+                solver.tune_placement(2, 6)
             solver.step(self.tp.nt - 1)
             return solver.get_status()
         nk = getattr(self.tp, 'newton', {})
