@@ -267,6 +267,8 @@ class Calculator(object):
                      # time-dependent mode: tp.newton['time_order'] = 2 steps with BDF2, the formula the reference's transient study
                      # asks COMSOL for (comsol_model.py:518-531: BDF, maxorder 2); default backward Euler
                      time_order=int(nk.get('time_order', 1)))
+        if nk.get('records') in ('f32', 'f64'):          # tp.newton['records'] = 'f32': the lane kernel's record columns in single precision
+            s.set_option('LANE_RECORDS', nk['records'])
         if xmesh is not None:
             s.set_grid(xmesh)
         elif not getattr(tp, 'mesh_uniform', True):

@@ -138,6 +138,7 @@ static bool option_assign(Options& o, const char* key_in, const char* value) {
   else if (key == "LANE_PIVOT_LIMIT") o.lane_pivot_limit = atof(value);
   else if (key == "LANE_ORDER") o.lane_order = iv;
   else if (key == "LANE_STAGGER") o.lane_stagger = iv;
+  else if (key == "LANE_RECORDS") o.lane_records_f32 = (value[0] == 'f' && value[1] == '3') ? 1 : 0;
   else if (key == "LANE_FUSED") o.lane_fused = value[0] ? (iv != 0 ? 1 : 0) : -1;
   else if (key == "PNP_KERNEL") o.pnp_kernel = iv;
   else if (key == "PNP_WAVES_PER_GRID") o.pnp_waves_per_grid = iv;
@@ -151,7 +152,7 @@ static bool option_assign(Options& o, const char* key_in, const char* value) {
 }
 
 static const char* const kOptionKeys[] = {"NEWTON_KERNEL", "NEWTON_EXCHANGE", "NEWTON_TEAM_THREADS", "NEWTON_REGS", "NEWTON_BLOCKS",
-                                          "NEWTON_LANE_GROUPS", "NEWTON_SWEEP_BLOCKS", "LANE_PIVOT_LIMIT", "LANE_ORDER", "LANE_STAGGER", "LANE_FUSED", "PNP_KERNEL",
+                                          "NEWTON_LANE_GROUPS", "NEWTON_SWEEP_BLOCKS", "LANE_PIVOT_LIMIT", "LANE_ORDER", "LANE_STAGGER", "LANE_FUSED", "LANE_RECORDS", "PNP_KERNEL",
                                           "PNP_WAVES_PER_GRID", "PNP_SPECIES_PER_WAVE", "PNP_STEP_STREAMS", "PNP_ALTERNATE_ROWS",
                                           "PNP_ST_WAVES_PER_CU", "PNP_NO_POST_UPLOAD_DISPATCH"};
 

@@ -191,12 +191,21 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
 }
 
 // ---- the solver ---------------------------------------------------------------------------------------------------------------
-template <int NB, int MODE, bool FUSED>
+// R32 (option LANE_RECORDS = f32, FUSED only): the columns T of the record travel in SINGLE precision -- t, the elimination, the
+// residual and everything else stay double.  The back-substitution x_i = t_i - T_i x_i+1 then carries a relative error of ~1e-7 into the
+// Newton UPDATE, not into the solution: the next residual is exact, so the iteration converges to the same state (oracle arithmetic,
+// tools/probe/f32_records_oracle.py: the same iteration counts on the bench workload and states equal to 5e-16) while a row moves 46 x
+// 8 + 84 x 4 bytes of record instead of 90 x 8 each way: 171 instead of 215 doubles per row and iteration.
+template <int NB, int MODE, bool FUSED, bool R32 = false>
 __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
+  static_assert(!R32 || FUSED, "single-precision records: the fused kernel only");
   constexpr int N = NB - 1, NREC = NB * NB + NB;
   constexpr int VP = (NB + 1) / 2, CP = (N + 1) / 2, RP = NREC / 2;     // 16-byte pairs per row: state / previous level / record
   constexpr bool MPB = MODE >= 1;
   constexpr bool FULL = MODE == 2;           // + homogeneous reactions (G.rt) and a constant convection velocity (G.pe); steric code path
+  // R32 record of a row, in 16-byte units: TP pairs of doubles (t, padded), then the NB * NB entries of T as floats, four to a unit
+  constexpr int TP = (NB + 1) / 2, TF = (NB * NB + 3) / 4, RQ = R32 ? TP + TF : RP;      // RQ: units a row's record takes
+  typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ double s_cb[N][LG];             // bulk concentrations of the wave's operating points
   // The record a row hands to the next one (T, t) and the LU factors of D' do not both fit the register file next to everything
   // else once the blocks are 8 x 8 or 9 x 9: the first TL columns of T then live in LDS (written as they are solved, read back
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   auto XS = [&](int i, int p) -> d2& { return xs[((size_t)i * VP + p) * LG]; };       // (!FUSED: the Newton update; cur stays 0)
   auto CO = [&](int i, int p) -> d2& { return tco[((size_t)i * CP + p) * LG]; };
   auto CN = [&](int i, int p) -> d2& { return tcn[((size_t)i * CP + p) * LG]; };
-  auto REC = [&](int i, int p) -> d2& { return rec[((size_t)i * RP + p) * LG]; };
+  auto REC = [&](int i, int p) -> d2& { return rec[((size_t)i * RQ + p) * LG]; };
   const double phiM = G.pb[b * 4 + 0], phiB = G.pb[b * 4 + 1];
   if (!side) {
 #pragma unroll
@@ -617,6 +626,12 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
             double col[NB];
 #pragma unroll
             for (int r = 0; r < NB; ++r)
+              if constexpr (R32) {      // t: doubles in the first TP units; T[j][r]: float j * NB + r behind them
+                col[r] = j < TL ? s_T[(j < TL ? j : 0) * NB + r][lane + 32]
+                         : j == NB ? __hip_atomic_load((const double*)&REC(m + 1, r >> 1) + (r & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : (double)__hip_atomic_load((const float*)&REC(m + 1, TP + ((j < NB ? j : 0) * NB + r) / 4) + (((j < NB ? j : 0) * NB + r) & 3),
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              } else
               col[r] = j < TL ? s_T[(j < TL ? j : 0) * NB + r][lane + 32]
                               : __hip_atomic_load((const double*)&REC(m + 1, ((j < NB ? NB + j * NB : 0) + r) >> 1) + (((j < NB ? NB + j * NB : 0) + r) & 1),
                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (j == NB: the partner's t)
@@ -672,14 +687,31 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         // the record leaves in the order it is produced -- t, then the columns of T -- as 16-byte pairs: an element with an even
         // index waits for its odd neighbour
         double held = 0.0;
+        f4 heldf = {0.0f, 0.0f, 0.0f, 0.0f};
         auto put = [&](const int e, double v) {
-          if ((e & 1) == 0) {
-            held = v;
+          if constexpr (R32) {
+            if (e < NB) {                      // t: pairs of doubles, the odd one out with a zero
+              if ((e & 1) == 0) held = v;
+              if ((e & 1) == 1 || e == NB - 1) {
+                d2 pr;
+                pr[0] = held;
+                pr[1] = (e & 1) ? v : 0.0;
+                __builtin_nontemporal_store(pr, &REC(i, e >> 1));
+              }
+            } else {                           // T: four floats to a unit
+              const int f = e - NB;
+              heldf[f & 3] = (float)v;
+              if ((f & 3) == 3 || f == NB * NB - 1) __builtin_nontemporal_store(heldf, (f4*)&REC(i, TP + f / 4));
+            }
           } else {
-            d2 pr;
-            pr[0] = held;
-            pr[1] = v;
-            __builtin_nontemporal_store(pr, &REC(i, e >> 1));      // (read back a whole pass later: no reason to keep the line)
+            if ((e & 1) == 0) {
+              held = v;
+            } else {
+              d2 pr;
+              pr[0] = held;
+              pr[1] = v;
+              __builtin_nontemporal_store(pr, &REC(i, e >> 1));      // (read back a whole pass later: no reason to keep the line)
+            }
           }
         };
         solve(rhs, 0);
@@ -773,11 +805,11 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
         const int nu_ = (n_dn > m ? n_dn : m) + 1;
         auto row_of = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 1) : (s <= m ? m - s : 0); };
         auto rec_of = [&](int s) { return side ? (s < n_dn ? m + 1 + s : nx - 2) : (s >= 1 && s <= m ? m - s : 0); };   // (a valid row where none is needed)
-        d2 Rn[RP], cn2[VP];
+        d2 Rn[RQ], cn2[VP];
         {
           const int i = row_of(0), ir = rec_of(0);
 #pragma unroll
-          for (int p = 0; p < RP; ++p) Rn[p] = __builtin_nontemporal_load(&REC(ir, p));
+          for (int p = 0; p < RQ; ++p) Rn[p] = __builtin_nontemporal_load(&REC(ir, p));
 #pragma unroll
           for (int p = 0; p < VP; ++p) cn2[p] = TS(i, p);
         }
@@ -785,25 +817,35 @@ __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
           const bool act = side ? s <= n_dn : s <= m;
           const bool special = side ? s == n_dn : s == 0;      // the row without a record
           const int i = row_of(s);
-          d2 R[RP], c2[VP];
+          d2 R[RQ], c2[VP];
 #pragma unroll
-          for (int p = 0; p < RP; ++p) R[p] = Rn[p];
+          for (int p = 0; p < RQ; ++p) R[p] = Rn[p];
 #pragma unroll
           for (int p = 0; p < VP; ++p) c2[p] = cn2[p];
           if (s + 1 < nu_) {
             const int in = row_of(s + 1), irn = rec_of(s + 1);
 #pragma unroll
-            for (int p = 0; p < RP; ++p) Rn[p] = __builtin_nontemporal_load(&REC(irn, p));
+            for (int p = 0; p < RQ; ++p) Rn[p] = __builtin_nontemporal_load(&REC(irn, p));
 #pragma unroll
             for (int p = 0; p < VP; ++p) cn2[p] = TS(in, p);
           }
           double y[NB];
 #pragma unroll
           for (int r = 0; r < NB; ++r) y[r] = R[r >> 1][r & 1];
+          if constexpr (R32) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+              for (int r = 0; r < NB; ++r) {
+                const f4 q = __builtin_bit_cast(f4, R[TP + (j * NB + r) / 4]);
+                y[r] = __builtin_fma(-(double)q[(j * NB + r) & 3], x[j], y[r]);
+              }
+          } else {
 #pragma unroll
           for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < NB; ++r) y[r] = __builtin_fma(-R[(NB + j * NB + r) >> 1][(NB + j * NB + r) & 1], x[j], y[r]);
+          }
           if (act) {
             double cc_[N], cn[N];
 #pragma unroll
@@ -1151,7 +1193,17 @@ static hipError_t launch_lane_nb(const NewtonArgs& a0, hipStream_t stream) {
     const int mode = (a.rt || a.convect) ? 2 : (a.mpb ? 1 : 0);
     const dim3 gk((unsigned)ng), bk(64);
     if (fused) {
-      if (mode == 2) hipLaunchKernelGGL((newton_lane_kernel<NB, 2, true>), gk, bk, 0, stream, a);
+      bool launched = false;
+      if constexpr (NB >= 6) {      // (the blocks of the HBM-bound shapes: N = 5 ... 8)
+        if (a.opt && a.opt->lane_records_f32 > 0) {
+          if (mode == 2) hipLaunchKernelGGL((newton_lane_kernel<NB, 2, true, true>), gk, bk, 0, stream, a);
+          else if (mode == 1) hipLaunchKernelGGL((newton_lane_kernel<NB, 1, true, true>), gk, bk, 0, stream, a);
+          else hipLaunchKernelGGL((newton_lane_kernel<NB, 0, true, true>), gk, bk, 0, stream, a);
+          launched = true;
+        }
+      }
+      if (launched) {
+      } else if (mode == 2) hipLaunchKernelGGL((newton_lane_kernel<NB, 2, true>), gk, bk, 0, stream, a);
       else if (mode == 1) hipLaunchKernelGGL((newton_lane_kernel<NB, 1, true>), gk, bk, 0, stream, a);
       else hipLaunchKernelGGL((newton_lane_kernel<NB, 0, true>), gk, bk, 0, stream, a);
     } else {

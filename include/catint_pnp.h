@@ -93,7 +93,8 @@ const char* pnp_last_error(const pnp_handle* h); /* h may be NULL: last create()
 const char* pnp_version(void);
 
 /* Debug / tuning switch of one handle: which kernel family runs, workspace sizes, probes.  key = the name of the environment variable
- * without its CATINT_ prefix (NEWTON_KERNEL = auto | generic | team | sweep | both | lane | lane2 | lane4 | workgroup, LANE_FUSED,
+ * without its CATINT_ prefix (NEWTON_KERNEL = auto | generic | team | sweep | both | lane | lane2 | lane4 | workgroup, LANE_FUSED, LANE_RECORDS = f64 | f32 (the
+ * columns T of the lane kernel's block-Thomas records in single precision: an inexact Newton update, the same converged state),
  * NEWTON_TEAM_THREADS, NEWTON_REGS, NEWTON_BLOCKS, NEWTON_LANE_GROUPS, NEWTON_SWEEP_BLOCKS, LANE_PIVOT_LIMIT, LANE_ORDER, PNP_KERNEL, PNP_WAVES_PER_GRID,
  * PNP_SPECIES_PER_WAVE, PNP_STEP_STREAMS, PNP_ALTERNATE_ROWS, PNP_ST_WAVES_PER_CU, PNP_NO_POST_UPLOAD_DISPATCH).  The environment is
  * read once, in pnp_create, as the defaults of the new handle; the library never reads it afterwards, so handles in one process

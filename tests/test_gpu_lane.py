@@ -354,6 +354,48 @@ def test_update_fused_into_the_back_substitution_and_separate_passes_are_the_sam
     assert np.array_equal(got[0], outs[0][0])
 
 
+@pytest.mark.parametrize("N,nx,B,kw", [
+    (5, 70, 37, {}),
+    (6, 96, 70, {'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 6}),
+    (7, 51, 35, {'mpb_radius': [3.5e-10] * 7}),
+    (8, 65, 37, {'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 8}),
+    (8, 64, 35, {'time_order': 2, 'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 8}),
+])
+def test_record_columns_in_single_precision_give_the_same_iteration(N, nx, B, kw, monkeypatch):
+    """Option LANE_RECORDS = f32: the columns T of the block-Thomas records travel as floats (t, the elimination and the residual stay
+    double).  The back-substitution then puts a relative error of ~1e-7 into the Newton UPDATE; the next residual is exact, so the
+    iteration ends on the same state: against the oracle -- which solves its linear systems in double throughout -- states within the
+    suite's bound and the oracle's iteration counts (one more iteration in a few operating points whose last update lands a hair above
+    the tolerance), on timesteps from the bulk state (damped first iterations) and on a stationary solve; and the states of the two
+    record formats agree below the Newton tolerance."""
+    D, q, cb, dx, phiM = make_lanes(N, nx, 4, 29)
+    dt = 0.3 * (6 * dx) * (nx * dx) / D.max()
+    monkeypatch.setenv('CATINT_LANE_RECORDS', 'f64')
+    ref64, _ = run_both(N, nx, B=B, seed=29, dt=dt, nsteps=4, stationary=False, newton_kw=kw)
+    def close_with_counts_at_most_one_apart(got, ref):
+        # (an update that lands a hair above the tolerance costs the inexact solve one more iteration now and then: the counts are the
+        #  oracle's in all but a few operating points, never more than one apart; the states are held to the suite's bound as always)
+        c, phi, its, st = got
+        rc, rphi, rit = ref
+        assert np.all(st == 0), st
+        cscale = np.abs(rc).max(axis=2, keepdims=True)
+        assert np.abs(c - rc).max() <= 2e-9 * cscale.max() and (np.abs(c - rc) / (np.abs(rc) + 1e-3 * cscale)).max() < 1e-6
+        assert np.abs(phi - rphi).max() <= 2e-9 * max(np.abs(rphi).max(), 0.025)
+        d = np.abs(its.astype(int) - np.asarray(rit, int))
+        assert d.max() <= 1 and (d != 0).mean() <= 0.1, (its, rit)
+    monkeypatch.setenv('CATINT_LANE_RECORDS', 'f32')
+    got, ref = run_both(N, nx, B=B, seed=29, dt=dt, nsteps=4, stationary=False, newton_kw=kw)
+    close_with_counts_at_most_one_apart(got, ref)
+    assert not np.array_equal(got[0], ref64[0])                      # (another linear solve: not the same bits)
+    assert np.abs(got[0] - ref64[0]).max() <= 1e-9 * np.abs(ref64[0]).max() and np.abs(got[1] - ref64[1]).max() <= 1e-10
+    if 'time_order' not in kw:
+        got, ref = run_both(N, nx, B=B, seed=31, newton_kw=kw)       # stationary
+        close_with_counts_at_most_one_apart(got, ref)
+    if N == 6:                                                        # homogeneous reactions + convection: the MODE 2 instances
+        got, ref = run_both(N, nx, B=B, seed=41, reactions=RX6, newton_kw=kw, dt=1e-7, nsteps=3, stationary=False, velocity=1e-4)
+        close_with_counts_at_most_one_apart(got, ref)
+
+
 @pytest.mark.parametrize("kernel,N,nx", [('lane', 3, 96), ('lane', 8, 64), ('lane2', 6, 80), ('lane2', 8, 48), ('lane4', 5, 80), ('lane4', 8, 48)])
 def test_error_estimate_stopping_rule(kernel, N, nx, monkeypatch):
     """pnp_newton_params.error_estimate: accept an iterate whose quadratic error estimate upd^2 / upd_prev is below the tolerance (saves
