@@ -492,7 +492,7 @@ def physical_mode(args, device, with_cpu, pmc, warm=lambda: None):
             del inpf
             sub[tag] = {'timesteps_per_s': EB * est / (msf * 1e-3), 'mean_newton_iterations_per_step': float(itf.sum()) / (EB * est),
                         'lanes_ok': okf}
-        sub['note'] = ('opt-in: 171 instead of 215 doubles per grid row and Newton iteration through HBM; same iteration counts in all but '
+        sub['note'] = ('opt-in: 139 instead of 215 doubles per grid row and Newton iteration through HBM; same iteration counts in all but '
                        '~0.4 % of the operating points (one more iteration), final states equal to 1e-15 (tools/probe/f32_records_probe.py)')
         if isinstance(out.get(key), dict) and 'error' not in out[key]:
             out[key]['with_f32_record_columns'] = sub

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void lane_transpose_kernel(const NewtonArgs G)
 // residual and everything else stay double.  The back-substitution x_i = t_i - T_i x_i+1 then carries a relative error of ~1e-7 into the
 // Newton UPDATE, not into the solution: the next residual is exact, so the iteration converges to the same state (oracle arithmetic,
 // tools/probe/f32_records_oracle.py: the same iteration counts on the bench workload and states equal to 5e-16) while a row moves 46 x
-// 8 + 84 x 4 bytes of record instead of 90 x 8 each way: 171 instead of 215 doubles per row and iteration.
+// 8 + 84 x 4 bytes of record instead of 90 x 8 each way: 139 instead of 215 doubles per row and iteration.
 template <int NB, int MODE, bool FUSED, bool R32 = false>
 __global__ __launch_bounds__(64) void newton_lane_kernel(const NewtonArgs G) {
   static_assert(!R32 || FUSED, "single-precision records: the fused kernel only");
