@@ -13,7 +13,7 @@ namespace pnp {
 enum NewtonKernelChoice { NK_AUTO = 0, NK_GENERIC, NK_TEAM, NK_SWEEP, NK_BOTH, NK_LANE, NK_LANE2, NK_LANE4, NK_WORKGROUP };
 struct Options {
   int newton_kernel = NK_AUTO;       // NEWTON_KERNEL = generic | team | sweep | both | lane | lane2 | lane4 | workgroup (tests, pnp_autotune)
-  int lane_records_f32 = 0;          // LANE_RECORDS = f32: the fused lane kernel keeps the columns T of its records in single precision (N >= 5)
+  int lane_records_f32 = 0;          // LANE_RECORDS = f32: the fused lane kernel keeps the columns T of its records in single precision (N >= 2)
   int lane_fused = -1;               // LANE_FUSED = 0 | 1: the lane kernel with the update inside the back-substitution; -1: by the batch
   int newton_exchange_global = 0;    // NEWTON_EXCHANGE = global: the row-per-thread kernel's buffers in device memory (creation time)
   int newton_team_threads = 0;       // NEWTON_TEAM_THREADS = 256 | 512 | 1024

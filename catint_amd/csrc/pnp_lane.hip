@@ -1194,7 +1194,7 @@ static hipError_t launch_lane_nb(const NewtonArgs& a0, hipStream_t stream) {
     const dim3 gk((unsigned)ng), bk(64);
     if (fused) {
       bool launched = false;
-      if constexpr (NB >= 6) {      // (the blocks of the HBM-bound shapes: N = 5 ... 8)
+      if constexpr (NB >= 3) {
         if (a.opt && a.opt->lane_records_f32 > 0) {
           if (mode == 2) hipLaunchKernelGGL((newton_lane_kernel<NB, 2, true, true>), gk, bk, 0, stream, a);
           else if (mode == 1) hipLaunchKernelGGL((newton_lane_kernel<NB, 1, true, true>), gk, bk, 0, stream, a);

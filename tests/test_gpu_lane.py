@@ -355,6 +355,7 @@ def test_update_fused_into_the_back_substitution_and_separate_passes_are_the_sam
 
 
 @pytest.mark.parametrize("N,nx,B,kw", [
+    (2, 64, 70, {}), (3, 97, 37, {}), (4, 80, 40, {'stern_capacitance': 0.25, 'wall_bc': 'stern'}),
     (5, 70, 37, {}),
     (6, 96, 70, {'stern_capacitance': 0.25, 'wall_bc': 'stern', 'mpb_radius': [3.5e-10] * 6}),
     (7, 51, 35, {'mpb_radius': [3.5e-10] * 7}),
